@@ -1,0 +1,363 @@
+"""ctypes binding of ``libchessvision_hip.so`` + the model objects ChessVision plugs in.
+
+The reference keeps two opaque callables in ``ChessVision._board_extractor`` / ``._classifier`` and only
+ever does ``obj(tensor)``, ``obj.eval()``, ``obj.to(device)`` and ``hasattr(obj, "metadata")``
+(reference ``chessvision/core.py:53-54,105-106,149-150,220,241``); its YOLO wrappers
+(``chessvision/utils.py:205-227,257-278``) show the accepted duck type.  ``HipBoardExtractor`` and
+``HipPieceClassifier`` follow that protocol and route the forward pass through the C ABI declared in
+``include/chessvision_hip.h``.  PyTorch is used for device memory and streams only.
+
+There is NO CPU fallback: if the shared library or a gfx950 device is missing, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from pathlib import Path
+from typing import Mapping
+
+import numpy as np
+import torch
+
+_LIB_NAME = "libchessvision_hip.so"
+PREC_F32, PREC_F16 = 0, 1
+_PRECISIONS = {"f32": PREC_F32, "fp32": PREC_F32, "float32": PREC_F32, "f16": PREC_F16, "fp16": PREC_F16,
+               "float16": PREC_F16}
+
+
+class HipBackendError(RuntimeError):
+    """Raised for every non-zero status of the C ABI (message = ``cv_last_error()``)."""
+
+
+class _Param(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char_p), ("data", ctypes.POINTER(ctypes.c_float)), ("ndim", ctypes.c_int32),
+                ("shape", ctypes.c_int64 * 4)]
+
+
+def library_path() -> Path:
+    env = os.environ.get("CHESSVISION_HIP_LIB")
+    if env:
+        return Path(env)
+    return Path(__file__).resolve().parent.parent / "lib" / _LIB_NAME
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+# (name, restype, argtypes) for every symbol include/chessvision_hip.h declares
+_vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+_fp = ctypes.POINTER(ctypes.c_float)
+SYMBOLS = [
+    ("cv_abi_version", _i, []),
+    ("cv_last_error", ctypes.c_char_p, []),
+    ("cv_device_count", _i, [ctypes.POINTER(_i)]),
+    ("cv_engine_create", _i, [_i, _i, ctypes.POINTER(_vp)]),
+    ("cv_engine_destroy", _i, [_vp]),
+    ("cv_load_unet", _i, [_vp, ctypes.POINTER(_Param), _i]),
+    ("cv_load_resnet18", _i, [_vp, ctypes.POINTER(_Param), _i]),
+    ("cv_engine_set_chunk", _i, [_vp, _i, _i]),
+    ("cv_unet_forward", _i, [_vp, _vp, _i, _vp, _vp]),
+    ("cv_resnet18_forward", _i, [_vp, _vp, _i, _vp, _vp]),
+    ("cv_unet_forward_u8", _i, [_vp, _vp, _i, _vp, _vp, _f, _vp]),
+    ("cv_resnet18_forward_u8", _i, [_vp, _vp, _i, _vp, _vp]),
+    ("cv_softmax13", _i, [_vp, _vp, _i, _vp, _vp]),
+    ("cv_get_activation", _i, [_vp, ctypes.c_char_p, ctypes.c_char_p, _fp, ctypes.c_size_t,
+                               ctypes.POINTER(ctypes.c_int64)]),
+    ("cv_model_macs", _i, [_vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64)]),
+    ("cv_profile_convs", _i, [_vp, ctypes.c_char_p, _vp, _i, _vp, _i, _vp, ctypes.POINTER(_f),
+                              ctypes.POINTER(_i), ctypes.POINTER(_f)]),
+    ("cv_profile_entry", _i, [_vp, _i, ctypes.c_char_p, _i, ctypes.POINTER(_f), ctypes.POINTER(ctypes.c_double),
+                              ctypes.POINTER(_i)]),
+    ("cv_op_conv2d", _i, [_vp, _vp, _i, _i, _i, _i, _fp, _i, _i, _i, _fp, _fp, _vp, _i, _vp, _vp]),
+    ("cv_op_conv_transpose2x2", _i, [_vp, _vp, _i, _i, _i, _i, _fp, _i, _fp, _vp, _vp]),
+    ("cv_op_maxpool2x2", _i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    ("cv_op_maxpool3x3s2", _i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    ("cv_op_upsample_bilinear2x", _i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    ("cv_selftest_mfma", _i, [_vp, ctypes.POINTER(_f), ctypes.POINTER(_f)]),
+]
+
+
+def load_library():
+    """dlopen the C-ABI library (built by ``__graft_entry__.build()``); raises if it is missing."""
+    global _lib
+    with _lib_lock:
+        if _lib is None:
+            path = library_path()
+            if not path.exists():
+                raise HipBackendError(
+                    f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+            lib = ctypes.CDLL(str(path))
+            for name, restype, argtypes in SYMBOLS:
+                fn = getattr(lib, name)            # AttributeError if the export is missing
+                fn.restype = restype
+                fn.argtypes = argtypes
+            if lib.cv_abi_version() != 1:
+                raise HipBackendError("libchessvision_hip ABI version mismatch")
+            _lib = lib
+    return _lib
+
+
+def _check(status: int) -> None:
+    if status != 0:
+        msg = load_library().cv_last_error()
+        raise HipBackendError(f"[cv status {status}] {msg.decode(errors='replace') if msg else 'unknown error'}")
+
+
+def _stream_ptr(device: torch.device) -> int:
+    return int(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _ptr(t: torch.Tensor) -> int:
+    return int(t.data_ptr())
+
+
+def _np_f32(a) -> np.ndarray:
+    if isinstance(a, torch.Tensor):
+        a = a.detach().to("cpu", torch.float32).numpy()
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _as_param_table(state_dict: Mapping[str, object]):
+    keep = []                                   # keeps numpy buffers alive during the call
+    entries = []
+    for key, value in state_dict.items():
+        if key.endswith("num_batches_tracked"):
+            continue
+        arr = _np_f32(value)
+        if arr.ndim > 4:
+            raise HipBackendError(f"state-dict entry {key} has {arr.ndim} dims")
+        keep.append(arr)
+        shape = (ctypes.c_int64 * 4)(*(list(arr.shape) + [0] * (4 - arr.ndim)))
+        entries.append(_Param(key.encode(), arr.ctypes.data_as(_fp), arr.ndim, shape))
+    table = (_Param * len(entries))(*entries)
+    return table, len(entries), keep
+
+
+class HipEngine:
+    """One engine = one device + one arithmetic precision + packed weights + workspace."""
+
+    def __init__(self, device: torch.device | str | int | None = None, precision: str = "f16",
+                 unet_chunk: int = 0, resnet_chunk: int = 0):
+        self._lib = load_library()
+        if not torch.cuda.is_available():
+            raise HipBackendError("no ROCm device visible to PyTorch: the HIP backend has no CPU fallback")
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if dev.type != "cuda":
+            raise HipBackendError(f"HIP backend needs a cuda(ROCm) device, got {dev}")
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        if precision not in _PRECISIONS:
+            raise HipBackendError(f"precision must be one of {sorted(_PRECISIONS)}")
+        self.device = dev
+        self.precision = "f16" if _PRECISIONS[precision] == PREC_F16 else "f32"
+        self._h = ctypes.c_void_p()
+        _check(self._lib.cv_engine_create(dev.index, _PRECISIONS[precision], ctypes.byref(self._h)))
+        if unet_chunk or resnet_chunk:
+            _check(self._lib.cv_engine_set_chunk(self._h, int(unet_chunk), int(resnet_chunk)))
+        self.has_unet = False
+        self.has_resnet = False
+
+    # -- lifecycle ------------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.cv_engine_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- weights --------------------------------------------------------------------------------
+    def load_unet(self, state_dict: Mapping[str, object]) -> None:
+        table, n, keep = _as_param_table(state_dict)
+        _check(self._lib.cv_load_unet(self._h, table, n))
+        del keep
+        self.has_unet = True
+
+    def load_resnet18(self, state_dict: Mapping[str, object]) -> None:
+        table, n, keep = _as_param_table(state_dict)
+        _check(self._lib.cv_load_resnet18(self._h, table, n))
+        del keep
+        self.has_resnet = True
+
+    # -- forward ----------------------------------------------------------------------------------
+    def _dev_f32(self, x: torch.Tensor, shape_tail) -> torch.Tensor:
+        if not isinstance(x, torch.Tensor):
+            raise HipBackendError("input must be a torch.Tensor")
+        if tuple(x.shape[1:]) != tuple(shape_tail):
+            raise HipBackendError(f"input shape {tuple(x.shape)} != (N,{','.join(map(str, shape_tail))})")
+        return x.to(device=self.device, dtype=torch.float32).contiguous()
+
+    def unet_forward(self, x: torch.Tensor) -> torch.Tensor:
+        """(B,3,256,256) float32 in [0,1] -> (B,1,256,256) float32 logits (device tensor)."""
+        x = self._dev_f32(x, (3, 256, 256))
+        out = torch.empty((x.shape[0], 1, 256, 256), dtype=torch.float32, device=self.device)
+        _check(self._lib.cv_unet_forward(self._h, _ptr(x), x.shape[0], _ptr(out), _stream_ptr(self.device)))
+        return out
+
+    def resnet18_forward(self, x: torch.Tensor) -> torch.Tensor:
+        """(N,1,64,64) float32 in [0,1] -> (N,13) float32 logits (device tensor)."""
+        x = self._dev_f32(x, (1, 64, 64))
+        out = torch.empty((x.shape[0], 13), dtype=torch.float32, device=self.device)
+        _check(self._lib.cv_resnet18_forward(self._h, _ptr(x), x.shape[0], _ptr(out), _stream_ptr(self.device)))
+        return out
+
+    def unet_forward_u8(self, x_u8: torch.Tensor, threshold: float = 0.5, want_mask: bool = True):
+        """(B,256,256,3) uint8 HWC -> (logits (B,1,256,256) f32, mask (B,256,256) u8 | None)."""
+        if x_u8.dtype != torch.uint8 or tuple(x_u8.shape[1:]) != (256, 256, 3):
+            raise HipBackendError("unet_forward_u8 expects (B,256,256,3) uint8")
+        x_u8 = x_u8.to(self.device).contiguous()
+        b = x_u8.shape[0]
+        logits = torch.empty((b, 1, 256, 256), dtype=torch.float32, device=self.device)
+        mask = torch.empty((b, 256, 256), dtype=torch.uint8, device=self.device) if want_mask else None
+        _check(self._lib.cv_unet_forward_u8(self._h, _ptr(x_u8), b, _ptr(logits), _ptr(mask) if want_mask else None,
+                                            float(threshold), _stream_ptr(self.device)))
+        return logits, mask
+
+    def resnet18_forward_u8(self, squares_u8: torch.Tensor) -> torch.Tensor:
+        """(N,64,64) uint8 -> (N,13) float32 softmax probabilities."""
+        if squares_u8.dtype != torch.uint8 or tuple(squares_u8.shape[1:]) != (64, 64):
+            raise HipBackendError("resnet18_forward_u8 expects (N,64,64) uint8")
+        squares_u8 = squares_u8.to(self.device).contiguous()
+        n = squares_u8.shape[0]
+        out = torch.empty((n, 13), dtype=torch.float32, device=self.device)
+        _check(self._lib.cv_resnet18_forward_u8(self._h, _ptr(squares_u8), n, _ptr(out), _stream_ptr(self.device)))
+        return out
+
+    def softmax13(self, logits: torch.Tensor) -> torch.Tensor:
+        logits = logits.to(self.device, torch.float32).contiguous()
+        out = torch.empty_like(logits)
+        _check(self._lib.cv_softmax13(self._h, _ptr(logits), logits.shape[0], _ptr(out), _stream_ptr(self.device)))
+        return out
+
+    # -- introspection ----------------------------------------------------------------------------
+    def activation(self, model: str, name: str) -> np.ndarray:
+        dims = (ctypes.c_int64 * 4)()
+        _check(self._lib.cv_get_activation(self._h, model.encode(), name.encode(), None, 0, dims))
+        out = np.empty(tuple(int(d) for d in dims), dtype=np.float32)
+        _check(self._lib.cv_get_activation(self._h, model.encode(), name.encode(), out.ctypes.data_as(_fp), out.size,
+                                           dims))
+        return out
+
+    def model_macs(self, model: str) -> int:
+        v = ctypes.c_int64()
+        _check(self._lib.cv_model_macs(self._h, model.encode(), ctypes.byref(v)))
+        return int(v.value)
+
+    def profile(self, model: str, x: torch.Tensor, iters: int = 1):
+        """Event-time every launch of `iters` forwards; returns (conv_ms, conv_launches, all_ms, entries)."""
+        x = x.to(self.device, torch.float32).contiguous()
+        n = x.shape[0]
+        out = torch.empty((n, 1, 256, 256) if model == "unet" else (n, 13), dtype=torch.float32, device=self.device)
+        conv_ms, all_ms, launches = _f(), _f(), _i()
+        _check(self._lib.cv_profile_convs(self._h, model.encode(), _ptr(x), n, _ptr(out), iters,
+                                          _stream_ptr(self.device), ctypes.byref(conv_ms), ctypes.byref(launches),
+                                          ctypes.byref(all_ms)))
+        entries = []
+        idx = 0
+        name = ctypes.create_string_buffer(128)
+        ms, macs, is_conv = _f(), ctypes.c_double(), _i()
+        while self._lib.cv_profile_entry(self._h, idx, name, 128, ctypes.byref(ms), ctypes.byref(macs),
+                                         ctypes.byref(is_conv)) == 0:
+            entries.append({"name": name.value.decode(), "ms": ms.value, "macs": macs.value, "conv": bool(is_conv.value)})
+            idx += 1
+        return conv_ms.value, launches.value, all_ms.value, entries
+
+    # -- single-layer entry points (parity tests) ------------------------------------------------
+    def op_conv2d(self, x, w, stride=1, scale=None, shift=None, residual=None, relu=False) -> torch.Tensor:
+        x = x.to(self.device, torch.float32).contiguous()
+        w = _np_f32(w)
+        n, cin, h, wd = x.shape
+        cout, _, k, _ = w.shape
+        pad = (k - 1) // 2
+        ho, wo = (h + 2 * pad - k) // stride + 1, (wd + 2 * pad - k) // stride + 1
+        y = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=self.device)
+        sc = _np_f32(scale) if scale is not None else None
+        sh = _np_f32(shift) if shift is not None else None
+        res = residual.to(self.device, torch.float32).contiguous() if residual is not None else None
+        _check(self._lib.cv_op_conv2d(self._h, _ptr(x), n, cin, h, wd, w.ctypes.data_as(_fp), cout, k, stride,
+                                      sc.ctypes.data_as(_fp) if sc is not None else None,
+                                      sh.ctypes.data_as(_fp) if sh is not None else None,
+                                      _ptr(res) if res is not None else None, int(bool(relu)), _ptr(y),
+                                      _stream_ptr(self.device)))
+        return y
+
+    def op_conv_transpose2x2(self, x, w, bias) -> torch.Tensor:
+        x = x.to(self.device, torch.float32).contiguous()
+        w, bias = _np_f32(w), _np_f32(bias)
+        n, cin, h, wd = x.shape
+        cout = w.shape[1]
+        y = torch.empty((n, cout, 2 * h, 2 * wd), dtype=torch.float32, device=self.device)
+        _check(self._lib.cv_op_conv_transpose2x2(self._h, _ptr(x), n, cin, h, wd, w.ctypes.data_as(_fp), cout,
+                                                 bias.ctypes.data_as(_fp), _ptr(y), _stream_ptr(self.device)))
+        return y
+
+    def _op_pool(self, fn, x, ho, wo) -> torch.Tensor:
+        x = x.to(self.device, torch.float32).contiguous()
+        n, c, h, wd = x.shape
+        y = torch.empty((n, c, ho(h), wo(wd)), dtype=torch.float32, device=self.device)
+        _check(fn(self._h, _ptr(x), n, c, h, wd, _ptr(y), _stream_ptr(self.device)))
+        return y
+
+    def op_maxpool2x2(self, x):
+        return self._op_pool(self._lib.cv_op_maxpool2x2, x, lambda h: h // 2, lambda w: w // 2)
+
+    def op_maxpool3x3s2(self, x):
+        return self._op_pool(self._lib.cv_op_maxpool3x3s2, x, lambda h: (h - 1) // 2 + 1, lambda w: (w - 1) // 2 + 1)
+
+    def op_upsample_bilinear2x(self, x):
+        return self._op_pool(self._lib.cv_op_upsample_bilinear2x, x, lambda h: 2 * h, lambda w: 2 * w)
+
+    def selftest_mfma(self):
+        a, b = _f(), _f()
+        _check(self._lib.cv_selftest_mfma(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
+
+class _HipModel:
+    """Common duck-typed module surface: ``__call__``, ``eval``, ``train``, ``to``, ``metadata``."""
+
+    model_name = ""
+
+    def __init__(self, engine: HipEngine, metadata: dict | None = None):
+        self.engine = engine
+        if metadata:
+            self.metadata = metadata
+
+    def eval(self):
+        return self                                    # inference-only engine
+
+    def train(self, mode: bool = True):
+        if mode:
+            raise HipBackendError("the HIP backend is inference-only (reference training is out of scope)")
+        return self
+
+    def to(self, device=None, *_, **__):
+        if device is not None and torch.device(device).type != "cuda":
+            raise HipBackendError(f"HIP model cannot move to {device}: there is no CPU fallback")
+        return self
+
+    def parameters(self):
+        return iter(())
+
+
+class HipBoardExtractor(_HipModel):
+    """UNet(3,1) forward on MI355X; drop-in for ``ChessVision.board_extractor`` (core.py:66-72,220)."""
+
+    model_name = "unet"
+
+    def __call__(self, image_batch: torch.Tensor) -> torch.Tensor:
+        return self.engine.unet_forward(image_batch)
+
+
+class HipPieceClassifier(_HipModel):
+    """ResNet-18 (1ch, 13 classes) forward on MI355X; drop-in for ``ChessVision.classifier`` (core.py:74-82,241)."""
+
+    model_name = "resnet18"
+
+    def __call__(self, batch: torch.Tensor) -> torch.Tensor:
+        return self.engine.resnet18_forward(batch)

@@ -1,0 +1,25 @@
+// conv_igemm.h -- host interface of the implicit-GEMM convolution kernels (conv_igemm.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "cv_kernels.h"
+
+namespace cv {
+
+// Every wave owns a 64-channel slab = kConvFC 16-row MFMA fragments; the host row permutation
+// (engine.cpp: conv_row_to_channel) depends on it.
+constexpr int kConvFC = 4;
+
+enum ConvCfg {            // <channel tile> x <pixel tile> of one 256-thread workgroup
+    kCfg64x256 = 0,       // Cout == 64 layers (full-resolution UNet, ResNet layer1)
+    kCfg64x128 = 1,       // Cout == 64, few pixels
+    kCfg128x128 = 2,      // Cout >= 128, few pixels (deep UNet / ResNet stages)
+    kCfg128x256 = 3,      // Cout >= 128, many pixels
+    kNumConvCfg = 4
+};
+
+hipError_t conv_igemm_prepare();                                   // raise dynamic-LDS limits (once per device)
+hipError_t conv_igemm_launch(int cfg, bool f16, const ConvParams& p, hipStream_t stream);
+int conv_cfg_ct(int cfg);
+int conv_cfg_pt(int cfg);
+
+}  // namespace cv

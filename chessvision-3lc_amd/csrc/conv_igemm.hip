@@ -1,0 +1,288 @@
+// conv_igemm.hip -- implicit-GEMM convolution on MFMA for gfx950 (CDNA4), hand-written.
+//
+// Serves every dense contraction on the ChessVision hot path:
+//   UNet  DoubleConv 3x3 p1 (x18), ConvTranspose2d k2 s2 (x4, as a 1-tap GEMM + pixel-shuffle store)
+//   ResNet-18 3x3 s1/s2 (x16), 1x1 s2 downsample (x3)
+// with BatchNorm(eval) affine, residual add and ReLU fused into the epilogue, so no activation is ever
+// re-read for normalisation (reference: conv2d -> batch_norm -> relu are three torch kernels).
+//
+// GEMM orientation:  D[ch][pix] = sum_k Wt[ch][k] * X[pix][k]      (k = tap-major, channel-minor)
+//   MFMA A operand = weights (rows = output channels), B operand = activations (cols = pixels).
+//   The 16x16 C/D fragment then gives each lane 4 consecutive rows of one pixel; the host packs weight
+//   rows so that a lane's rows across its FC fragments are 4*FC *consecutive channels*, hence every
+//   lane stores 32 B (f16) / 64 B (f32) contiguous NHWC bytes and 4 lanes cover a 128-B line.
+//
+// Staging:  one "stage" = 128 bytes of K per row (64 f16 / 32 f32).  Both operands are brought HBM/L2 ->
+//   LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction, no VGPR round trip) into an
+//   NS-deep ring; one s_barrier per stage, counted s_waitcnt vmcnt(N) so NS-2 stages stay in flight
+//   across the barrier.  Rows are 128 B = 8 x 16-B chunks, chunk c of row r stored at position c^(r&7)
+//   (XOR swizzle applied on the *source* address for activations, pre-applied by the host for weights)
+//   so the ds_read_b128 fragment reads are bank-conflict free.
+//   The activation gather needs no bounds checks: tensors carry a zero border (cv_kernels.h).
+#include "cv_kernels.h"
+#include "conv_igemm.h"
+
+namespace cv {
+
+template <typename T> struct FragT;
+template <> struct FragT<half_t> { typedef half8 V; };
+template <> struct FragT<float>  { typedef f4 V; };
+
+__device__ __forceinline__ void mma16(f4& acc, const half8& a, const half8& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+}
+// f32: one 16-B chunk = 4 k-values per lane; lane group q owns chunk (sub*4+q), MFMA j contracts the
+// j-th value of all four groups.  The k order inside a stage is permuted identically for A and B.
+__device__ __forceinline__ void mma16(f4& acc, const f4& a, const f4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ void glds16(const char* g, char* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+template <int N> __device__ __forceinline__ void wait_vm_barrier() {
+    // every wave: its own DMA of the stage about to be read has landed (all but N younger ones), its
+    // LDS reads of the stage about to be overwritten have returned; then the workgroup rendezvous.
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+template <typename T, int N> struct OutVec;   // N consecutive channels of one pixel -> 16-B stores
+template <int N> struct OutVec<half_t, N> {
+    static __device__ __forceinline__ void store(half_t* dst, const float* v) {
+#pragma unroll
+        for (int i = 0; i < N; i += 8) {
+            half8 h;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) h[j] = (half_t)v[i + j];
+            *reinterpret_cast<half8*>(dst + i) = h;
+        }
+    }
+    static __device__ __forceinline__ void add(const half_t* src, float* v) {
+#pragma unroll
+        for (int i = 0; i < N; i += 8) {
+            const half8 h = *reinterpret_cast<const half8*>(src + i);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[i + j] += (float)h[j];
+        }
+    }
+};
+template <int N> struct OutVec<float, N> {
+    static __device__ __forceinline__ void store(float* dst, const float* v) {
+#pragma unroll
+        for (int i = 0; i < N; i += 4) {
+            f4 o = {v[i], v[i + 1], v[i + 2], v[i + 3]};
+            *reinterpret_cast<f4*>(dst + i) = o;
+        }
+    }
+    static __device__ __forceinline__ void add(const float* src, float* v) {
+#pragma unroll
+        for (int i = 0; i < N; i += 4) {
+            const f4 o = *reinterpret_cast<const f4*>(src + i);
+            v[i] += o[0]; v[i + 1] += o[1]; v[i + 2] += o[2]; v[i + 3] += o[3];
+        }
+    }
+};
+
+// CT x PT = channel x pixel tile of the workgroup (4 waves as WGC x 4/WGC); every wave owns a 64-channel
+// slab (FC = 4 fragments: the row permutation the host packs for) and PT*WGC/4 pixels.
+template <typename T, int CT, int PT, int WGC, int NS>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
+    constexpr int WGP = 4 / WGC;
+    constexpr int WCT = CT / WGC, WPT = PT / WGP;
+    constexpr int FC = WCT / 16, FP = WPT / 16;
+    static_assert(FC == kConvFC, "host weight packing assumes 64-channel wave slabs");
+    constexpr int STAGE = (CT + PT) * 128;
+    constexpr int LW = CT / 32, LX = PT / 32;          // DMA wave-instructions per stage
+    constexpr int L = LW + LX;
+    typedef typename FragT<T>::V V;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* koffs = reinterpret_cast<int*>(smem + NS * STAGE);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ctTile = blockIdx.x % p.nCt;
+    const int ptTile = blockIdx.x / p.nCt;
+    const int nS = p.nStages;
+    const int HoWo = p.Ho * p.Wo;
+
+    for (int i = tid; i < nS * 8; i += 256) koffs[i] = p.koff[i];
+
+    // DMA source of this lane's activation rows: row r of the pixel tile <-> output pixel ptTile*PT + r
+    unsigned xoff[LX];
+#pragma unroll
+    for (int i = 0; i < LX; ++i) {
+        int pix = ptTile * PT + (i * 4 + wave) * 8 + (lane >> 3);
+        pix = pix < p.M ? pix : p.M - 1;
+        const int n = pix / HoWo;
+        const int rem = pix - n * HoWo;
+        const int oy = rem / p.Wo;
+        const int ox = rem - oy * p.Wo;
+        xoff[i] = (unsigned)((n * p.xHp + oy * p.stride) * p.xWp + ox * p.stride) * (unsigned)p.xCs *
+                  (unsigned)sizeof(T);
+    }
+    const int myChunk = (lane & 7) ^ (lane >> 3);      // logical K chunk this lane fetches (swizzled)
+    const char* wsrc = p.w + (size_t)ctTile * nS * (CT * 128) + wave * 1024 + lane * 16;
+    __syncthreads();                                    // koffs visible
+
+    auto issue = [&](int s, int buf) {
+        char* sW = smem + buf * STAGE;
+        char* sX = sW + CT * 128;
+        const char* gw = wsrc + (size_t)s * (CT * 128);
+#pragma unroll
+        for (int i = 0; i < LW; ++i) glds16(gw + i * 4096, sW + (i * 4 + wave) * 1024);
+        const int ko = koffs[s * 8 + myChunk];
+#pragma unroll
+        for (int i = 0; i < LX; ++i) glds16(p.x + xoff[i] + ko, sX + (i * 4 + wave) * 1024);
+    };
+
+    const int wci = wave / WGP, wpi = wave % WGP;
+    const int q = lane >> 4, l15 = lane & 15;
+    const int rowW = (wci * WCT + l15) * 128;
+    const int rowX = CT * 128 + (wpi * WPT + l15) * 128;
+    const int sw0 = (q ^ (lane & 7)) * 16;              // chunk (0*4+q) of a row with (row&7)==(lane&7)
+
+    f4 acc[FC][FP];
+#pragma unroll
+    for (int f = 0; f < FC; ++f)
+#pragma unroll
+        for (int g = 0; g < FP; ++g) acc[f][g] = f4{0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](int buf) {
+        const char* s = smem + buf * STAGE;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int sw = sw0 ^ (sub * 64);
+            V a[FC], b[FP];
+#pragma unroll
+            for (int f = 0; f < FC; ++f) a[f] = *reinterpret_cast<const V*>(s + rowW + f * 2048 + sw);
+#pragma unroll
+            for (int g = 0; g < FP; ++g) b[g] = *reinterpret_cast<const V*>(s + rowX + g * 2048 + sw);
+#pragma unroll
+            for (int f = 0; f < FC; ++f)
+#pragma unroll
+                for (int g = 0; g < FP; ++g) mma16(acc[f][g], a[f], b[g]);
+        }
+    };
+
+    if constexpr (NS == 2) {
+        issue(0, 0);
+        int buf = 0;
+        for (int t = 0; t < nS; ++t) {
+            wait_vm_barrier<0>();
+            if (t + 1 < nS) issue(t + 1, buf ^ 1);
+            compute(buf);
+            buf ^= 1;
+        }
+    } else {
+        static_assert(NS == 3, "ring depth 2 or 3");
+        issue(0, 0);
+        if (nS > 1) issue(1, 1);
+        int bufC = 0, bufI = 2;
+        for (int t = 0; t < nS; ++t) {
+            if (t + 1 < nS) wait_vm_barrier<L>(); else wait_vm_barrier<0>();
+            if (t + 2 < nS) issue(t + 2, bufI);
+            compute(bufC);
+            bufC = bufC == 2 ? 0 : bufC + 1;
+            bufI = bufI == 2 ? 0 : bufI + 1;
+        }
+    }
+
+    // ---- epilogue: BN affine (+ residual) (+ ReLU), convert, 16-B NHWC stores -------------------------
+    constexpr int NV = 4 * FC;                          // consecutive channels held by this lane
+    const int row0 = ctTile * CT + wci * WCT + q * NV;  // first GEMM row (== channel, by host permutation)
+    float sc[NV], sh[NV];
+#pragma unroll
+    for (int i = 0; i < NV; i += 4) {
+        const f4 a = *reinterpret_cast<const f4*>(p.scale + row0 + i);
+        const f4 b = *reinterpret_cast<const f4*>(p.shift + row0 + i);
+        sc[i] = a[0]; sc[i + 1] = a[1]; sc[i + 2] = a[2]; sc[i + 3] = a[3];
+        sh[i] = b[0]; sh[i + 1] = b[1]; sh[i + 2] = b[2]; sh[i + 3] = b[3];
+    }
+    int co0 = row0, dy = 0, dx = 0;
+    if (p.shuffle) {                                     // rows are (dy, dx, co): k2 s2 transposed conv
+        const int g = row0 / p.Cout;
+        co0 = row0 - g * p.Cout;
+        dy = g >> 1;
+        dx = g & 1;
+    }
+    T* const ybase = reinterpret_cast<T*>(p.y);
+    const T* const rbase = reinterpret_cast<const T*>(p.res);
+#pragma unroll
+    for (int g = 0; g < FP; ++g) {
+        const int pix = ptTile * PT + wpi * WPT + g * 16 + l15;
+        if (pix < p.M && row0 < p.rows) {
+            const int n = pix / HoWo;
+            const int rem = pix - n * HoWo;
+            const int oy = rem / p.Wo;
+            const int ox = rem - oy * p.Wo;
+            const size_t opix = p.shuffle
+                ? (size_t)(n * p.yHp + 2 * oy + dy + 1) * p.yWp + (2 * ox + dx + 1)
+                : (size_t)(n * p.yHp + oy + 1) * p.yWp + (ox + 1);
+            float v[NV];
+#pragma unroll
+            for (int f = 0; f < FC; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[f * 4 + r] = acc[f][g][r] * sc[f * 4 + r] + sh[f * 4 + r];
+            if (rbase) OutVec<T, NV>::add(rbase + opix * p.rCs + p.rCoff + co0, v);
+            if (p.relu) {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+            }
+            OutVec<T, NV>::store(ybase + opix * p.yCs + p.yCoff + co0, v);
+        }
+    }
+}
+
+// ---- host-side launch -------------------------------------------------------------------------------
+template <typename T, int CT, int PT, int WGC, int NS>
+static hipError_t launch_one(const ConvParams& p, hipStream_t stream) {
+    const size_t lds = (size_t)NS * (CT + PT) * 128 + (((size_t)p.nStages * 8 * 4 + 15) & ~(size_t)15);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    const int nPt = (p.M + PT - 1) / PT;
+    auto kern = conv_igemm_kernel<T, CT, PT, WGC, NS>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nPt * p.nCt)), dim3(256), lds, stream, p);
+    return hipGetLastError();
+}
+
+template <typename T, int CT, int PT, int WGC, int NS>
+static hipError_t prepare_one() {
+    auto kern = conv_igemm_kernel<T, CT, PT, WGC, NS>;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+#define CV_FOR_EACH_CFG(X, T)        \
+    X(T, 64, 256, 1, 3, kCfg64x256)  \
+    X(T, 64, 128, 1, 3, kCfg64x128)  \
+    X(T, 128, 128, 2, 3, kCfg128x128) \
+    X(T, 128, 256, 2, 3, kCfg128x256)
+
+hipError_t conv_igemm_prepare() {
+    hipError_t e;
+#define X(T, CT, PT, WGC, NS, ID) \
+    if ((e = prepare_one<T, CT, PT, WGC, NS>()) != hipSuccess) return e;
+    CV_FOR_EACH_CFG(X, half_t)
+    CV_FOR_EACH_CFG(X, float)
+#undef X
+    return hipSuccess;
+}
+
+hipError_t conv_igemm_launch(int cfg, bool f16, const ConvParams& p, hipStream_t stream) {
+#define X(T, CT, PT, WGC, NS, ID) \
+    if (cfg == ID) return launch_one<T, CT, PT, WGC, NS>(p, stream);
+    if (f16) { CV_FOR_EACH_CFG(X, half_t) } else { CV_FOR_EACH_CFG(X, float) }
+#undef X
+    return hipErrorInvalidValue;
+}
+
+int conv_cfg_ct(int cfg) { return (cfg == kCfg64x256 || cfg == kCfg64x128) ? 64 : 128; }
+int conv_cfg_pt(int cfg) { return (cfg == kCfg64x256 || cfg == kCfg128x256) ? 256 : 128; }
+
+}  // namespace cv

@@ -1,0 +1,379 @@
+// cv_api.cpp -- the extern "C" surface declared in include/chessvision_hip.h.
+#include "../../include/chessvision_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "engine.h"
+#include "models.h"
+#include "pointwise.h"
+
+using namespace cv;
+
+struct cv_engine {
+    Engine impl;
+};
+
+namespace {
+
+struct DeviceGuard {                       // every entry point runs on the engine's device
+    int prev = -1;
+    explicit DeviceGuard(int dev) { (void)hipGetDevice(&prev); if (prev != dev) (void)hipSetDevice(dev); else prev = -1; }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+int finish(const Status& s) { return s.code; }
+
+Status to_map(const cv_param_t* params, int n, ParamMap& pm) {
+    if (n < 0 || (n > 0 && !params)) return fail(CV_ERR_INVALID, "null parameter table");
+    for (int i = 0; i < n; ++i) {
+        const cv_param_t& p = params[i];
+        if (!p.name || !p.data || p.ndim < 0 || p.ndim > 4) return fail(CV_ERR_INVALID, "malformed cv_param_t entry " + std::to_string(i));
+        ParamView v;
+        v.data = p.data;
+        for (int d = 0; d < p.ndim; ++d) v.shape.push_back(p.shape[d]);
+        pm[p.name] = v;
+    }
+    return Status();
+}
+
+Status check_engine(cv_engine_t* eng) {
+    if (!eng) return fail(CV_ERR_INVALID, "null engine handle");
+    return Status();
+}
+
+}  // namespace
+
+extern "C" {
+
+int cv_abi_version(void) { return CV_ABI_VERSION; }
+const char* cv_last_error(void) { return get_error(); }
+
+int cv_device_count(int* count) {
+    if (!count) return finish(fail(CV_ERR_INVALID, "null count"));
+    hipError_t e = hipGetDeviceCount(count);
+    if (e != hipSuccess) { *count = 0; return finish(hip_fail(e, "hipGetDeviceCount")); }
+    return CV_OK;
+}
+
+int cv_engine_create(int device, int precision, cv_engine_t** out) {
+    if (!out) return finish(fail(CV_ERR_INVALID, "null out pointer"));
+    *out = nullptr;
+    if (precision != CV_PREC_F32 && precision != CV_PREC_F16) return finish(fail(CV_ERR_INVALID, "unknown precision"));
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return finish(fail(CV_ERR_HIP, std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0")));
+    if (device < 0 || device >= count) return finish(fail(CV_ERR_INVALID, "device ordinal out of range"));
+    DeviceGuard g(device);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return finish(hip_fail(e, "hipGetDeviceProperties"));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return finish(fail(CV_ERR_STATE, std::string("libchessvision_hip is built for gfx950 (MI355X); device is ") + prop.gcnArchName));
+    if ((e = conv_igemm_prepare()) != hipSuccess) return finish(hip_fail(e, "conv_igemm_prepare"));
+    cv_engine* eng = new (std::nothrow) cv_engine();
+    if (!eng) return finish(fail(CV_ERR_NOMEM, "out of host memory"));
+    eng->impl.device = device;
+    eng->impl.f16 = precision == CV_PREC_F16;
+    *out = eng;
+    return CV_OK;
+}
+
+int cv_engine_destroy(cv_engine_t* eng) {
+    if (!eng) return CV_OK;
+    {
+        DeviceGuard g(eng->impl.device);
+        (void)hipDeviceSynchronize();
+        eng->impl.unet.reset();
+        eng->impl.resnet.reset();
+    }
+    delete eng;
+    return CV_OK;
+}
+
+int cv_engine_set_chunk(cv_engine_t* eng, int unet_images, int resnet_squares) {
+    Status s = check_engine(eng);
+    if (!s.ok()) return finish(s);
+    std::lock_guard<std::mutex> lk(eng->impl.mu);
+    if (eng->impl.unet || eng->impl.resnet) return finish(fail(CV_ERR_STATE, "cv_engine_set_chunk must precede cv_load_*"));
+    if (unet_images < 0 || resnet_squares < 0) return finish(fail(CV_ERR_INVALID, "negative chunk"));
+    if (unet_images) eng->impl.unet_chunk = unet_images;
+    if (resnet_squares) eng->impl.resnet_chunk = resnet_squares;
+    return CV_OK;
+}
+
+int cv_load_unet(cv_engine_t* eng, const cv_param_t* params, int n_params) {
+    Status s = check_engine(eng);
+    if (!s.ok()) return finish(s);
+    std::lock_guard<std::mutex> lk(eng->impl.mu);
+    DeviceGuard g(eng->impl.device);
+    ParamMap pm;
+    s = to_map(params, n_params, pm);
+    if (s.ok()) s = unet_load(eng->impl, pm);
+    return finish(s);
+}
+
+int cv_load_resnet18(cv_engine_t* eng, const cv_param_t* params, int n_params) {
+    Status s = check_engine(eng);
+    if (!s.ok()) return finish(s);
+    std::lock_guard<std::mutex> lk(eng->impl.mu);
+    DeviceGuard g(eng->impl.device);
+    ParamMap pm;
+    s = to_map(params, n_params, pm);
+    if (s.ok()) s = resnet_load(eng->impl, pm);
+    return finish(s);
+}
+
+int cv_unet_forward(cv_engine_t* eng, const float* x, int batch, float* logits, void* stream) {
+    Status s = check_engine(eng);
+    if (!s.ok()) return finish(s);
+    std::lock_guard<std::mutex> lk(eng->impl.mu);
+    DeviceGuard g(eng->impl.device);
+    return finish(unet_forward(eng->impl, x, false, batch, logits, nullptr, 0.5f, (hipStream_t)stream));
+}
+
+int cv_unet_forward_u8(cv_engine_t* eng, const uint8_t* x_u8, int batch, float* logits, uint8_t* mask,
+                       float threshold, void* stream) {
+    Status s = check_engine(eng);
+    if (!s.ok()) return finish(s);
+    if (!(threshold >= 0.f && threshold <= 1.f)) return finish(fail(CV_ERR_INVALID, "threshold must be between 0 and 1"));
+    std::lock_guard<std::mutex> lk(eng->impl.mu);
+    DeviceGuard g(eng->impl.device);
+    return finish(unet_forward(eng->impl, x_u8, true, batch, logits, mask, threshold, (hipStream_t)stream));
+}
+
+int cv_resnet18_forward(cv_engine_t* eng, const float* x, int n, float* logits, void* stream) {
+    Status s = check_engine(eng);
+    if (!s.ok()) return finish(s);
+    std::lock_guard<std::mutex> lk(eng->impl.mu);
+    DeviceGuard g(eng->impl.device);
+    return finish(resnet_forward(eng->impl, x, false, n, logits, false, (hipStream_t)stream));
+}
+
+int cv_resnet18_forward_u8(cv_engine_t* eng, const uint8_t* squares_u8, int n, float* probs, void* stream) {
+    Status s = check_engine(eng);
+    if (!s.ok()) return finish(s);
+    std::lock_guard<std::mutex> lk(eng->impl.mu);
+    DeviceGuard g(eng->impl.device);
+    return finish(resnet_forward(eng->impl, squares_u8, true, n, probs, true, (hipStream_t)stream));
+}
+
+int cv_softmax13(cv_engine_t* eng, const float* logits, int n, float* probs, void* stream) {
+    Status s = check_engine(eng);
+    if (!s.ok()) return finish(s);
+    if (n < 0 || (n > 0 && (!logits || !probs))) return finish(fail(CV_ERR_INVALID, "cv_softmax13: null tensor"));
+    if (n == 0) return CV_OK;
+    DeviceGuard g(eng->impl.device);
+    hipError_t e = softmax13(logits, n, probs, (hipStream_t)stream);
+    if (e != hipSuccess) return finish(hip_fail(e, "softmax13"));
+    return CV_OK;
+}
+
+int cv_get_activation(cv_engine_t* eng, const char* model, const char* name, float* out_host, size_t out_capacity,
+                      int64_t dims[4]) {
+    Status s = check_engine(eng);
+    if (!s.ok()) return finish(s);
+    if (!model || !name || !dims) return finish(fail(CV_ERR_INVALID, "null argument"));
+    std::lock_guard<std::mutex> lk(eng->impl.mu);
+    DeviceGuard g(eng->impl.device);
+    TensorRef t;
+    if (std::strcmp(model, "unet") == 0) s = unet_activation(eng->impl, name, &t);
+    else if (std::strcmp(model, "resnet18") == 0) s = resnet_activation(eng->impl, name, &t);
+    else s = fail(CV_ERR_INVALID, "model must be 'unet' or 'resnet18'");
+    if (!s.ok()) return finish(s);
+    dims[0] = t.N; dims[1] = t.C; dims[2] = t.H; dims[3] = t.W;
+    const size_t numel = (size_t)t.N * t.C * t.H * t.W;
+    if (!out_host) return CV_OK;                          // shape query
+    if (out_capacity < numel) return finish(fail(CV_ERR_INVALID, "output buffer too small"));
+    DeviceBuffer tmp;
+    s = tmp.alloc(numel * sizeof(float), false);
+    if (!s.ok()) return finish(s);
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = unpack_nchw_f32(eng->impl.f16, t, (float*)tmp.ptr, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(out_host, tmp.ptr, numel * sizeof(float), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return finish(hip_fail(e, "cv_get_activation"));
+    return CV_OK;
+}
+
+int cv_model_macs(cv_engine_t* eng, const char* model, int64_t* macs) {
+    Status s = check_engine(eng);
+    if (!s.ok()) return finish(s);
+    if (!model || !macs) return finish(fail(CV_ERR_INVALID, "null argument"));
+    if (std::strcmp(model, "unet") == 0) *macs = unet_macs(eng->impl);
+    else if (std::strcmp(model, "resnet18") == 0) *macs = resnet_macs(eng->impl);
+    else return finish(fail(CV_ERR_INVALID, "model must be 'unet' or 'resnet18'"));
+    if (*macs == 0) return finish(fail(CV_ERR_STATE, "model not loaded"));
+    return CV_OK;
+}
+
+int cv_profile_convs(cv_engine_t* eng, const char* model, const void* x, int batch, void* out, int iters,
+                     void* stream, float* conv_ms_total, int* conv_launches, float* all_ms_total) {
+    Status s = check_engine(eng);
+    if (!s.ok()) return finish(s);
+    if (!model || iters <= 0) return finish(fail(CV_ERR_INVALID, "bad profile arguments"));
+    std::lock_guard<std::mutex> lk(eng->impl.mu);
+    DeviceGuard g(eng->impl.device);
+    Engine& e = eng->impl;
+    e.prof_clear();
+    e.profiling = true;
+    const bool is_unet = std::strcmp(model, "unet") == 0;
+    for (int i = 0; i < iters && s.ok(); ++i) {
+        if (is_unet) s = unet_forward(e, x, false, batch, (float*)out, nullptr, 0.5f, (hipStream_t)stream);
+        else s = resnet_forward(e, x, false, batch, (float*)out, false, (hipStream_t)stream);
+    }
+    e.profiling = false;
+    if (s.ok()) s = e.prof_collect();
+    if (!s.ok()) { e.prof_clear(); return finish(s); }
+    float conv = 0.f, all = 0.f;
+    int n = 0;
+    for (auto& pe : e.prof) { all += pe.ms; if (pe.is_conv) { conv += pe.ms; ++n; } }
+    if (conv_ms_total) *conv_ms_total = conv;
+    if (conv_launches) *conv_launches = n;
+    if (all_ms_total) *all_ms_total = all;
+    return CV_OK;
+}
+
+int cv_profile_entry(cv_engine_t* eng, int index, char* name, int name_cap, float* ms, double* macs, int* is_conv) {
+    Status s = check_engine(eng);
+    if (!s.ok()) return finish(s);
+    std::lock_guard<std::mutex> lk(eng->impl.mu);
+    if (index < 0 || index >= (int)eng->impl.prof.size()) return finish(fail(CV_ERR_INVALID, "profile index out of range"));
+    const ProfileEntry& pe = eng->impl.prof[index];
+    if (name && name_cap > 0) { std::strncpy(name, pe.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+    if (ms) *ms = pe.ms;
+    if (macs) *macs = pe.macs;
+    if (is_conv) *is_conv = pe.is_conv ? 1 : 0;
+    return CV_OK;
+}
+
+// ---- single-layer entry points (parity tests) -------------------------------------------------------
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+int cv_op_conv2d(cv_engine_t* eng, const float* x, int n, int cin, int h, int w_, const float* w_host, int cout,
+                 int k, int stride, const float* scale_host, const float* shift_host, const float* residual,
+                 int relu, float* y, void* stream) {
+    Status s = check_engine(eng);
+    if (!s.ok()) return finish(s);
+    if (!x || !w_host || !y || n <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w_ <= 0 || stride <= 0)
+        return finish(fail(CV_ERR_INVALID, "cv_op_conv2d: bad argument"));
+    std::lock_guard<std::mutex> lk(eng->impl.mu);
+    DeviceGuard g(eng->impl.device);
+    Engine& e = eng->impl;
+    hipStream_t st = (hipStream_t)stream;
+    const int pad = (k - 1) / 2;
+    const int ho = (h + 2 * pad - k) / stride + 1, wo = (w_ + 2 * pad - k) / stride + 1;
+    const int cinPad = round_up(cin, 8);
+    std::vector<float> ones(cout, 1.f), zeros(cout, 0.f);
+    ConvLayer L;
+    s = L.build_conv("op_conv2d", e.f16, w_host, cout, cin, k, stride, scale_host ? scale_host : ones.data(),
+                     shift_host ? shift_host : zeros.data(), cinPad, choose_cfg(cout, (int64_t)n * ho * wo));
+    if (!s.ok()) return finish(s);
+    Activation ax, ay, ar;
+    if ((s = ax.create(n, h, w_, cinPad, e.f16)).ok() && (s = ay.create(n, ho, wo, cout, e.f16)).ok()) {
+        hipError_t err = pack_nchw_f32(e.f16, x, cin, ax.ref(n), st);
+        TensorRef rr;
+        if (err == hipSuccess && residual) {
+            s = ar.create(n, ho, wo, cout, e.f16);
+            if (s.ok()) { err = pack_nchw_f32(e.f16, residual, cout, ar.ref(n), st); rr = ar.ref(n); }
+        }
+        if (s.ok() && err == hipSuccess) s = e.run_conv(L, ax.ref(n), ay.ref(n), residual ? &rr : nullptr, relu != 0, st);
+        if (s.ok() && err == hipSuccess) err = unpack_nchw_f32(e.f16, ay.ref(n), y, st);
+        if (s.ok() && err == hipSuccess) err = hipStreamSynchronize(st);
+        if (s.ok() && err != hipSuccess) s = hip_fail(err, "cv_op_conv2d");
+    }
+    return finish(s);
+}
+
+int cv_op_conv_transpose2x2(cv_engine_t* eng, const float* x, int n, int cin, int h, int w_, const float* w_host,
+                            int cout, const float* bias_host, float* y, void* stream) {
+    Status s = check_engine(eng);
+    if (!s.ok()) return finish(s);
+    if (!x || !w_host || !y || !bias_host || n <= 0) return finish(fail(CV_ERR_INVALID, "cv_op_conv_transpose2x2: bad argument"));
+    std::lock_guard<std::mutex> lk(eng->impl.mu);
+    DeviceGuard g(eng->impl.device);
+    Engine& e = eng->impl;
+    hipStream_t st = (hipStream_t)stream;
+    ConvLayer L;
+    s = L.build_convT("op_convT", e.f16, w_host, cin, cout, bias_host, choose_cfg(4 * cout, (int64_t)n * h * w_));
+    if (!s.ok()) return finish(s);
+    Activation ax, ay;
+    if ((s = ax.create(n, h, w_, cin, e.f16)).ok() && (s = ay.create(n, 2 * h, 2 * w_, cout, e.f16)).ok()) {
+        hipError_t err = pack_nchw_f32(e.f16, x, cin, ax.ref(n), st);
+        if (err == hipSuccess) s = e.run_conv(L, ax.ref(n), ay.ref(n), nullptr, false, st);
+        if (s.ok() && err == hipSuccess) err = unpack_nchw_f32(e.f16, ay.ref(n), y, st);
+        if (s.ok() && err == hipSuccess) err = hipStreamSynchronize(st);
+        if (s.ok() && err != hipSuccess) s = hip_fail(err, "cv_op_conv_transpose2x2");
+    }
+    return finish(s);
+}
+
+typedef hipError_t (*pool_fn)(bool, const TensorRef&, const TensorRef&, hipStream_t);
+static int pool_like(cv_engine_t* eng, const float* x, int n, int c, int h, int w_, int ho, int wo, float* y,
+                     void* stream, pool_fn fn, const char* what) {
+    Status s = check_engine(eng);
+    if (!s.ok()) return finish(s);
+    if (!x || !y || n <= 0 || c <= 0) return finish(fail(CV_ERR_INVALID, std::string(what) + ": bad argument"));
+    std::lock_guard<std::mutex> lk(eng->impl.mu);
+    DeviceGuard g(eng->impl.device);
+    Engine& e = eng->impl;
+    hipStream_t st = (hipStream_t)stream;
+    const int cp = round_up(c, 8);
+    Activation ax, ay;
+    if ((s = ax.create(n, h, w_, cp, e.f16)).ok() && (s = ay.create(n, ho, wo, cp, e.f16)).ok()) {
+        hipError_t err = pack_nchw_f32(e.f16, x, c, ax.ref(n), st);
+        if (err == hipSuccess) err = fn(e.f16, ax.ref(n), ay.ref(n), st);
+        if (err == hipSuccess) err = unpack_nchw_f32(e.f16, ay.ref(n, 0, c), y, st);
+        if (err == hipSuccess) err = hipStreamSynchronize(st);
+        if (err != hipSuccess) s = hip_fail(err, what);
+    }
+    return finish(s);
+}
+
+int cv_op_maxpool2x2(cv_engine_t* eng, const float* x, int n, int c, int h, int w_, float* y, void* stream) {
+    return pool_like(eng, x, n, c, h, w_, h / 2, w_ / 2, y, stream, maxpool2x2, "cv_op_maxpool2x2");
+}
+int cv_op_maxpool3x3s2(cv_engine_t* eng, const float* x, int n, int c, int h, int w_, float* y, void* stream) {
+    return pool_like(eng, x, n, c, h, w_, (h + 2 - 3) / 2 + 1, (w_ + 2 - 3) / 2 + 1, y, stream, maxpool3x3s2, "cv_op_maxpool3x3s2");
+}
+int cv_op_upsample_bilinear2x(cv_engine_t* eng, const float* x, int n, int c, int h, int w_, float* y, void* stream) {
+    return pool_like(eng, x, n, c, h, w_, 2 * h, 2 * w_, y, stream, upsample_bilinear2x, "cv_op_upsample_bilinear2x");
+}
+
+int cv_selftest_mfma(cv_engine_t* eng, float* max_err_f16, float* max_err_f32) {
+    Status s = check_engine(eng);
+    if (!s.ok()) return finish(s);
+    DeviceGuard g(eng->impl.device);
+    // asymmetric integer-valued operands: exact in f16 and f32, so the expected error is exactly 0
+    _Float16 a16[16 * 32], b16[16 * 32];
+    float a32[16 * 16], b32[16 * 16], ref16[256], ref32[256], got[256];
+    for (int i = 0; i < 16; ++i)
+        for (int k = 0; k < 32; ++k) { a16[i * 32 + k] = (_Float16)(float)((i * 3 + k * 5) % 7 - 3); b16[i * 32 + k] = (_Float16)(float)((i * 5 + k * 2 + 1) % 9 - 4); }
+    for (int i = 0; i < 16; ++i)
+        for (int k = 0; k < 16; ++k) { a32[i * 16 + k] = (float)((i * 3 + k * 5) % 7 - 3); b32[i * 16 + k] = (float)((i * 5 + k * 2 + 1) % 9 - 4); }
+    for (int i = 0; i < 16; ++i)
+        for (int j = 0; j < 16; ++j) {
+            float s16 = 0, s32 = 0;
+            for (int k = 0; k < 32; ++k) s16 += (float)a16[i * 32 + k] * (float)b16[j * 32 + k];
+            for (int k = 0; k < 16; ++k) s32 += a32[i * 16 + k] * b32[j * 16 + k];
+            ref16[i * 16 + j] = s16; ref32[i * 16 + j] = s32;
+        }
+    DeviceBuffer da, db, dd;
+    hipError_t e = hipSuccess;
+    float err16 = 0.f, err32 = 0.f;
+    if (!(s = da.upload(a16, sizeof(a16))).ok() || !(s = db.upload(b16, sizeof(b16))).ok() || !(s = dd.alloc(sizeof(got), true)).ok()) return finish(s);
+    e = mfma_probe_f16((const half_t*)da.ptr, (const half_t*)db.ptr, (float*)dd.ptr, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(got, dd.ptr, sizeof(got), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return finish(hip_fail(e, "mfma_probe_f16"));
+    for (int i = 0; i < 256; ++i) err16 = std::max(err16, std::fabs(got[i] - ref16[i]));
+    if (!(s = da.upload(a32, sizeof(a32))).ok() || !(s = db.upload(b32, sizeof(b32))).ok()) return finish(s);
+    e = mfma_probe_f32((const float*)da.ptr, (const float*)db.ptr, (float*)dd.ptr, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(got, dd.ptr, sizeof(got), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return finish(hip_fail(e, "mfma_probe_f32"));
+    for (int i = 0; i < 256; ++i) err32 = std::max(err32, std::fabs(got[i] - ref32[i]));
+    if (max_err_f16) *max_err_f16 = err16;
+    if (max_err_f32) *max_err_f32 = err32;
+    return CV_OK;
+}
+
+}  // extern "C"

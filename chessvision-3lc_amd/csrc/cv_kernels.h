@@ -1,0 +1,56 @@
+// cv_kernels.h -- device-side contracts shared by the HIP kernels and the host engine.
+//
+// Activation layout ("PHWC"): every activation tensor lives in HBM as zero-bordered NHWC,
+//     elem(n, y, x, c) = base[ ((n*(H+2) + y+1)*(W+2) + x+1) * Cs + Coff + c ]
+// with a 1-pixel border that is zeroed once at allocation and never written again.  The border gives
+// 3x3/pad-1 convolutions and the 3x3/s2/p1 max-pool (inputs are post-ReLU, so 0 == -inf for the max)
+// their padding for free: no kernel on the path ever bounds-checks a load.  Cs (channel stride) and Coff
+// let a producer write into a channel slice of a wider buffer, which is how the UNet skip `torch.cat`
+// (Up.forward: cat([skip, upsampled], dim=1)) disappears: encoder and up-conv write the two halves of one
+// buffer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cv {
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+struct TensorRef {            // a channel slice of a PHWC tensor
+    void* base;               // address of padded element (n=0, y=-1, x=-1, c=0)
+    int N, H, W;              // interior extent
+    int Cs;                   // channel stride of the underlying buffer (elements)
+    int Coff;                 // first channel of the slice
+    int C;                    // channels in the slice
+};
+
+// Implicit-GEMM convolution:  D[ch][pix] = sum_k Wt[ch][k] * X[pix][k]
+//   k runs over (tap, input channel); a "stage" is 128 bytes of K per row (64 f16 / 32 f32 values).
+struct ConvParams {
+    const char* x;            // input PHWC base
+    const char* w;            // packed weights: [ctTile][stage][CT rows][8 x 16 B, XOR-swizzled]
+    const int* koff;          // [nStages*8] byte offset of each 16-B K chunk relative to a pixel's base
+    const float* scale;       // [rows] epilogue scale  (BN gamma / sqrt(var + eps), or 1)
+    const float* shift;       // [rows] epilogue shift  (BN beta - mean*scale, or conv bias)
+    const char* res;          // optional residual PHWC base (same pixel grid as the output), or null
+    char* y;                  // output PHWC base
+    int M;                    // output pixels = N*Ho*Wo
+    int Ho, Wo;               // output pixel grid per image
+    int xHp, xWp;             // input padded dims (Hi+2, Wi+2)
+    int stride;               // convolution stride
+    int xCs;                  // input channel stride (elements)
+    int yHp, yWp;             // output padded dims
+    int yCs, yCoff;           // output channel stride / first channel
+    int rCs, rCoff;           // residual channel stride / first channel
+    int Cout;                 // channels per output pixel (rows / 4 in shuffle mode)
+    int rows;                 // real GEMM rows (multiple of 16); rows beyond are padding
+    int nStages;              // K stages of 128 bytes
+    int nCt;                  // channel tiles
+    int relu;
+    int shuffle;              // 1: rows = (dy,dx,co) of a k2 s2 transposed conv -> pixel-shuffle store
+};
+
+}  // namespace cv

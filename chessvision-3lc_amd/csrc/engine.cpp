@@ -1,0 +1,246 @@
+// engine.cpp -- weight packing, device buffers, conv launch plumbing and profiling hooks.
+#include "engine.h"
+#include "models.h"
+
+#include <cmath>
+#include <cstring>
+
+namespace cv {
+
+// ---- error plumbing: thread-local message, never abort (SURVEY.md section 8b "Errors") -------------
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+const char* get_error() { return g_err.c_str(); }
+Status fail(int code, const std::string& msg) {
+    set_error(msg);
+    Status s; s.code = code;
+    return s;
+}
+Status hip_fail(hipError_t e, const char* what) {
+    return fail(2, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+// ---- device memory -------------------------------------------------------------------------------
+DeviceBuffer::~DeviceBuffer() {
+    if (ptr) (void)hipFree(ptr);
+}
+Status DeviceBuffer::alloc(size_t n, bool zero) {
+    if (ptr) { (void)hipFree(ptr); ptr = nullptr; }
+    bytes = n;
+    if (n == 0) return Status();
+    hipError_t e = hipMalloc(&ptr, n);
+    if (e != hipSuccess) { ptr = nullptr; return fail(4, std::string("hipMalloc(") + std::to_string(n) + "): " + hipGetErrorString(e)); }
+    if (zero) CV_HIP(hipMemset(ptr, 0, n));
+    return Status();
+}
+Status DeviceBuffer::upload(const void* host, size_t n) {
+    CV_TRY(alloc(n, false));
+    CV_HIP(hipMemcpy(ptr, host, n, hipMemcpyHostToDevice));
+    return Status();
+}
+
+Status Activation::create(int cap_, int h, int w, int c, bool f16_) {
+    cap = cap_; H = h; W = w; C = c; f16 = f16_;
+    const size_t total = bytes_per_image() * (size_t)cap;
+    if (total >= ((size_t)1 << 32))
+        return fail(1, "activation buffer >= 4 GiB: lower the chunk size (32-bit DMA offsets)");
+    return buf.alloc(total, /*zero=*/true);     // zero border, written never again
+}
+
+// ---- implicit-GEMM weight packing ----------------------------------------------------------------
+// LDS row R of a channel tile holds the weights of channel tile*CT + conv_row_to_channel(R): inside each
+// 64-row wave slab the (fragment f, quad q) fields are swapped so that the lane that owns MFMA rows
+// 4q..4q+3 of fragments f = 0..3 ends up with 16 consecutive channels (conv_igemm.hip epilogue).
+static inline int conv_row_to_channel(int R) {
+    const int slab = R / 64, within = R % 64;
+    const int f = within / 16, i = within % 16, q = i / 4, r = i % 4;
+    return slab * 64 + q * (4 * kConvFC) + f * 4 + r;
+}
+
+template <typename T>
+static void pack_rows(std::vector<char>& out, int CT, int nCt, int nStages, int rows, int K,
+                      const std::vector<float>& Wk /* [rows][K] */) {
+    const int epc = 16 / (int)sizeof(T);
+    out.assign((size_t)nCt * nStages * CT * 128, 0);
+    T* dst = reinterpret_cast<T*>(out.data());
+    for (int t = 0; t < nCt; ++t)
+        for (int s = 0; s < nStages; ++s)
+            for (int R = 0; R < CT; ++R) {
+                const int row = t * CT + conv_row_to_channel(R);
+                for (int pos = 0; pos < 8; ++pos) {
+                    const int c = pos ^ (R & 7);
+                    const int kc = s * 8 + c;
+                    T* d = dst + (((size_t)(t * nStages + s) * CT + R) * 8 + pos) * epc;
+                    for (int e = 0; e < epc; ++e) {
+                        const int kk = kc * epc + e;
+                        const float v = (row < rows && kk < K) ? Wk[(size_t)row * K + kk] : 0.f;
+                        d[e] = (T)v;
+                    }
+                }
+            }
+}
+
+static Status finish_layer(ConvLayer& L, const std::vector<float>& Wk, int K, const std::vector<float>& scale,
+                           const std::vector<float>& shift) {
+    const int esz = L.f16 ? 2 : 4, epc = 16 / esz;
+    const int CT = conv_cfg_ct(L.cfg);
+    const int nChunks = (K + epc - 1) / epc;
+    L.nStages = (nChunks + 7) / 8;
+    L.nCt = (L.rows + CT - 1) / CT;
+    L.rowsPad = L.nCt * CT;
+    std::vector<char> packed;
+    if (L.f16) pack_rows<_Float16>(packed, CT, L.nCt, L.nStages, L.rows, K, Wk);
+    else       pack_rows<float>(packed, CT, L.nCt, L.nStages, L.rows, K, Wk);
+    CV_TRY(L.w.upload(packed.data(), packed.size()));
+    std::vector<float> sc(L.rowsPad, 0.f), sh(L.rowsPad, 0.f);
+    std::memcpy(sc.data(), scale.data(), sizeof(float) * L.rows);
+    std::memcpy(sh.data(), shift.data(), sizeof(float) * L.rows);
+    CV_TRY(L.scale.upload(sc.data(), sc.size() * sizeof(float)));
+    CV_TRY(L.shift.upload(sh.data(), sh.size() * sizeof(float)));
+    L.koff.clear();
+    return Status();
+}
+
+Status ConvLayer::build_conv(const std::string& name_, bool f16_, const float* w_oihw, int cout_, int cin_, int k_,
+                             int stride_, const float* scale_, const float* shift_, int cinPad_, int cfg_) {
+    name = name_; f16 = f16_; cin = cin_; cinPad = cinPad_; cout = cout_; k = k_; stride = stride_;
+    shuffle = false; rows = cout_; cfg = cfg_;
+    if (cinPad % 8 || cinPad < cin) return fail(1, name + ": input channel padding must be a multiple of 8");
+    if (k != 1 && k != 3) return fail(1, name + ": implicit-GEMM path supports 1x1 and 3x3 kernels");
+    if (cout % 16) return fail(1, name + ": output channels must be a multiple of 16");
+    const int K = k * k * cinPad;
+    std::vector<float> Wk((size_t)rows * K, 0.f);
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int ky = 0; ky < k; ++ky)
+                for (int kx = 0; kx < k; ++kx)
+                    Wk[(size_t)co * K + (ky * k + kx) * cinPad + ci] = w_oihw[(((size_t)co * cin + ci) * k + ky) * k + kx];
+    std::vector<float> sc(scale_, scale_ + cout), sh(shift_, shift_ + cout);
+    return finish_layer(*this, Wk, K, sc, sh);
+}
+
+Status ConvLayer::build_convT(const std::string& name_, bool f16_, const float* w_iohw, int cin_, int cout_,
+                              const float* bias, int cfg_) {
+    name = name_; f16 = f16_; cin = cin_; cinPad = cin_; cout = cout_; k = 1; stride = 1;
+    shuffle = true; rows = 4 * cout_; cfg = cfg_;
+    if (cin % 8) return fail(1, name + ": transposed-conv input channels must be a multiple of 8");
+    if (cout % 16) return fail(1, name + ": transposed-conv output channels must be a multiple of 16");
+    const int K = cin;
+    std::vector<float> Wk((size_t)rows * K, 0.f), sc(rows, 1.f), sh(rows, 0.f);
+    for (int ci = 0; ci < cin; ++ci)
+        for (int co = 0; co < cout; ++co)
+            for (int d = 0; d < 4; ++d)      // d = dy*2 + dx
+                Wk[(size_t)(d * cout + co) * K + ci] = w_iohw[((size_t)ci * cout + co) * 4 + d];
+    for (int d = 0; d < 4; ++d)
+        for (int co = 0; co < cout; ++co) sh[d * cout + co] = bias[co];
+    return finish_layer(*this, Wk, K, sc, sh);
+}
+
+// byte offset of every 16-B K chunk relative to the address of the pixel's top-left tap
+Status ConvLayer::get_koff(const TensorRef& x, const int** out) {
+    const KoffKey key{x.W + 2, x.Cs, x.Coff};
+    auto it = koff.find(key);
+    if (it == koff.end()) {
+        const int esz = f16 ? 2 : 4, epc = 16 / esz;
+        const int K = k * k * cinPad;
+        const int pad = (k - 1) / 2;
+        std::vector<int> tab((size_t)nStages * 8, 0);
+        for (int kc = 0; kc < nStages * 8; ++kc) {
+            int kk = kc * epc;
+            if (kk >= K) kk = 0;                         // zero weights there; keep the gather on real data
+            const int tap = kk / cinPad, ci = kk % cinPad;
+            const int ky = tap / k, kx = tap % k;
+            const long long off = ((long long)((ky + 1 - pad) * key.xWp + (kx + 1 - pad)) * x.Cs + x.Coff + ci) * esz;
+            tab[kc] = (int)off;
+        }
+        auto buf = std::make_unique<DeviceBuffer>();
+        CV_TRY(buf->upload(tab.data(), tab.size() * sizeof(int)));
+        it = koff.emplace(key, std::move(buf)).first;
+    }
+    *out = reinterpret_cast<const int*>(it->second->ptr);
+    return Status();
+}
+
+int choose_cfg(int rows, int64_t pixels) {
+    const bool wide = rows % 128 == 0;
+    const int ct = wide ? 128 : 64;
+    const int64_t blocks256 = ((pixels + 255) / 256) * ((rows + ct - 1) / ct);
+    const bool big = blocks256 >= 2 * 256;              // >= two full waves of workgroups at PT = 256
+    if (wide) return big ? kCfg128x256 : kCfg128x128;
+    return big ? kCfg64x256 : kCfg64x128;
+}
+
+// ---- engine --------------------------------------------------------------------------------------
+Engine::Engine() {}
+Engine::~Engine() { prof_clear(); }
+
+Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, const TensorRef* res, bool relu,
+                        hipStream_t s) {
+    if (x.C != L.cinPad) return fail(1, L.name + ": input slice has " + std::to_string(x.C) + " channels, layer packs " + std::to_string(L.cinPad));
+    const int esz = f16 ? 2 : 4;
+    if ((x.Cs * esz) % 16 || (x.Coff * esz) % 16 || (y.Cs * esz) % 16 || (y.Coff * esz) % 16)
+        return fail(1, L.name + ": channel strides/offsets must keep 16-byte alignment");
+    ConvParams p;
+    std::memset(&p, 0, sizeof(p));
+    const int pad = (L.k - 1) / 2;
+    int Ho, Wo;
+    if (L.shuffle) { Ho = x.H; Wo = x.W; if (y.H != 2 * x.H || y.W != 2 * x.W) return fail(1, L.name + ": output must be 2x the input"); }
+    else {
+        Ho = (x.H + 2 * pad - L.k) / L.stride + 1; Wo = (x.W + 2 * pad - L.k) / L.stride + 1;
+        if (y.H != Ho || y.W != Wo) return fail(1, L.name + ": output extent mismatch");
+    }
+    if (y.C != L.cout || y.N != x.N) return fail(1, L.name + ": output slice mismatch");
+    const int* koff = nullptr;
+    CV_TRY(L.get_koff(x, &koff));
+    p.x = reinterpret_cast<const char*>(x.base);
+    p.w = reinterpret_cast<const char*>(L.w.ptr);
+    p.koff = koff;
+    p.scale = reinterpret_cast<const float*>(L.scale.ptr);
+    p.shift = reinterpret_cast<const float*>(L.shift.ptr);
+    p.res = nullptr;
+    if (res) {
+        if (res->H != y.H || res->W != y.W || res->C != y.C) return fail(1, L.name + ": residual shape mismatch");
+        p.res = reinterpret_cast<const char*>(res->base); p.rCs = res->Cs; p.rCoff = res->Coff;
+    }
+    p.y = reinterpret_cast<char*>(y.base);
+    p.M = x.N * Ho * Wo; p.Ho = Ho; p.Wo = Wo;
+    p.xHp = x.H + 2; p.xWp = x.W + 2; p.stride = L.stride; p.xCs = x.Cs;
+    p.yHp = y.H + 2; p.yWp = y.W + 2; p.yCs = y.Cs; p.yCoff = y.Coff;
+    p.Cout = L.cout; p.rows = L.rows; p.nStages = L.nStages; p.nCt = L.nCt; p.relu = relu ? 1 : 0; p.shuffle = L.shuffle ? 1 : 0;
+    if (profiling) prof_begin(L.name, true, (double)L.macs_per_out_pixel() * (double)p.M, s);
+    hipError_t e = conv_igemm_launch(L.cfg, f16, p, s);
+    if (profiling) prof_end(s);
+    if (e != hipSuccess) return hip_fail(e, ("conv launch " + L.name).c_str());
+    return Status();
+}
+
+void Engine::prof_begin(const std::string& name, bool is_conv, double macs, hipStream_t s) {
+    ProfileEntry pe;
+    pe.name = name; pe.is_conv = is_conv; pe.macs = macs;
+    (void)hipEventCreate(&pe.e0);
+    (void)hipEventCreate(&pe.e1);
+    (void)hipEventRecord(pe.e0, s);
+    prof.push_back(pe);
+}
+void Engine::prof_end(hipStream_t s) {
+    if (!prof.empty()) (void)hipEventRecord(prof.back().e1, s);
+}
+Status Engine::prof_collect() {
+    for (auto& pe : prof) {
+        if (!pe.e0) continue;
+        CV_HIP(hipEventSynchronize(pe.e1));
+        CV_HIP(hipEventElapsedTime(&pe.ms, pe.e0, pe.e1));
+        (void)hipEventDestroy(pe.e0); (void)hipEventDestroy(pe.e1);
+        pe.e0 = pe.e1 = nullptr;
+    }
+    return Status();
+}
+void Engine::prof_clear() {
+    for (auto& pe : prof) {
+        if (pe.e0) (void)hipEventDestroy(pe.e0);
+        if (pe.e1) (void)hipEventDestroy(pe.e1);
+    }
+    prof.clear();
+}
+
+}  // namespace cv

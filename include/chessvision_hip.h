@@ -1,0 +1,156 @@
+/*
+ * chessvision_hip.h -- C ABI of libchessvision_hip.so
+ *
+ * MI355X (gfx950 / CDNA4) implementation of the ChessVision CNN inference hot path:
+ *   - UNet(3 -> 1) 256x256 board-segmentation forward
+ *   - ResNet-18 (1 channel in, 13 classes) 64x64 square-classifier forward
+ *
+ * The reference (gudbrandtandberg/ChessVision-3LC) is pure Python and has no FFI of its own; the seam
+ * this library sits behind is the reference's "callable model object" boundary:
+ *     chessvision/core.py:220   logits = self.board_extractor(image_batch)      -> cv_unet_forward
+ *     chessvision/core.py:241   predictions = self.classifier(batch)            -> cv_resnet18_forward
+ *     chessvision/core.py:84-106, utils.py:42-86  model construction + checkpoint load
+ *                                                                               -> cv_engine_create,
+ *                                                                                  cv_load_unet, cv_load_resnet18
+ *     chessvision/core.py:215-216 (u8 HWC /255 -> NCHW), core.py:273 + utils.py:101-112 (sigmoid,
+ *     threshold -> 0/255 mask)                                                  -> cv_unet_forward_u8
+ *     chessvision/core.py:236-237 (/=255), core.py:242 (softmax dim=1)          -> cv_resnet18_forward_u8
+ * The ctypes binding a maintainer adds on the reference side is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns CV_OK (0) or a CV_ERR_* code; cv_last_error() returns a thread-local,
+ *     NUL-terminated description of the most recent failure on the calling thread.  Nothing aborts.
+ *   - all tensor arguments of the *_forward* functions are DEVICE pointers on the engine's device;
+ *     `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are asynchronous
+ *     with respect to the host and ordered on `stream`.
+ *   - the caller owns inputs and outputs; the engine owns its packed weights and its workspace and
+ *     frees them in cv_engine_destroy.  The library never frees caller memory.
+ *   - an engine serialises concurrent forward calls with an internal mutex (one workspace per engine).
+ *   - plain C types only: no torch / C++ types cross this boundary.
+ */
+#ifndef CHESSVISION_HIP_H
+#define CHESSVISION_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CV_ABI_VERSION 1
+
+enum cv_status {
+    CV_OK = 0,
+    CV_ERR_INVALID = 1,   /* bad argument / shape / missing or mis-shaped parameter            */
+    CV_ERR_HIP = 2,       /* a HIP runtime call failed (message carries hipGetErrorString)     */
+    CV_ERR_STATE = 3,     /* model not loaded, wrong device, ...                               */
+    CV_ERR_NOMEM = 4
+};
+
+/* arithmetic type of the convolution path */
+enum cv_precision {
+    CV_PREC_F32 = 0,      /* f32 activations/weights, f32-input MFMA (exact f32 products, f32 accumulate) */
+    CV_PREC_F16 = 1       /* f16 activations/weights, f16 MFMA with f32 accumulate, f32 BN/bias epilogue  */
+};
+
+typedef struct cv_engine cv_engine_t;     /* opaque */
+
+/* One entry of a PyTorch state dict: name = state-dict key (reference key names, e.g.
+ * "inc.double_conv.0.weight", "layer2.0.downsample.1.running_var", "fc.bias"); data = HOST pointer to
+ * contiguous row-major float32.  Non-float entries (num_batches_tracked) may be omitted. */
+typedef struct cv_param {
+    const char*  name;
+    const float* data;
+    int32_t      ndim;
+    int64_t      shape[4];
+} cv_param_t;
+
+/* ---- library / error ---------------------------------------------------------------------------- */
+int         cv_abi_version(void);
+const char* cv_last_error(void);
+int         cv_device_count(int* count);
+
+/* ---- engine lifecycle ---------------------------------------------------------------------------- */
+/* device: HIP device ordinal; precision: enum cv_precision.  Replaces nn.Module.to(device)/.eval()
+ * (core.py:105-106,149-150): an engine is always in inference mode. */
+int cv_engine_create(int device, int precision, cv_engine_t** out);
+int cv_engine_destroy(cv_engine_t* eng);
+
+/* Load + pack weights (host fp32 state dict -> device, BN folded to per-channel scale/shift applied in
+ * the conv epilogue).  cv_load_unet auto-detects the transposed-conv vs bilinear variant from the
+ * presence of "up1.up.weight" and validates every key/shape, failing with the offending key name.
+ * Replaces model.load_state_dict(...) of utils.py:59-79. */
+int cv_load_unet(cv_engine_t* eng, const cv_param_t* params, int n_params);
+int cv_load_resnet18(cv_engine_t* eng, const cv_param_t* params, int n_params);
+
+/* Largest number of images (UNet) / squares (ResNet) processed per internal pass; larger batches are
+ * looped inside the forward call.  0 = keep default.  Must be called before the first forward. */
+int cv_engine_set_chunk(cv_engine_t* eng, int unet_images, int resnet_squares);
+
+/* ---- forward (the hot path) ---------------------------------------------------------------------- */
+/* x: (batch,3,256,256) float32 NCHW in [0,1]  ->  logits: (batch,1,256,256) float32.
+ * Same tensor contract as `self.board_extractor(image_batch)` (core.py:220). */
+int cv_unet_forward(cv_engine_t* eng, const float* x, int batch, float* logits, void* stream);
+
+/* x: (n,1,64,64) float32 in [0,1]  ->  logits: (n,13) float32 (no softmax).
+ * Same tensor contract as `self.classifier(batch)` (core.py:241). */
+int cv_resnet18_forward(cv_engine_t* eng, const float* x, int n, float* logits, void* stream);
+
+/* Fused variants for the batched pipeline (u8 in, pre/post-processing of core.py on device):
+ * x_u8: (batch,256,256,3) uint8 HWC, channel order as given (no BGR->RGB swap, core.py:212-216);
+ * logits: (batch,1,256,256) float32; mask (nullable): (batch,256,256) uint8 = 255 where
+ * sigmoid(logit) > threshold else 0 (core.py:273, utils.py:101-112). */
+int cv_unet_forward_u8(cv_engine_t* eng, const uint8_t* x_u8, int batch, float* logits, uint8_t* mask,
+                       float threshold, void* stream);
+/* squares_u8: (n,64,64) uint8 -> probs: (n,13) float32 = softmax(logits, dim=1) (core.py:236-242). */
+int cv_resnet18_forward_u8(cv_engine_t* eng, const uint8_t* squares_u8, int n, float* probs, void* stream);
+
+/* (n,13) logits -> softmax probabilities, in place allowed (core.py:242). */
+int cv_softmax13(cv_engine_t* eng, const float* logits, int n, float* probs, void* stream);
+
+/* ---- introspection (tests, bench, profiling) ----------------------------------------------------- */
+/* Copy an intermediate activation of the LAST forward chunk out of the workspace as float32 NCHW
+ * (n,c,h,w written to dims[4]).  `name` is the producing module's state-dict prefix, e.g.
+ * "inc.double_conv.3", "down4.maxpool_conv.1.double_conv.5" (= named_modules()[52],
+ * train_unet.py:210), "up1.up", "layer1.0", "maxpool".  out_capacity in floats.  Synchronises. */
+int cv_get_activation(cv_engine_t* eng, const char* model, const char* name, float* out_host,
+                      size_t out_capacity, int64_t dims[4]);
+
+/* Algorithmic work of one forward: multiply-accumulates per image (UNet) / per square (ResNet). */
+int cv_model_macs(cv_engine_t* eng, const char* model, int64_t* macs);
+
+/* Time the conv kernels of one forward with HIP events on `stream` (used by bench.py for the
+ * roofline figure): runs the forward `iters` times on resident inputs and returns the summed
+ * duration (ms) of all implicit-GEMM conv launches and their count. */
+int cv_profile_convs(cv_engine_t* eng, const char* model, const void* x, int batch, void* out, int iters,
+                     void* stream, float* conv_ms_total, int* conv_launches, float* all_ms_total);
+
+/* Iterate the per-launch records of the last cv_profile_convs call (index 0 .. until CV_ERR_INVALID):
+ * name = producing module, ms = event-timed duration, macs = algorithmic multiply-accumulates. */
+int cv_profile_entry(cv_engine_t* eng, int index, char* name, int name_cap, float* ms, double* macs,
+                     int* is_conv);
+
+/* Stand-alone single-layer entry points used by the parity tests (float32 NCHW device tensors in,
+ * float32 NCHW out; packing to the internal layout happens inside, on `stream`).
+ *   conv:  y = act( scale[c] * conv2d(x, w, stride, pad=(k-1)/2) + shift[c] (+ residual) )
+ *          w: HOST (cout,cin,k,k) float32; scale/shift: HOST (cout); residual nullable (device). */
+int cv_op_conv2d(cv_engine_t* eng, const float* x, int n, int cin, int h, int w_, const float* w_host,
+                 int cout, int k, int stride, const float* scale_host, const float* shift_host,
+                 const float* residual, int relu, float* y, void* stream);
+/*   conv-transpose k2 s2:  y(n,cout,2h,2w) = convT(x, w) + bias;  w: HOST (cin,cout,2,2) */
+int cv_op_conv_transpose2x2(cv_engine_t* eng, const float* x, int n, int cin, int h, int w_,
+                            const float* w_host, int cout, const float* bias_host, float* y, void* stream);
+int cv_op_maxpool2x2(cv_engine_t* eng, const float* x, int n, int c, int h, int w_, float* y, void* stream);
+int cv_op_maxpool3x3s2(cv_engine_t* eng, const float* x, int n, int c, int h, int w_, float* y, void* stream);
+int cv_op_upsample_bilinear2x(cv_engine_t* eng, const float* x, int n, int c, int h, int w_, float* y,
+                              void* stream);
+
+/* MFMA lane-map self test: computes D = A(16xK) * B(Kx16) with the kernels' fragment loaders for both
+ * precisions and returns the max abs error against a host reference (used by tests; 0 expected). */
+int cv_selftest_mfma(cv_engine_t* eng, float* max_err_f16, float* max_err_f32);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHESSVISION_HIP_H */
