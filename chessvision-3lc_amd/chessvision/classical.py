@@ -1,0 +1,259 @@
+"""Classical-CV stages between the two CNNs, restated on numpy (no OpenCV in this image or on the GPU box).
+
+These are the SURVEY.md section 8(f) "next" rows on the CPU side of the hot path; the reference calls OpenCV
+for all of them (``chessvision/core.py:212,299-300,360,373-374,394,398``; ``chessvision/utils.py:131-132``).
+OpenCV 4.11 is not importable here, so nothing below can be bit-pinned against it; each function states the
+OpenCV behaviour it follows, and ``tests/test_classical.py`` pins the mask -> quadrangle chain on the reference's
+own fixtures (``data/board_extraction/masks/*.png`` against ``coordinates.json``).
+"""
+from __future__ import annotations
+
+import numpy as np
+from numpy.typing import NDArray
+from scipy import ndimage
+
+# 8-neighbourhood in clockwise order starting at west, (dy, dx) in image coordinates (y down)
+_NBR = [(0, -1), (-1, -1), (-1, 0), (-1, 1), (0, 1), (1, 1), (1, 0), (1, -1)]
+_NBR_INDEX = {d: i for i, d in enumerate(_NBR)}
+
+
+# ---- resize (cv2.resize(..., interpolation=cv2.INTER_AREA), core.py:212) --------------------------------
+def _area_weights(src: int, dst: int) -> NDArray[np.float64]:
+    """(dst, src) matrix of pixel-coverage fractions for a down-scale src -> dst."""
+    scale = src / dst
+    w = np.zeros((dst, src), dtype=np.float64)
+    for d in range(dst):
+        lo, hi = d * scale, (d + 1) * scale
+        for s in range(int(np.floor(lo)), min(src, int(np.ceil(hi)))):
+            w[d, s] = max(0.0, min(hi, s + 1) - max(lo, s)) / scale
+    return w
+
+
+def _linear_weights(src: int, dst: int) -> NDArray[np.float64]:
+    scale = src / dst
+    w = np.zeros((dst, src), dtype=np.float64)
+    for d in range(dst):
+        f = (d + 0.5) * scale - 0.5
+        i0 = int(np.floor(f))
+        t = f - i0
+        a, b = min(max(i0, 0), src - 1), min(max(i0 + 1, 0), src - 1)
+        w[d, a] += 1.0 - t
+        w[d, b] += t
+    return w
+
+
+def resize_area(image: NDArray[np.uint8], size: tuple[int, int]) -> NDArray[np.uint8]:
+    """INTER_AREA resize to ``size = (width, height)``.
+
+    Integer shrink factors are the exact box mean with round-half-up (OpenCV's ResizeAreaFast:
+    ``(sum + n/2) / n``); fractional shrink uses coverage-weighted means; enlarging falls back to bilinear, which is
+    what INTER_AREA does when the scale is >= 1."""
+    w_out, h_out = size
+    img = image if image.ndim == 3 else image[:, :, None]
+    h, w, _ = img.shape
+    if (h, w) == (h_out, w_out):
+        out = img.copy()
+    elif h % h_out == 0 and w % w_out == 0:
+        fy, fx = h // h_out, w // w_out
+        acc = img.reshape(h_out, fy, w_out, fx, -1).astype(np.uint32).sum(axis=(1, 3))
+        out = ((acc + (fy * fx) // 2) // (fy * fx)).astype(np.uint8)
+    else:
+        wy = _area_weights(h, h_out) if h_out <= h else _linear_weights(h, h_out)
+        wx = _area_weights(w, w_out) if w_out <= w else _linear_weights(w, w_out)
+        acc = np.einsum("ys,swc->ywc", wy, img.astype(np.float64))
+        acc = np.einsum("xw,ywc->yxc", wx, acc)
+        out = np.clip(np.rint(acc), 0, 255).astype(np.uint8)
+    return out if image.ndim == 3 else out[:, :, 0]
+
+
+# ---- contours (cv2.findContours(mask, RETR_CCOMP, CHAIN_APPROX_*), core.py:360) -------------------------
+def _trace_border(f: NDArray[np.bool_], start: tuple[int, int], prev: tuple[int, int]) -> NDArray[np.int32]:
+    """Suzuki-Abe border following (step 3 of Algorithm 1) from ``start`` with ``prev`` the background pixel
+    the raster scan came from.  Returns the border as (x, y) points in traversal order."""
+    h, w = f.shape
+
+    def at(y, x):
+        return 0 <= y < h and 0 <= x < w and f[y, x]
+
+    i, j = start
+    # 3.1: clockwise around (i, j) starting from prev, find a foreground pixel
+    k0 = _NBR_INDEX[(prev[0] - i, prev[1] - j)]
+    first = None
+    for s in range(8):
+        dy, dx = _NBR[(k0 + s) % 8]
+        if at(i + dy, j + dx):
+            first = (i + dy, j + dx)
+            break
+    if first is None:
+        return np.array([[j, i]], dtype=np.int32)
+    pts = []
+    i2, j2 = first
+    i3, j3 = i, j
+    while True:
+        # 3.3: counter-clockwise around (i3, j3) starting after (i2, j2)
+        k = _NBR_INDEX[(i2 - i3, j2 - j3)]
+        for s in range(1, 9):
+            dy, dx = _NBR[(k - s) % 8]
+            if at(i3 + dy, j3 + dx):
+                i4, j4 = i3 + dy, j3 + dx
+                break
+        pts.append((j3, i3))
+        if (i4, j4) == (i, j) and (i3, j3) == first:
+            break
+        i2, j2 = i3, j3
+        i3, j3 = i4, j4
+    return np.array(pts, dtype=np.int32)
+
+
+def find_contours(mask: NDArray[np.uint8]) -> list[NDArray[np.int32]]:
+    """Outer borders of the 8-connected foreground components, then hole borders (RETR_CCOMP returns both
+    levels as one flat list).  Every border pixel is returned (CHAIN_APPROX_NONE); the reference asks for
+    TC89_KCOS chain compression, which only thins the point list that ``approx_poly_dp`` consumes next."""
+    f = np.asarray(mask) != 0
+    out: list[NDArray[np.int32]] = []
+    lab, n = ndimage.label(f, structure=np.ones((3, 3), dtype=bool))
+    if n:
+        firsts = ndimage.minimum_position(np.arange(f.size).reshape(f.shape), lab, index=np.arange(1, n + 1))
+        for (y, x) in firsts:
+            out.append(_trace_border(f, (int(y), int(x)), (int(y), int(x) - 1)).reshape(-1, 1, 2))
+    # holes: 4-connected background components that do not touch the frame
+    blab, bn = ndimage.label(~f)
+    if bn:
+        frame = set(np.unique(np.concatenate([blab[0], blab[-1], blab[:, 0], blab[:, -1]]))) - {0}
+        ids = [k for k in range(1, bn + 1) if k not in frame]
+        if ids:
+            firsts = ndimage.minimum_position(np.arange(f.size).reshape(f.shape), blab, index=ids)
+            for (y, x) in firsts:       # (y, x) = first hole pixel; the pixel to its left is foreground
+                out.append(_trace_border(f, (int(y), int(x) - 1), (int(y), int(x))).reshape(-1, 1, 2))
+    return out
+
+
+def contour_area(contour: NDArray[np.int32]) -> float:
+    p = contour.reshape(-1, 2).astype(np.float64)
+    if len(p) < 3:
+        return 0.0
+    x, y = p[:, 0], p[:, 1]
+    return float(abs(np.dot(x, np.roll(y, -1)) - np.dot(y, np.roll(x, -1))) * 0.5)
+
+
+def bounding_rect(contour: NDArray[np.int32]) -> tuple[int, int, int, int]:
+    p = contour.reshape(-1, 2)
+    x0, y0 = int(p[:, 0].min()), int(p[:, 1].min())
+    return x0, y0, int(p[:, 0].max()) - x0 + 1, int(p[:, 1].max()) - y0 + 1
+
+
+def arc_length(contour: NDArray[np.int32], closed: bool = True) -> float:
+    p = contour.reshape(-1, 2).astype(np.float64)
+    d = np.diff(np.vstack([p, p[:1]]) if closed else p, axis=0)
+    return float(np.sqrt((d * d).sum(axis=1)).sum())
+
+
+def approx_poly_dp(contour: NDArray[np.int32], epsilon: float) -> NDArray[np.int32]:
+    """Douglas-Peucker for a CLOSED curve, following cv2.approxPolyDP's strategy: (1) three farthest-point hops
+    from point 0 pick the initial split, (2) stack-driven refinement against ``epsilon``, (3) one clean-up sweep
+    that drops vertices lying within sqrt(0.5)*epsilon of the chord between their neighbours."""
+    src = contour.reshape(-1, 2).astype(np.int64)
+    count = len(src)
+    if count == 0:
+        return np.zeros((0, 1, 2), dtype=np.int32)
+    eps2 = float(epsilon) * float(epsilon)
+    pos, right_start, le_eps = 0, 0, False
+    for _ in range(3):
+        pos = (pos + right_start) % count
+        d = ((np.roll(src, -pos, axis=0) - src[pos]) ** 2).sum(axis=1)
+        j = int(np.argmax(d[1:])) + 1 if count > 1 else 0
+        right_start = j
+        le_eps = float(d[j]) <= eps2
+    if le_eps:
+        return src[pos].reshape(1, 1, 2).astype(np.int32)
+    a, b = pos % count, (right_start + pos) % count
+    stack = [(b, a), (a, b)]
+    dst: list[tuple[int, int]] = []
+    while stack:
+        s, e = stack.pop()
+        start, end = src[s], src[e]
+        if (s + 1) % count != e:
+            idx = np.arange(s + 1, e if e > s else e + count) % count
+            dx, dy = float(end[0] - start[0]), float(end[1] - start[1])
+            dist = np.abs((src[idx, 1] - start[1]) * dx - (src[idx, 0] - start[0]) * dy)
+            m = int(np.argmax(dist))
+            le = float(dist[m]) ** 2 <= eps2 * (dx * dx + dy * dy)
+            split = int(idx[m])
+        else:
+            le, split = True, s
+        if le:
+            dst.append((int(start[0]), int(start[1])))
+        else:
+            stack.append((split, e))
+            stack.append((s, split))
+    # clean-up sweep over the closed result: drop a vertex when it is (nearly) on the chord of its neighbours
+    pts = list(dst)
+    i = 0
+    while len(pts) > 2 and i < len(pts):
+        start, cur, end = pts[i - 1], pts[i], pts[(i + 1) % len(pts)]
+        dx, dy = end[0] - start[0], end[1] - start[1]
+        dist = abs((cur[0] - start[0]) * dy - (cur[1] - start[1]) * dx)
+        inner = (cur[0] - start[0]) * (end[0] - cur[0]) + (cur[1] - start[1]) * (end[1] - cur[1])
+        if dist * dist <= 0.5 * eps2 * (dx * dx + dy * dy) and dx != 0 and dy != 0 and inner >= 0:
+            del pts[i]
+        else:
+            i += 1
+    return np.array(pts, dtype=np.int32).reshape(-1, 1, 2)
+
+
+# ---- perspective (cv2.getPerspectiveTransform + cv2.warpPerspective, utils.py:131-132) -----------------
+def get_perspective_transform(src: NDArray[np.float32], dst: NDArray[np.float32]) -> NDArray[np.float64]:
+    """3x3 homography mapping the four ``src`` points onto ``dst`` (h33 = 1)."""
+    src = np.asarray(src, dtype=np.float64).reshape(4, 2)
+    dst = np.asarray(dst, dtype=np.float64).reshape(4, 2)
+    a = np.zeros((8, 8))
+    b = np.zeros(8)
+    for i, ((x, y), (u, v)) in enumerate(zip(src, dst)):
+        a[i] = [x, y, 1, 0, 0, 0, -x * u, -y * u]
+        a[i + 4] = [0, 0, 0, x, y, 1, -x * v, -y * v]
+        b[i], b[i + 4] = u, v
+    h = np.linalg.solve(a, b)
+    return np.append(h, 1.0).reshape(3, 3)
+
+
+def warp_perspective(image: NDArray[np.uint8], m: NDArray[np.float64], size: tuple[int, int]) -> NDArray[np.uint8]:
+    """dst(x, y) = bilinear(src, M^-1 (x, y, 1)), constant-zero border; source coordinates are snapped to 1/32
+    pixel like OpenCV's fixed-point remap (INTER_BITS = 5)."""
+    w_out, h_out = size
+    inv = np.linalg.inv(m)
+    xs, ys = np.meshgrid(np.arange(w_out, dtype=np.float64), np.arange(h_out, dtype=np.float64))
+    den = inv[2, 0] * xs + inv[2, 1] * ys + inv[2, 2]
+    den = np.where(den == 0, 1e-12, den)
+    sx = (inv[0, 0] * xs + inv[0, 1] * ys + inv[0, 2]) / den
+    sy = (inv[1, 0] * xs + inv[1, 1] * ys + inv[1, 2]) / den
+    sx = np.rint(sx * 32.0) / 32.0
+    sy = np.rint(sy * 32.0) / 32.0
+    x0, y0 = np.floor(sx).astype(np.int64), np.floor(sy).astype(np.int64)
+    fx, fy = sx - x0, sy - y0
+    img = image if image.ndim == 3 else image[:, :, None]
+    h, w, c = img.shape
+    padded = np.zeros((h + 2, w + 2, c), dtype=np.float64)
+    padded[1:-1, 1:-1] = img
+
+    def tap(yy, xx):
+        yy = np.clip(yy + 1, 0, h + 1)
+        xx = np.clip(xx + 1, 0, w + 1)
+        return padded[yy, xx]
+
+    inside = (x0 >= -1) & (x0 < w) & (y0 >= -1) & (y0 < h)
+    fx, fy = fx[..., None], fy[..., None]
+    val = ((1 - fy) * ((1 - fx) * tap(y0, x0) + fx * tap(y0, x0 + 1)) +
+           fy * ((1 - fx) * tap(y0 + 1, x0) + fx * tap(y0 + 1, x0 + 1)))
+    val = np.where(inside[..., None], val, 0.0)
+    out = np.clip(np.rint(val), 0, 255).astype(np.uint8)
+    return out if image.ndim == 3 else out[:, :, 0]
+
+
+def bgr_to_gray(image: NDArray[np.uint8]) -> NDArray[np.uint8]:
+    """cv2.cvtColor(BGR2GRAY) for 8-bit: (1868 B + 9617 G + 4899 R + 2^13) >> 14."""
+    b, g, r = (image[..., i].astype(np.int32) for i in range(3))
+    return ((b * 1868 + g * 9617 + r * 4899 + (1 << 13)) >> 14).astype(np.uint8)
+
+
+def flip_horizontal(image: NDArray[np.uint8]) -> NDArray[np.uint8]:
+    return np.ascontiguousarray(image[:, ::-1])

@@ -1,0 +1,295 @@
+"""``ChessVision`` -- image -> board -> FEN, with both CNN forwards running on MI355X through the C ABI.
+
+Mirrors the public surface of the reference's ``chessvision/core.py`` (constructor kwargs, attributes read by
+``scripts/eval/evaluate.py:357-358`` and ``tests/test_chessvision.py:29-42``, the two model properties, the three
+pipeline methods and the static helpers) so the Flask endpoint and the evaluation script run unchanged.  The
+model objects behind ``board_extractor`` / ``classifier`` are ``HipBoardExtractor`` / ``HipPieceClassifier``;
+the classical stages in between run on the host (``classical.py``) exactly where the reference runs OpenCV.
+
+Deliberate deviations, all on the permissive side:
+  * ``board_extractor_weights=None`` resolves to ``constants.BEST_EXTRACTOR_WEIGHTS`` at load time (the reference
+    crashes on ``Path(None)``); the attribute itself keeps the value passed in.
+  * model ids ``""`` / ``"unet"`` / ``"hip"`` select the UNet, ``""`` / ``"resnet18"`` the ResNet-18
+    (``evaluate.py:212,214`` passes ``""``); ``"yolo"`` raises ImportError -- that model family is out of scope.
+  * lazy initialisation is guarded by a lock (Flask request threads share one instance, ``cv_endpoint.py:131-133``).
+  * extras: ``precision=`` kwarg (env ``CHESSVISION_HIP_PRECISION``, default "f32"), ``process_images`` (batched),
+    ``predict`` alias.
+"""
+from __future__ import annotations
+
+import logging
+import os
+import threading
+import time
+from typing import Sequence
+
+import numpy as np
+import torch
+from numpy.typing import NDArray
+
+from . import classical, constants, utils
+from .cv_types import BoardExtractionResult, ChessVisionResult, PositionResult, ValidationFix
+from .fen import board_fen
+
+logger = logging.getLogger(__name__)
+
+_UNET_IDS = (None, "", "unet", "hip")
+_RESNET_IDS = ("", "resnet18", "hip")
+
+
+class ChessVision:
+    """Chess position detection from images (drop-in for the reference class of the same name)."""
+
+    def __init__(
+        self,
+        board_extractor_weights: str | None = None,
+        board_extractor_model_id: str | None = None,
+        classifier_weights: str | None = None,
+        classifier_model_id: str | None = None,
+        lazy_load: bool = True,
+        precision: str | None = None,
+    ):
+        logger.info("Initializing ChessVision instance...")
+        self.device = utils.get_device()
+        self._board_extractor = None
+        self._classifier = None
+        self._board_extractor_weights = board_extractor_weights
+        self._board_extractor_model_id = board_extractor_model_id
+        self._classifier_weights = classifier_weights
+        self._classifier_model_id = classifier_model_id
+        self._precision = precision or os.environ.get("CHESSVISION_HIP_PRECISION", "f32")
+        self._engine = None
+        self._init_lock = threading.RLock()
+        if not lazy_load:
+            logger.info("Eager loading models...")
+            self._initialize_board_extractor()
+            self._initialize_classifier()
+            logger.info("Models loaded successfully")
+
+    # ---- model objects ---------------------------------------------------------------------------
+    def _get_engine(self):
+        if self._engine is None:
+            from .hip_backend import HipEngine          # raises when the library or the GPU is missing
+
+            self._engine = HipEngine(self.device, precision=self._precision)
+        return self._engine
+
+    @property
+    def board_extractor(self):
+        if self._board_extractor is None:
+            with self._init_lock:
+                if self._board_extractor is None:
+                    self._initialize_board_extractor()
+        assert self._board_extractor is not None
+        return self._board_extractor
+
+    @property
+    def classifier(self):
+        if self._classifier is None:
+            with self._init_lock:
+                if self._classifier is None:
+                    self._initialize_classifier()
+        assert self._classifier is not None
+        if hasattr(self._classifier, "metadata"):
+            logger.info(f"Classifier metadata: {self._classifier.metadata}")
+        return self._classifier
+
+    def _initialize_board_extractor(self) -> None:
+        logger.info("Initializing board extraction model...")
+        model_id = self._board_extractor_model_id
+        if model_id == "yolo":
+            raise ImportError("YOLO board extractors are outside the MI355X hot path (UNet only)")
+        assert model_id in _UNET_IDS, f"Invalid board extractor model ID: {model_id}"
+        model = utils.get_board_extractor_model(self._get_engine())
+        model = utils.load_model_checkpoint(model, self._board_extractor_weights or constants.BEST_EXTRACTOR_WEIGHTS,
+                                            self.device)
+        if hasattr(model, "metadata"):
+            logger.info(f"Board extractor metadata: {model.metadata}")
+        model.eval()
+        model.to(self.device)
+        self._board_extractor = model
+
+    def _initialize_classifier(self) -> None:
+        logger.info("Initializing piece classifier model...")
+        model_id = self._classifier_model_id
+        if model_id == "yolo":
+            raise ImportError("YOLO classifiers are outside the MI355X hot path (ResNet-18 only)")
+        if model_id is None:
+            # the reference tries YOLO first and falls back to ResNet-18 on ImportError (core.py:113-130)
+            logger.info("YOLO not available, falling back to ResNet18")
+            self._classifier_model_id = "resnet18"
+        weights = self._classifier_weights or constants.BEST_CLASSIFIER_WEIGHTS
+        model = utils.get_classifier_model(self._classifier_model_id or "resnet18", self._get_engine())
+        model = utils.load_model_checkpoint(model, weights, self.device)
+        self._classifier_weights = weights
+        model.eval()
+        model.to(self.device)
+        self._classifier = model
+
+    # ---- pipeline -----------------------------------------------------------------------------------
+    def process_image(self, image: NDArray[np.uint8], threshold: float = 0.5, flip: bool = False) -> ChessVisionResult:
+        """Raw BGR image -> board extraction -> (if a board was found) position."""
+        assert isinstance(image, np.ndarray), "Image must be a numpy array"
+        assert image.dtype == np.uint8, "Image must be uint8"
+        assert len(image.shape) == 3, "Image must be 3-dimensional (H,W,C)"
+        logger.info("Starting image processing pipeline...")
+        started = time.time()
+        board_result = self.extract_board(image, threshold)
+        position_result = None
+        if board_result.board_image is None:
+            logger.info("No valid board found in image")
+        else:
+            logger.info("Board successfully extracted")
+            position_result = self.classify_position(board_result.board_image, flip)
+            logger.info("Position classification completed")
+        elapsed = time.time() - started
+        logger.info(f"Processing completed in {elapsed:.2f} seconds")
+        return ChessVisionResult(board_extraction=board_result, position=position_result, processing_time=elapsed)
+
+    predict = process_image                                  # name used by BASELINE.json's north_star
+
+    def extract_board(self, image: NDArray[np.uint8], threshold: float = 0.5) -> BoardExtractionResult:
+        comp_image = classical.resize_area(image, constants.INPUT_SIZE)
+        batch = torch.Tensor(np.array([comp_image])) / 255           # (1,256,256,3) float32, channels as given
+        batch = batch.permute(0, 3, 1, 2).to(self.device)
+        with torch.no_grad():
+            logits = self.board_extractor(batch)[0].squeeze().cpu().numpy()
+        return self.process_board_extraction_logits(logits, image, threshold)
+
+    def classify_position(self, board_image: NDArray[np.uint8], flip: bool = False) -> PositionResult:
+        squares = self.extract_squares(board_image)
+        square_names = constants.SQUARE_NAMES_FLIPPED if flip else constants.SQUARE_NAMES_NORMAL
+        batch = torch.Tensor(squares).permute(0, 3, 1, 2).to(self.device)
+        batch /= 255.0
+        with torch.no_grad():
+            predictions = self.classifier(batch)
+            probabilities = torch.softmax(predictions, dim=1)
+            probabilities_np = probabilities.detach().cpu().numpy()
+        return self.process_position_probabilities(probabilities=probabilities_np, square_names=square_names,
+                                                   square_crops=squares)
+
+    def process_images(self, images: Sequence[NDArray[np.uint8]], threshold: float = 0.5,
+                       flip: bool = False) -> list[ChessVisionResult]:
+        """Batched pipeline (new; the reference processes one image per call): one UNet pass over all images with
+        the u8 -> /255 packing and the sigmoid/threshold mask on device, host contour/warp per board, then ONE
+        classifier pass over every found board's 64 squares with softmax on device."""
+        started = time.time()
+        for image in images:
+            assert isinstance(image, np.ndarray) and image.dtype == np.uint8 and image.ndim == 3
+        if not images:
+            return []
+        _ = self.board_extractor, self.classifier
+        eng = self._get_engine()
+        small = np.stack([classical.resize_area(im, constants.INPUT_SIZE) for im in images])
+        logits_dev, _mask = eng.unet_forward_u8(torch.from_numpy(small), threshold=threshold, want_mask=False)
+        logits = logits_dev[:, 0].cpu().numpy()
+        boards = [self.process_board_extraction_logits(logits[i], images[i], threshold) for i in range(len(images))]
+        found = [i for i, b in enumerate(boards) if b.board_image is not None]
+        positions: dict[int, PositionResult] = {}
+        if found:
+            squares = [self.extract_squares(boards[i].board_image) for i in found]
+            flat = torch.from_numpy(np.concatenate(squares)[..., 0])                  # (64*n, 64, 64) uint8
+            probs = eng.resnet18_forward_u8(flat).cpu().numpy().reshape(len(found), 64, constants.NUM_CLASSES)
+            names = constants.SQUARE_NAMES_FLIPPED if flip else constants.SQUARE_NAMES_NORMAL
+            for k, i in enumerate(found):
+                positions[i] = self.process_position_probabilities(probs[k], names, squares[k])
+        per_image = (time.time() - started) / len(images)
+        return [ChessVisionResult(board_extraction=boards[i], position=positions.get(i), processing_time=per_image)
+                for i in range(len(images))]
+
+    # ---- host-side post-processing (static, usable without models) ----------------------------------
+    @staticmethod
+    def process_board_extraction_logits(logits: NDArray[np.float32], orig_image: NDArray[np.uint8],
+                                        threshold: float) -> BoardExtractionResult:
+        assert isinstance(logits, np.ndarray), "Logits must be a numpy array"
+        assert logits.dtype == np.float32, "Logits must be float32"
+        assert isinstance(orig_image, np.ndarray), "Original image must be a numpy array"
+        assert orig_image.dtype == np.uint8, "Original image must be uint8"
+        probabilities = torch.sigmoid(torch.from_numpy(logits)).numpy()
+        binary_mask = utils.create_binary_mask(probabilities, threshold)
+        quadrangle = ChessVision._find_quadrangle(binary_mask)
+        if quadrangle is None:
+            logger.info("Failed to extract board from image")
+            return BoardExtractionResult(board_image=None, binary_mask=binary_mask, quadrangle=None, probabilities=logits)
+        scaled = ChessVision._scale_quadrangle(quadrangle, (orig_image.shape[0], orig_image.shape[1]))
+        assert scaled.dtype == np.float32, "Scaled quadrangle must be float32"
+        board = utils.extract_perspective(orig_image, scaled, constants.BOARD_SIZE)
+        board = classical.flip_horizontal(classical.bgr_to_gray(board))
+        return BoardExtractionResult(board_image=board, binary_mask=binary_mask, quadrangle=scaled, probabilities=logits)
+
+    @staticmethod
+    def process_position_probabilities(probabilities: NDArray[np.float32], square_names: list[str],
+                                       square_crops: NDArray[np.uint8]) -> PositionResult:
+        best = np.argmax(probabilities, axis=1)
+        labels = [constants.LABEL_NAMES[i] for i in best]
+        original_fen = board_fen(labels, square_names)
+        validated, fixes = ChessVision.validate_position(labels, probabilities, square_names)
+        return PositionResult(fen=board_fen(validated, square_names), original_fen=original_fen,
+                              model_probabilities=probabilities, squares=square_crops, square_names=square_names,
+                              validation_fixes=fixes)
+
+    @staticmethod
+    def _find_quadrangle(mask: NDArray[np.uint8]) -> NDArray[np.int32] | None:
+        """First contour that simplifies (epsilon = 10% of its perimeter) to exactly four vertices."""
+        contours = classical.find_contours(mask)
+        if len(contours) > 1:
+            contours = ChessVision._filter_contours((mask.shape[0], mask.shape[1]), contours)
+        for contour in contours:
+            candidate = classical.approx_poly_dp(contour, 0.1 * classical.arc_length(contour, True))
+            if len(candidate) == 4:
+                return ChessVision._rotate_quadrangle(candidate)
+        return None
+
+    @staticmethod
+    def _filter_contours(img_shape: tuple[int, int], contours: list[NDArray[np.int32]], min_ratio_bounding: float = 0.6,
+                         min_area_percentage: float = 0.35, max_area_percentage: float = 1.0) -> list[NDArray[np.int32]]:
+        """Keep contours covering 35%..100% of the mask whose bounding box is at least 0.6 square."""
+        mask_area = float(img_shape[0] * img_shape[1])
+        kept = []
+        for contour in contours:
+            share = classical.contour_area(contour) / mask_area
+            if not (min_area_percentage <= share <= max_area_percentage):
+                continue
+            _, _, w, h = classical.bounding_rect(contour)
+            if utils.ratio(h, w) >= min_ratio_bounding:
+                kept.append(contour)
+        return kept
+
+    @staticmethod
+    def _rotate_quadrangle(approx: NDArray[np.int32]) -> NDArray[np.int32]:
+        """Start the vertex list at the top-right corner (the list runs counter-clockwise on screen)."""
+        if approx[0, 0, 0] < approx[2, 0, 0]:
+            approx = approx[[3, 0, 1, 2], :, :]
+        return approx
+
+    @staticmethod
+    def _scale_quadrangle(approx: NDArray[np.int32], orig_size: tuple[int, int]) -> NDArray[np.float32]:
+        """256-px mask coordinates -> input-image pixels; the factor uses the HEIGHT only (reference core.py:416)."""
+        return np.array(approx * (orig_size[0] / 256.0), dtype=np.float32)
+
+    @staticmethod
+    def extract_squares(board: NDArray[np.uint8]) -> NDArray[np.uint8]:
+        """(H, W) board -> (64, H/8, W/8, 1) squares in reading order a8..h8, ..., a1..h1."""
+        h, w = board.shape
+        sh, sw = h // 8, w // 8
+        tiles = board[: sh * 8, : sw * 8].reshape(8, sh, 8, sw).swapaxes(1, 2)
+        return tiles.reshape(64, sh, sw, 1)
+
+    @staticmethod
+    def validate_position(pred_labels: list[str], probabilities: NDArray[np.float32],
+                          square_names: list[str]) -> tuple[list[str], list[ValidationFix]]:
+        """Rule 1 (the only live rule in the reference, core.py:453-469): a pawn predicted on rank 1 or 8 is
+        replaced by the most probable non-pawn class.  ``pred_labels`` is modified in place, as in the reference."""
+        fixes: list[ValidationFix] = []
+        order = np.argsort(probabilities)
+        for i, (label, name) in enumerate(zip(pred_labels, square_names)):
+            if label not in ("P", "p") or name not in constants.INVALID_PAWN_SQUARES:
+                continue
+            for alt in order[i][::-1]:
+                piece = constants.LABEL_NAMES[alt]
+                if piece not in ("P", "p"):
+                    fixes.append(ValidationFix(square_name=name, original_piece=label, corrected_piece=piece,
+                                               rule_name="no_pawns_on_ends"))
+                    pred_labels[i] = piece
+                    break
+        return pred_labels, fixes
