@@ -21,9 +21,10 @@ import numpy as np
 import torch
 
 _LIB_NAME = "libchessvision_hip.so"
-PREC_F32, PREC_F16 = 0, 1
+PREC_F32, PREC_F16, PREC_F16X3 = 0, 1, 2
 _PRECISIONS = {"f32": PREC_F32, "fp32": PREC_F32, "float32": PREC_F32, "f16": PREC_F16, "fp16": PREC_F16,
-               "float16": PREC_F16}
+               "float16": PREC_F16, "f16x3": PREC_F16X3, "split": PREC_F16X3}
+_PREC_NAMES = {PREC_F32: "f32", PREC_F16: "f16", PREC_F16X3: "f16x3"}
 
 
 class HipBackendError(RuntimeError):
@@ -151,7 +152,7 @@ class HipEngine:
         if precision not in _PRECISIONS:
             raise HipBackendError(f"precision must be one of {sorted(_PRECISIONS)}")
         self.device = dev
-        self.precision = "f16" if _PRECISIONS[precision] == PREC_F16 else "f32"
+        self.precision = _PREC_NAMES[_PRECISIONS[precision]]
         self._h = ctypes.c_void_p()
         _check(self._lib.cv_engine_create(dev.index, _PRECISIONS[precision], ctypes.byref(self._h)))
         if unet_chunk or resnet_chunk:

@@ -18,7 +18,7 @@ enum ConvCfg {            // <channel tile> x <pixel tile> of one 256-thread wor
 };
 
 hipError_t conv_igemm_prepare();                                   // raise dynamic-LDS limits (once per device)
-hipError_t conv_igemm_launch(int cfg, bool f16, const ConvParams& p, hipStream_t stream);
+hipError_t conv_igemm_launch(int cfg, int dt, const ConvParams& p, hipStream_t stream);
 int conv_cfg_ct(int cfg);
 int conv_cfg_pt(int cfg);
 

@@ -27,6 +27,7 @@ namespace cv {
 template <typename T> struct FragT;
 template <> struct FragT<half_t> { typedef half8 V; };
 template <> struct FragT<float>  { typedef f4 V; };
+template <> struct FragT<split_t> { typedef half8 V; };
 
 __device__ __forceinline__ void mma16(f4& acc, const half8& a, const half8& b) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
@@ -51,9 +52,11 @@ template <int N> __device__ __forceinline__ void wait_vm_barrier() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-template <typename T, int N> struct OutVec;   // N consecutive channels of one pixel -> 16-B stores
+// N consecutive channels of one pixel -> 16-B stores.  ch0 = absolute index of the first channel in the buffer
+// (selects the [hi,lo] / [lo,hi] chunk order of split-f16 groups; unused otherwise).
+template <typename T, int N> struct OutVec;
 template <int N> struct OutVec<half_t, N> {
-    static __device__ __forceinline__ void store(half_t* dst, const float* v) {
+    static __device__ __forceinline__ void store(half_t* dst, int, const float* v) {
 #pragma unroll
         for (int i = 0; i < N; i += 8) {
             half8 h;
@@ -62,7 +65,7 @@ template <int N> struct OutVec<half_t, N> {
             *reinterpret_cast<half8*>(dst + i) = h;
         }
     }
-    static __device__ __forceinline__ void add(const half_t* src, float* v) {
+    static __device__ __forceinline__ void add(const half_t* src, int, float* v) {
 #pragma unroll
         for (int i = 0; i < N; i += 8) {
             const half8 h = *reinterpret_cast<const half8*>(src + i);
@@ -72,18 +75,42 @@ template <int N> struct OutVec<half_t, N> {
     }
 };
 template <int N> struct OutVec<float, N> {
-    static __device__ __forceinline__ void store(float* dst, const float* v) {
+    static __device__ __forceinline__ void store(float* dst, int, const float* v) {
 #pragma unroll
         for (int i = 0; i < N; i += 4) {
             f4 o = {v[i], v[i + 1], v[i + 2], v[i + 3]};
             *reinterpret_cast<f4*>(dst + i) = o;
         }
     }
-    static __device__ __forceinline__ void add(const float* src, float* v) {
+    static __device__ __forceinline__ void add(const float* src, int, float* v) {
 #pragma unroll
         for (int i = 0; i < N; i += 4) {
             const f4 o = *reinterpret_cast<const f4*>(src + i);
             v[i] += o[0]; v[i + 1] += o[1]; v[i + 2] += o[2]; v[i + 3] += o[3];
+        }
+    }
+};
+template <int N> struct OutVec<split_t, N> {
+    static __device__ __forceinline__ void store(split_t* dst, int ch0, const float* v) {
+        char* p = reinterpret_cast<char*>(dst);
+#pragma unroll
+        for (int i = 0; i < N; i += 8) {
+            const int par = ((ch0 + i) >> 3) & 1;
+            half8 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { hi[j] = (half_t)v[i + j]; lo[j] = (half_t)(v[i + j] - (float)hi[j]); }
+            *reinterpret_cast<half8*>(p + i * 4 + (par ? 16 : 0)) = hi;
+            *reinterpret_cast<half8*>(p + i * 4 + (par ? 0 : 16)) = lo;
+        }
+    }
+    static __device__ __forceinline__ void add(const split_t* src, int ch0, float* v) {
+        const char* p = reinterpret_cast<const char*>(src);
+#pragma unroll
+        for (int i = 0; i < N; i += 8) {
+            const half8 a = *reinterpret_cast<const half8*>(p + i * 4);
+            const half8 b = *reinterpret_cast<const half8*>(p + i * 4 + 16);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[i + j] += (float)a[j] + (float)b[j];
         }
     }
 };
@@ -156,18 +183,44 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 
     auto compute = [&](int buf) {
         const char* s = smem + buf * STAGE;
+        if constexpr (sizeof(T) == 4 && !__is_same(T, float)) {
+            // split-f16: one 32-deep k-step per stage.  Lane group q owns K-group q of the stage: its hi chunk sits
+            // at logical chunk 2q + (q&1), its lo chunk at 2q + 1 - (q&1) (alternating LDS bank halves).
+            const int chi = 2 * q + (q & 1), clo = 2 * q + 1 - (q & 1);
+            const int swh = (chi ^ (lane & 7)) * 16, swl = (clo ^ (lane & 7)) * 16;
+            V ah[FC], al[FC], bh[FP], bl[FP];
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            const int sw = sw0 ^ (sub * 64);
-            V a[FC], b[FP];
+            for (int f = 0; f < FC; ++f) {
+                ah[f] = *reinterpret_cast<const V*>(s + rowW + f * 2048 + swh);
+                al[f] = *reinterpret_cast<const V*>(s + rowW + f * 2048 + swl);
+            }
 #pragma unroll
-            for (int f = 0; f < FC; ++f) a[f] = *reinterpret_cast<const V*>(s + rowW + f * 2048 + sw);
-#pragma unroll
-            for (int g = 0; g < FP; ++g) b[g] = *reinterpret_cast<const V*>(s + rowX + g * 2048 + sw);
+            for (int g = 0; g < FP; ++g) {
+                bh[g] = *reinterpret_cast<const V*>(s + rowX + g * 2048 + swh);
+                bl[g] = *reinterpret_cast<const V*>(s + rowX + g * 2048 + swl);
+            }
 #pragma unroll
             for (int f = 0; f < FC; ++f)
 #pragma unroll
-                for (int g = 0; g < FP; ++g) mma16(acc[f][g], a[f], b[g]);
+                for (int g = 0; g < FP; ++g) {
+                    mma16(acc[f][g], al[f], bh[g]);      // small cross terms first, then the leading product
+                    mma16(acc[f][g], ah[f], bl[g]);
+                    mma16(acc[f][g], ah[f], bh[g]);
+                }
+        } else {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                const int sw = sw0 ^ (sub * 64);
+                V a[FC], b[FP];
+#pragma unroll
+                for (int f = 0; f < FC; ++f) a[f] = *reinterpret_cast<const V*>(s + rowW + f * 2048 + sw);
+#pragma unroll
+                for (int g = 0; g < FP; ++g) b[g] = *reinterpret_cast<const V*>(s + rowX + g * 2048 + sw);
+#pragma unroll
+                for (int f = 0; f < FC; ++f)
+#pragma unroll
+                    for (int g = 0; g < FP; ++g) mma16(acc[f][g], a[f], b[g]);
+            }
         }
     };
 
@@ -230,12 +283,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             for (int f = 0; f < FC; ++f)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[f * 4 + r] = acc[f][g][r] * sc[f * 4 + r] + sh[f * 4 + r];
-            if (rbase) OutVec<T, NV>::add(rbase + opix * p.rCs + p.rCoff + co0, v);
+            if (rbase) OutVec<T, NV>::add(rbase + opix * p.rCs + p.rCoff + co0, p.rCoff + co0, v);
             if (p.relu) {
 #pragma unroll
                 for (int i = 0; i < NV; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
             }
-            OutVec<T, NV>::store(ybase + opix * p.yCs + p.yCoff + co0, v);
+            OutVec<T, NV>::store(ybase + opix * p.yCs + p.yCoff + co0, p.yCoff + co0, v);
         }
     }
 }
@@ -270,14 +323,15 @@ hipError_t conv_igemm_prepare() {
     if ((e = prepare_one<T, CT, PT, WGC, NS>()) != hipSuccess) return e;
     CV_FOR_EACH_CFG(X, half_t)
     CV_FOR_EACH_CFG(X, float)
+    CV_FOR_EACH_CFG(X, split_t)
 #undef X
     return hipSuccess;
 }
 
-hipError_t conv_igemm_launch(int cfg, bool f16, const ConvParams& p, hipStream_t stream) {
+hipError_t conv_igemm_launch(int cfg, int dt, const ConvParams& p, hipStream_t stream) {
 #define X(T, CT, PT, WGC, NS, ID) \
     if (cfg == ID) return launch_one<T, CT, PT, WGC, NS>(p, stream);
-    if (f16) { CV_FOR_EACH_CFG(X, half_t) } else { CV_FOR_EACH_CFG(X, float) }
+    if (dt == kF16) { CV_FOR_EACH_CFG(X, half_t) } else if (dt == kSplit) { CV_FOR_EACH_CFG(X, split_t) } else { CV_FOR_EACH_CFG(X, float) }
 #undef X
     return hipErrorInvalidValue;
 }

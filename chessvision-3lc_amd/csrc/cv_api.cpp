@@ -60,7 +60,9 @@ int cv_device_count(int* count) {
 int cv_engine_create(int device, int precision, cv_engine_t** out) {
     if (!out) return finish(fail(CV_ERR_INVALID, "null out pointer"));
     *out = nullptr;
-    if (precision != CV_PREC_F32 && precision != CV_PREC_F16) return finish(fail(CV_ERR_INVALID, "unknown precision"));
+    if (precision != CV_PREC_F32 && precision != CV_PREC_F16 && precision != CV_PREC_F16X3)
+        return finish(fail(CV_ERR_INVALID, "unknown precision"));
+    static_assert((int)CV_PREC_F32 == (int)kF32 && (int)CV_PREC_F16 == (int)kF16 && (int)CV_PREC_F16X3 == (int)kSplit, "enum values must match");
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0)
@@ -75,7 +77,7 @@ int cv_engine_create(int device, int precision, cv_engine_t** out) {
     cv_engine* eng = new (std::nothrow) cv_engine();
     if (!eng) return finish(fail(CV_ERR_NOMEM, "out of host memory"));
     eng->impl.device = device;
-    eng->impl.f16 = precision == CV_PREC_F16;
+    eng->impl.dt = precision;                      // CV_PREC_* values equal cv::DType
     *out = eng;
     return CV_OK;
 }
@@ -190,7 +192,7 @@ int cv_get_activation(cv_engine_t* eng, const char* model, const char* name, flo
     s = tmp.alloc(numel * sizeof(float), false);
     if (!s.ok()) return finish(s);
     hipError_t e = hipDeviceSynchronize();
-    if (e == hipSuccess) e = unpack_nchw_f32(eng->impl.f16, t, (float*)tmp.ptr, nullptr);
+    if (e == hipSuccess) e = unpack_nchw_f32(eng->impl.dt, t, (float*)tmp.ptr, nullptr);
     if (e == hipSuccess) e = hipMemcpy(out_host, tmp.ptr, numel * sizeof(float), hipMemcpyDeviceToHost);
     if (e != hipSuccess) return finish(hip_fail(e, "cv_get_activation"));
     return CV_OK;
@@ -266,19 +268,19 @@ int cv_op_conv2d(cv_engine_t* eng, const float* x, int n, int cin, int h, int w_
     const int cinPad = round_up(cin, 8);
     std::vector<float> ones(cout, 1.f), zeros(cout, 0.f);
     ConvLayer L;
-    s = L.build_conv("op_conv2d", e.f16, w_host, cout, cin, k, stride, scale_host ? scale_host : ones.data(),
+    s = L.build_conv("op_conv2d", e.dt, w_host, cout, cin, k, stride, scale_host ? scale_host : ones.data(),
                      shift_host ? shift_host : zeros.data(), cinPad, choose_cfg(cout, (int64_t)n * ho * wo));
     if (!s.ok()) return finish(s);
     Activation ax, ay, ar;
-    if ((s = ax.create(n, h, w_, cinPad, e.f16)).ok() && (s = ay.create(n, ho, wo, cout, e.f16)).ok()) {
-        hipError_t err = pack_nchw_f32(e.f16, x, cin, ax.ref(n), st);
+    if ((s = ax.create(n, h, w_, cinPad, e.dt)).ok() && (s = ay.create(n, ho, wo, cout, e.dt)).ok()) {
+        hipError_t err = pack_nchw_f32(e.dt, x, cin, ax.ref(n), st);
         TensorRef rr;
         if (err == hipSuccess && residual) {
-            s = ar.create(n, ho, wo, cout, e.f16);
-            if (s.ok()) { err = pack_nchw_f32(e.f16, residual, cout, ar.ref(n), st); rr = ar.ref(n); }
+            s = ar.create(n, ho, wo, cout, e.dt);
+            if (s.ok()) { err = pack_nchw_f32(e.dt, residual, cout, ar.ref(n), st); rr = ar.ref(n); }
         }
         if (s.ok() && err == hipSuccess) s = e.run_conv(L, ax.ref(n), ay.ref(n), residual ? &rr : nullptr, relu != 0, st);
-        if (s.ok() && err == hipSuccess) err = unpack_nchw_f32(e.f16, ay.ref(n), y, st);
+        if (s.ok() && err == hipSuccess) err = unpack_nchw_f32(e.dt, ay.ref(n), y, st);
         if (s.ok() && err == hipSuccess) err = hipStreamSynchronize(st);
         if (s.ok() && err != hipSuccess) s = hip_fail(err, "cv_op_conv2d");
     }
@@ -295,20 +297,20 @@ int cv_op_conv_transpose2x2(cv_engine_t* eng, const float* x, int n, int cin, in
     Engine& e = eng->impl;
     hipStream_t st = (hipStream_t)stream;
     ConvLayer L;
-    s = L.build_convT("op_convT", e.f16, w_host, cin, cout, bias_host, choose_cfg(4 * cout, (int64_t)n * h * w_));
+    s = L.build_convT("op_convT", e.dt, w_host, cin, cout, bias_host, choose_cfg(4 * cout, (int64_t)n * h * w_));
     if (!s.ok()) return finish(s);
     Activation ax, ay;
-    if ((s = ax.create(n, h, w_, cin, e.f16)).ok() && (s = ay.create(n, 2 * h, 2 * w_, cout, e.f16)).ok()) {
-        hipError_t err = pack_nchw_f32(e.f16, x, cin, ax.ref(n), st);
+    if ((s = ax.create(n, h, w_, cin, e.dt)).ok() && (s = ay.create(n, 2 * h, 2 * w_, cout, e.dt)).ok()) {
+        hipError_t err = pack_nchw_f32(e.dt, x, cin, ax.ref(n), st);
         if (err == hipSuccess) s = e.run_conv(L, ax.ref(n), ay.ref(n), nullptr, false, st);
-        if (s.ok() && err == hipSuccess) err = unpack_nchw_f32(e.f16, ay.ref(n), y, st);
+        if (s.ok() && err == hipSuccess) err = unpack_nchw_f32(e.dt, ay.ref(n), y, st);
         if (s.ok() && err == hipSuccess) err = hipStreamSynchronize(st);
         if (s.ok() && err != hipSuccess) s = hip_fail(err, "cv_op_conv_transpose2x2");
     }
     return finish(s);
 }
 
-typedef hipError_t (*pool_fn)(bool, const TensorRef&, const TensorRef&, hipStream_t);
+typedef hipError_t (*pool_fn)(int, const TensorRef&, const TensorRef&, hipStream_t);
 static int pool_like(cv_engine_t* eng, const float* x, int n, int c, int h, int w_, int ho, int wo, float* y,
                      void* stream, pool_fn fn, const char* what) {
     Status s = check_engine(eng);
@@ -320,10 +322,10 @@ static int pool_like(cv_engine_t* eng, const float* x, int n, int c, int h, int 
     hipStream_t st = (hipStream_t)stream;
     const int cp = round_up(c, 8);
     Activation ax, ay;
-    if ((s = ax.create(n, h, w_, cp, e.f16)).ok() && (s = ay.create(n, ho, wo, cp, e.f16)).ok()) {
-        hipError_t err = pack_nchw_f32(e.f16, x, c, ax.ref(n), st);
-        if (err == hipSuccess) err = fn(e.f16, ax.ref(n), ay.ref(n), st);
-        if (err == hipSuccess) err = unpack_nchw_f32(e.f16, ay.ref(n, 0, c), y, st);
+    if ((s = ax.create(n, h, w_, cp, e.dt)).ok() && (s = ay.create(n, ho, wo, cp, e.dt)).ok()) {
+        hipError_t err = pack_nchw_f32(e.dt, x, c, ax.ref(n), st);
+        if (err == hipSuccess) err = fn(e.dt, ax.ref(n), ay.ref(n), st);
+        if (err == hipSuccess) err = unpack_nchw_f32(e.dt, ay.ref(n, 0, c), y, st);
         if (err == hipSuccess) err = hipStreamSynchronize(st);
         if (err != hipSuccess) s = hip_fail(err, what);
     }

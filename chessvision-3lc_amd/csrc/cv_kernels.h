@@ -14,6 +14,18 @@
 
 namespace cv {
 
+// Element types of activation / weight tensors.
+//   kF32   : float, f32-input MFMA (exact f32 products)
+//   kF16   : _Float16, f16 MFMA, f32 accumulate
+//   kSplit : "f16x3" -- every value v is carried as hi = f16(v), lo = f16(v - hi) (22+ significant bits);
+//            a group of 8 channels occupies 32 bytes = one 16-B chunk of hi's and one of lo's (order [hi,lo]
+//            for even groups, [lo,hi] for odd groups, so that MFMA fragment reads alternate LDS bank halves);
+//            products are formed as hi*hi + hi*lo + lo*hi on the f16 MFMA with f32 accumulate.
+enum DType : int { kF32 = 0, kF16 = 1, kSplit = 2 };
+struct split_t { uint32_t raw; };              // 4 bytes per channel, see kSplit
+__host__ __device__ inline int dtype_size(int dt) { return dt == kF16 ? 2 : 4; }
+__host__ __device__ inline int dtype_group(int dt) { return dt == kF32 ? 4 : 8; }    // channels per 16/32-B group
+
 typedef _Float16 half_t;
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));

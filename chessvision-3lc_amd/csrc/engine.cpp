@@ -39,8 +39,8 @@ Status DeviceBuffer::upload(const void* host, size_t n) {
     return Status();
 }
 
-Status Activation::create(int cap_, int h, int w, int c, bool f16_) {
-    cap = cap_; H = h; W = w; C = c; f16 = f16_;
+Status Activation::create(int cap_, int h, int w, int c, int dt_) {
+    cap = cap_; H = h; W = w; C = c; dt = dt_;
     const size_t total = bytes_per_image() * (size_t)cap;
     if (total >= ((size_t)1 << 32))
         return fail(1, "activation buffer >= 4 GiB: lower the chunk size (32-bit DMA offsets)");
@@ -57,24 +57,34 @@ static inline int conv_row_to_channel(int R) {
     return slab * 64 + q * (4 * kConvFC) + f * 4 + r;
 }
 
-template <typename T>
-static void pack_rows(std::vector<char>& out, int CT, int nCt, int nStages, int rows, int K,
+// A K row is a sequence of 16-byte chunks.  chunk_k0 / chunk_is_lo describe what chunk kc of the row holds:
+//   f16  : 8 values k0..k0+7             f32 : 4 values k0..k0+3
+//   split: K-group kg = kc/2 (8 values); even kg = [hi chunk, lo chunk], odd kg = [lo chunk, hi chunk]
+static inline int chunks_for(int dt, int K) { return dt == kF32 ? (K + 3) / 4 : dt == kF16 ? (K + 7) / 8 : 2 * ((K + 7) / 8); }
+static inline int chunk_k0(int dt, int kc) { return dt == kF32 ? kc * 4 : dt == kF16 ? kc * 8 : (kc / 2) * 8; }
+static inline bool chunk_is_lo(int dt, int kc) { return dt == kSplit && ((kc & 1) != ((kc / 2) & 1)); }
+
+static void pack_rows(int dt, std::vector<char>& out, int CT, int nCt, int nStages, int rows, int K,
                       const std::vector<float>& Wk /* [rows][K] */) {
-    const int epc = 16 / (int)sizeof(T);
     out.assign((size_t)nCt * nStages * CT * 128, 0);
-    T* dst = reinterpret_cast<T*>(out.data());
+    const int per = dt == kF32 ? 4 : 8;                    // values per chunk
     for (int t = 0; t < nCt; ++t)
         for (int s = 0; s < nStages; ++s)
             for (int R = 0; R < CT; ++R) {
                 const int row = t * CT + conv_row_to_channel(R);
                 for (int pos = 0; pos < 8; ++pos) {
-                    const int c = pos ^ (R & 7);
-                    const int kc = s * 8 + c;
-                    T* d = dst + (((size_t)(t * nStages + s) * CT + R) * 8 + pos) * epc;
-                    for (int e = 0; e < epc; ++e) {
-                        const int kk = kc * epc + e;
+                    const int kc = s * 8 + (pos ^ (R & 7));
+                    char* d = out.data() + (((size_t)(t * nStages + s) * CT + R) * 8 + pos) * 16;
+                    const int k0 = chunk_k0(dt, kc);
+                    const bool lo = chunk_is_lo(dt, kc);
+                    for (int e = 0; e < per; ++e) {
+                        const int kk = k0 + e;
                         const float v = (row < rows && kk < K) ? Wk[(size_t)row * K + kk] : 0.f;
-                        d[e] = (T)v;
+                        if (dt == kF32) reinterpret_cast<float*>(d)[e] = v;
+                        else {
+                            const _Float16 hi = (_Float16)v;
+                            reinterpret_cast<_Float16*>(d)[e] = lo ? (_Float16)(v - (float)hi) : hi;
+                        }
                     }
                 }
             }
@@ -82,15 +92,12 @@ static void pack_rows(std::vector<char>& out, int CT, int nCt, int nStages, int 
 
 static Status finish_layer(ConvLayer& L, const std::vector<float>& Wk, int K, const std::vector<float>& scale,
                            const std::vector<float>& shift) {
-    const int esz = L.f16 ? 2 : 4, epc = 16 / esz;
     const int CT = conv_cfg_ct(L.cfg);
-    const int nChunks = (K + epc - 1) / epc;
-    L.nStages = (nChunks + 7) / 8;
+    L.nStages = (chunks_for(L.dt, K) + 7) / 8;
     L.nCt = (L.rows + CT - 1) / CT;
     L.rowsPad = L.nCt * CT;
     std::vector<char> packed;
-    if (L.f16) pack_rows<_Float16>(packed, CT, L.nCt, L.nStages, L.rows, K, Wk);
-    else       pack_rows<float>(packed, CT, L.nCt, L.nStages, L.rows, K, Wk);
+    pack_rows(L.dt, packed, CT, L.nCt, L.nStages, L.rows, K, Wk);
     CV_TRY(L.w.upload(packed.data(), packed.size()));
     std::vector<float> sc(L.rowsPad, 0.f), sh(L.rowsPad, 0.f);
     std::memcpy(sc.data(), scale.data(), sizeof(float) * L.rows);
@@ -101,9 +108,9 @@ static Status finish_layer(ConvLayer& L, const std::vector<float>& Wk, int K, co
     return Status();
 }
 
-Status ConvLayer::build_conv(const std::string& name_, bool f16_, const float* w_oihw, int cout_, int cin_, int k_,
+Status ConvLayer::build_conv(const std::string& name_, int dt_, const float* w_oihw, int cout_, int cin_, int k_,
                              int stride_, const float* scale_, const float* shift_, int cinPad_, int cfg_) {
-    name = name_; f16 = f16_; cin = cin_; cinPad = cinPad_; cout = cout_; k = k_; stride = stride_;
+    name = name_; dt = dt_; cin = cin_; cinPad = cinPad_; cout = cout_; k = k_; stride = stride_;
     shuffle = false; rows = cout_; cfg = cfg_;
     if (cinPad % 8 || cinPad < cin) return fail(1, name + ": input channel padding must be a multiple of 8");
     if (k != 1 && k != 3) return fail(1, name + ": implicit-GEMM path supports 1x1 and 3x3 kernels");
@@ -119,9 +126,9 @@ Status ConvLayer::build_conv(const std::string& name_, bool f16_, const float* w
     return finish_layer(*this, Wk, K, sc, sh);
 }
 
-Status ConvLayer::build_convT(const std::string& name_, bool f16_, const float* w_iohw, int cin_, int cout_,
+Status ConvLayer::build_convT(const std::string& name_, int dt_, const float* w_iohw, int cin_, int cout_,
                               const float* bias, int cfg_) {
-    name = name_; f16 = f16_; cin = cin_; cinPad = cin_; cout = cout_; k = 1; stride = 1;
+    name = name_; dt = dt_; cin = cin_; cinPad = cin_; cout = cout_; k = 1; stride = 1;
     shuffle = true; rows = 4 * cout_; cfg = cfg_;
     if (cin % 8) return fail(1, name + ": transposed-conv input channels must be a multiple of 8");
     if (cout % 16) return fail(1, name + ": transposed-conv output channels must be a multiple of 16");
@@ -141,16 +148,21 @@ Status ConvLayer::get_koff(const TensorRef& x, const int** out) {
     const KoffKey key{x.W + 2, x.Cs, x.Coff};
     auto it = koff.find(key);
     if (it == koff.end()) {
-        const int esz = f16 ? 2 : 4, epc = 16 / esz;
+        const int esz = dtype_size(dt);
         const int K = k * k * cinPad;
         const int pad = (k - 1) / 2;
         std::vector<int> tab((size_t)nStages * 8, 0);
         for (int kc = 0; kc < nStages * 8; ++kc) {
-            int kk = kc * epc;
+            int kk = chunk_k0(dt, kc);
             if (kk >= K) kk = 0;                         // zero weights there; keep the gather on real data
             const int tap = kk / cinPad, ci = kk % cinPad;
             const int ky = tap / k, kx = tap % k;
-            const long long off = ((long long)((ky + 1 - pad) * key.xWp + (kx + 1 - pad)) * x.Cs + x.Coff + ci) * esz;
+            long long off = ((long long)((ky + 1 - pad) * key.xWp + (kx + 1 - pad)) * x.Cs + x.Coff + ci) * esz;
+            if (dt == kSplit) {                          // pick the hi or lo chunk of the 32-byte channel group
+                const bool odd_group = (((x.Coff + ci) / 8) & 1) != 0;
+                const bool want_lo = chunk_is_lo(dt, kc);
+                off += (want_lo != odd_group) ? 16 : 0;  // even group: [hi, lo]; odd group: [lo, hi]
+            }
             tab[kc] = (int)off;
         }
         auto buf = std::make_unique<DeviceBuffer>();
@@ -177,7 +189,9 @@ Engine::~Engine() { prof_clear(); }
 Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, const TensorRef* res, bool relu,
                         hipStream_t s) {
     if (x.C != L.cinPad) return fail(1, L.name + ": input slice has " + std::to_string(x.C) + " channels, layer packs " + std::to_string(L.cinPad));
-    const int esz = f16 ? 2 : 4;
+    const int esz = dtype_size(dt);
+    if (dt == kSplit && (x.Coff % 8 || y.Coff % 8 || (res && res->Coff % 8)))
+        return fail(1, L.name + ": split-f16 slices must start on an 8-channel group");
     if ((x.Cs * esz) % 16 || (x.Coff * esz) % 16 || (y.Cs * esz) % 16 || (y.Coff * esz) % 16)
         return fail(1, L.name + ": channel strides/offsets must keep 16-byte alignment");
     ConvParams p;
@@ -208,7 +222,7 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
     p.yHp = y.H + 2; p.yWp = y.W + 2; p.yCs = y.Cs; p.yCoff = y.Coff;
     p.Cout = L.cout; p.rows = L.rows; p.nStages = L.nStages; p.nCt = L.nCt; p.relu = relu ? 1 : 0; p.shuffle = L.shuffle ? 1 : 0;
     if (profiling) prof_begin(L.name, true, (double)L.macs_per_out_pixel() * (double)p.M, s);
-    hipError_t e = conv_igemm_launch(L.cfg, f16, p, s);
+    hipError_t e = conv_igemm_launch(L.cfg, dt, p, s);
     if (profiling) prof_end(s);
     if (e != hipSuccess) return hip_fail(e, ("conv launch " + L.name).c_str());
     return Status();

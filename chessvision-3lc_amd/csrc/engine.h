@@ -59,14 +59,14 @@ struct DeviceBuffer {
 struct Activation {
     DeviceBuffer buf;
     int cap = 0, H = 0, W = 0, C = 0;
-    bool f16 = true;
-    Status create(int cap_, int h, int w, int c, bool f16_);
+    int dt = kF16;
+    Status create(int cap_, int h, int w, int c, int dt_);
     TensorRef ref(int n, int coff = 0, int c = -1) const {
         TensorRef t;
         t.base = buf.ptr; t.N = n; t.H = H; t.W = W; t.Cs = C; t.Coff = coff; t.C = c < 0 ? C - coff : c;
         return t;
     }
-    size_t bytes_per_image() const { return (size_t)(H + 2) * (W + 2) * C * (f16 ? 2 : 4); }
+    size_t bytes_per_image() const { return (size_t)(H + 2) * (W + 2) * C * dtype_size(dt); }
 };
 
 // a packed implicit-GEMM layer (conv k x k, or k2 s2 transposed conv as 1-tap GEMM + pixel shuffle)
@@ -75,7 +75,7 @@ struct ConvLayer {
     int cin = 0, cinPad = 0, cout = 0, k = 1, stride = 1;
     bool shuffle = false;
     int rows = 0, rowsPad = 0, nStages = 0, nCt = 0, cfg = 0;
-    bool f16 = true;
+    int dt = kF16;
     DeviceBuffer w, scale, shift;
     // koff tables are geometry dependent: keyed by (xWp, xCs, xCoff)
     struct KoffKey { int xWp, xCs, xCoff; bool operator<(const KoffKey& o) const {
@@ -83,10 +83,10 @@ struct ConvLayer {
     std::map<KoffKey, std::unique_ptr<DeviceBuffer>> koff;
 
     // w_oihw: (cout, cin, k, k); scale/shift: (cout)
-    Status build_conv(const std::string& name_, bool f16_, const float* w_oihw, int cout_, int cin_, int k_,
+    Status build_conv(const std::string& name_, int dt_, const float* w_oihw, int cout_, int cin_, int k_,
                       int stride_, const float* scale_, const float* shift_, int cinPad_, int cfg_);
     // w_iohw: (cin, cout, 2, 2); bias: (cout)
-    Status build_convT(const std::string& name_, bool f16_, const float* w_iohw, int cin_, int cout_,
+    Status build_convT(const std::string& name_, int dt_, const float* w_iohw, int cin_, int cout_,
                        const float* bias, int cfg_);
     Status get_koff(const TensorRef& x, const int** out);
     int64_t macs_per_out_pixel() const { return shuffle ? (int64_t)cin * cout * 4 : (int64_t)cin * k * k * cout; }
@@ -103,7 +103,7 @@ struct ProfileEntry {
 class Engine {
   public:
     int device = 0;
-    bool f16 = true;
+    int dt = kF16;
     std::mutex mu;
     int unet_chunk = 16;
     int resnet_chunk = 4096;

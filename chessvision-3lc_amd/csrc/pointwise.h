@@ -1,4 +1,4 @@
-// pointwise.h -- host interface of the bandwidth-bound kernels (pointwise.hip).
+// pointwise.h -- host interface of the bandwidth-bound kernels (pointwise.hip).  `dt` is a cv::DType.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "cv_kernels.h"
@@ -6,27 +6,27 @@
 namespace cv {
 
 // NCHW float32 (n, c, h, w) -> PHWC slice `dst` (dst.C >= c; channels [c, dst.C) are written as zero)
-hipError_t pack_nchw_f32(bool f16, const float* src, int c, const TensorRef& dst, hipStream_t s);
+hipError_t pack_nchw_f32(int dt, const float* src, int c, const TensorRef& dst, hipStream_t s);
 // (n, h, w, 3) uint8 -> PHWC slice with value/255 (core.py:215); dst.C == 8, channels 3..7 zero
-hipError_t pack_hwc3_u8(bool f16, const uint8_t* src, const TensorRef& dst, hipStream_t s);
+hipError_t pack_hwc3_u8(int dt, const uint8_t* src, const TensorRef& dst, hipStream_t s);
 // PHWC slice -> NCHW float32
-hipError_t unpack_nchw_f32(bool f16, const TensorRef& src, float* dst, hipStream_t s);
+hipError_t unpack_nchw_f32(int dt, const TensorRef& src, float* dst, hipStream_t s);
 
-hipError_t maxpool2x2(bool f16, const TensorRef& src, const TensorRef& dst, hipStream_t s);
-hipError_t maxpool3x3s2(bool f16, const TensorRef& src, const TensorRef& dst, hipStream_t s);
-hipError_t upsample_bilinear2x(bool f16, const TensorRef& src, const TensorRef& dst, hipStream_t s);
+hipError_t maxpool2x2(int dt, const TensorRef& src, const TensorRef& dst, hipStream_t s);
+hipError_t maxpool3x3s2(int dt, const TensorRef& src, const TensorRef& dst, hipStream_t s);
+hipError_t upsample_bilinear2x(int dt, const TensorRef& src, const TensorRef& dst, hipStream_t s);
 
 // 1x1 conv C -> 1 (+bias): logits (n,1,h,w) float32; mask (nullable) = sigmoid(logit) > thr ? 255 : 0
-hipError_t outc_1x1(bool f16, const TensorRef& src, const float* w, const float* bias, float* logits,
+hipError_t outc_1x1(int dt, const TensorRef& src, const float* w, const float* bias, float* logits,
                     uint8_t* mask, float threshold, hipStream_t s);
 
 // ResNet stem: conv 7x7 s2 p3 (1 -> 64, no bias) + BN affine + ReLU.  x: (n,1,64,64) f32 or (n,64,64) u8
 // (u8 is scaled by /255 first, core.py:237).  w: [64][49] f32, scale/shift [64].  dst: 64 ch @ 32x32.
-hipError_t stem7x7(bool f16, const void* x, bool x_is_u8, int n, const float* w, const float* scale,
+hipError_t stem7x7(int dt, const void* x, bool x_is_u8, int n, const float* w, const float* scale,
                    const float* shift, const TensorRef& dst, hipStream_t s);
 
 // global average pool + Linear(C -> 13) (+ optional softmax).  w: [13][C] f32, b: [13]
-hipError_t head_avgpool_fc(bool f16, const TensorRef& src, const float* w, const float* b, float* out,
+hipError_t head_avgpool_fc(int dt, const TensorRef& src, const float* w, const float* b, float* out,
                            int softmax, hipStream_t s);
 hipError_t softmax13(const float* logits, int n, float* probs, hipStream_t s);
 

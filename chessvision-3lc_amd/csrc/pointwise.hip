@@ -13,15 +13,57 @@
 
 namespace cv {
 
-template <typename T> struct V16;
-template <> struct V16<half_t> { static constexpr int N = 8; typedef half8 V; };
-template <> struct V16<float>  { static constexpr int N = 4; typedef f4 V; };
+// A "group" = the channels one lane moves per access: 8 (f16: 16 B; split-f16: 16 B hi + 16 B lo) or 4 (f32: 16 B).
+template <typename T> struct Grp;
+template <> struct Grp<half_t> {
+    static constexpr int N = 8, BYTES = 16;
+    static __device__ __forceinline__ void load(const char* p, int, float* v) {
+        const half8 h = *reinterpret_cast<const half8*>(p);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (float)h[j];
+    }
+    static __device__ __forceinline__ void store(char* p, int, const float* v) {
+        half8 h;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) h[j] = (half_t)v[j];
+        *reinterpret_cast<half8*>(p) = h;
+    }
+};
+template <> struct Grp<float> {
+    static constexpr int N = 4, BYTES = 16;
+    static __device__ __forceinline__ void load(const char* p, int, float* v) {
+        const f4 h = *reinterpret_cast<const f4*>(p);
+        v[0] = h[0]; v[1] = h[1]; v[2] = h[2]; v[3] = h[3];
+    }
+    static __device__ __forceinline__ void store(char* p, int, const float* v) {
+        *reinterpret_cast<f4*>(p) = f4{v[0], v[1], v[2], v[3]};
+    }
+};
+template <> struct Grp<split_t> {              // [hi x8][lo x8] for even groups, [lo x8][hi x8] for odd ones
+    static constexpr int N = 8, BYTES = 32;
+    static __device__ __forceinline__ void load(const char* p, int parity, float* v) {
+        const half8 hi = *reinterpret_cast<const half8*>(p + (parity ? 16 : 0));
+        const half8 lo = *reinterpret_cast<const half8*>(p + (parity ? 0 : 16));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (float)hi[j] + (float)lo[j];
+    }
+    static __device__ __forceinline__ void store(char* p, int parity, const float* v) {
+        half8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { hi[j] = (half_t)v[j]; lo[j] = (half_t)(v[j] - (float)hi[j]); }
+        *reinterpret_cast<half8*>(p + (parity ? 16 : 0)) = hi;
+        *reinterpret_cast<half8*>(p + (parity ? 0 : 16)) = lo;
+    }
+};
 
 __device__ __forceinline__ size_t pix_index(const TensorRef& t, int n, int y, int x) {
     return (size_t)(n * (t.H + 2) + y + 1) * (t.W + 2) + (x + 1);
 }
-template <typename T> __device__ __forceinline__ T* elem_ptr(const TensorRef& t, size_t pix, int c) {
-    return reinterpret_cast<T*>(t.base) + pix * t.Cs + t.Coff + c;
+// byte address and hi/lo parity of group g (counted from the slice's first channel) of pixel `pix`
+template <typename T> __device__ __forceinline__ char* grp_ptr(const TensorRef& t, size_t pix, int g, int* parity) {
+    constexpr int ESZ = Grp<T>::BYTES / Grp<T>::N;
+    *parity = (t.Coff / Grp<T>::N + g) & 1;
+    return reinterpret_cast<char*>(t.base) + (pix * t.Cs + t.Coff) * ESZ + (size_t)g * Grp<T>::BYTES;
 }
 
 static inline unsigned grid_for(size_t work, int block = 256) {
@@ -29,31 +71,42 @@ static inline unsigned grid_for(size_t work, int block = 256) {
     return (unsigned)(g < 1 ? 1 : g);
 }
 
+// decode a flat (pixel, group) work index of tensor `t`
+struct PG { int n, y, x, g; bool live; };
+template <typename T> __device__ __forceinline__ PG decode_pg(const TensorRef& t) {
+    const int groups = t.C / Grp<T>::N;
+    const size_t total = (size_t)t.N * t.H * t.W * groups;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    PG r;
+    r.live = idx < total;
+    r.g = (int)(idx % groups);
+    size_t pix = idx / groups;
+    r.x = (int)(pix % t.W); pix /= t.W;
+    r.y = (int)(pix % t.H);
+    r.n = (int)(pix / t.H);
+    return r;
+}
+
 // ---- packing ----------------------------------------------------------------------------------------
 template <typename T>
 __global__ void pack_nchw_f32_kernel(const float* __restrict__ src, int c, TensorRef dst) {
-    constexpr int VN = V16<T>::N;
-    const int groups = dst.C / VN;
-    const size_t total = (size_t)dst.N * dst.H * dst.W * groups;
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int g = (int)(idx % groups);
-    size_t pix = idx / groups;
-    const int x = (int)(pix % dst.W); pix /= dst.W;
-    const int y = (int)(pix % dst.H);
-    const int n = (int)(pix / dst.H);
-    typename V16<T>::V v;
+    constexpr int GN = Grp<T>::N;
+    const PG p = decode_pg<T>(dst);
+    if (!p.live) return;
+    float v[GN];
 #pragma unroll
-    for (int j = 0; j < VN; ++j) {
-        const int ch = g * VN + j;
-        const float f = ch < c ? src[((size_t)(n * c + ch) * dst.H + y) * dst.W + x] : 0.f;
-        v[j] = (T)f;
+    for (int j = 0; j < GN; ++j) {
+        const int ch = p.g * GN + j;
+        v[j] = ch < c ? src[((size_t)(p.n * c + ch) * dst.H + p.y) * dst.W + p.x] : 0.f;
     }
-    *reinterpret_cast<typename V16<T>::V*>(elem_ptr<T>(dst, pix_index(dst, n, y, x), g * VN)) = v;
+    int par;
+    char* d = grp_ptr<T>(dst, pix_index(dst, p.n, p.y, p.x), p.g, &par);
+    Grp<T>::store(d, par, v);
 }
 
 template <typename T>
 __global__ void pack_hwc3_u8_kernel(const uint8_t* __restrict__ src, TensorRef dst) {
+    constexpr int GN = Grp<T>::N;
     const size_t total = (size_t)dst.N * dst.H * dst.W;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
@@ -62,20 +115,18 @@ __global__ void pack_hwc3_u8_kernel(const uint8_t* __restrict__ src, TensorRef d
     const int y = (int)(pix % dst.H);
     const int n = (int)(pix / dst.H);
     const uint8_t* s = src + idx * 3;
-    float f[8] = {(float)s[0] / 255.f, (float)s[1] / 255.f, (float)s[2] / 255.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    T* d = elem_ptr<T>(dst, pix_index(dst, n, y, x), 0);
-    constexpr int VN = V16<T>::N;
+    const float f[8] = {(float)s[0] / 255.f, (float)s[1] / 255.f, (float)s[2] / 255.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 8; i += VN) {
-        typename V16<T>::V v;
-#pragma unroll
-        for (int j = 0; j < VN; ++j) v[j] = (T)f[i + j];
-        *reinterpret_cast<typename V16<T>::V*>(d + i) = v;
+    for (int g = 0; g < 8 / GN; ++g) {
+        int par;
+        char* d = grp_ptr<T>(dst, pix_index(dst, n, y, x), g, &par);
+        Grp<T>::store(d, par, f + g * GN);
     }
 }
 
 template <typename T>
 __global__ void unpack_nchw_f32_kernel(TensorRef src, float* __restrict__ dst) {
+    constexpr int GN = Grp<T>::N;
     const size_t total = (size_t)src.N * src.C * src.H * src.W;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
@@ -84,107 +135,95 @@ __global__ void unpack_nchw_f32_kernel(TensorRef src, float* __restrict__ dst) {
     const int y = (int)(r % src.H); r /= src.H;
     const int c = (int)(r % src.C);
     const int n = (int)(r / src.C);
-    dst[idx] = (float)*elem_ptr<T>(src, pix_index(src, n, y, x), c);
+    int par;
+    const char* p = grp_ptr<T>(src, pix_index(src, n, y, x), c / GN, &par);
+    float v[GN];
+    Grp<T>::load(p, par, v);
+    float out = v[0];
+#pragma unroll
+    for (int j = 1; j < GN; ++j) out = (c % GN) == j ? v[j] : out;
+    dst[idx] = out;
 }
 
 // ---- pooling / upsampling --------------------------------------------------------------------------
 template <typename T>
 __global__ void maxpool2x2_kernel(TensorRef src, TensorRef dst) {
-    constexpr int VN = V16<T>::N;
-    typedef typename V16<T>::V V;
-    const int groups = dst.C / VN;
-    const size_t total = (size_t)dst.N * dst.H * dst.W * groups;
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int g = (int)(idx % groups);
-    size_t pix = idx / groups;
-    const int x = (int)(pix % dst.W); pix /= dst.W;
-    const int y = (int)(pix % dst.H);
-    const int n = (int)(pix / dst.H);
-    const size_t p00 = pix_index(src, n, 2 * y, 2 * x);
-    const size_t rowp = (size_t)(src.W + 2);
-    const V a = *reinterpret_cast<const V*>(elem_ptr<T>(src, p00, g * VN));
-    const V b = *reinterpret_cast<const V*>(elem_ptr<T>(src, p00 + 1, g * VN));
-    const V c = *reinterpret_cast<const V*>(elem_ptr<T>(src, p00 + rowp, g * VN));
-    const V d = *reinterpret_cast<const V*>(elem_ptr<T>(src, p00 + rowp + 1, g * VN));
-    const V m = __builtin_elementwise_max(__builtin_elementwise_max(a, b), __builtin_elementwise_max(c, d));
-    *reinterpret_cast<V*>(elem_ptr<T>(dst, pix_index(dst, n, y, x), g * VN)) = m;
+    constexpr int GN = Grp<T>::N;
+    const PG p = decode_pg<T>(dst);
+    if (!p.live) return;
+    float m[GN], v[GN];
+    int par;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const char* s = grp_ptr<T>(src, pix_index(src, p.n, 2 * p.y + (t >> 1), 2 * p.x + (t & 1)), p.g, &par);
+        Grp<T>::load(s, par, v);
+#pragma unroll
+        for (int j = 0; j < GN; ++j) m[j] = t == 0 ? v[j] : fmaxf(m[j], v[j]);
+    }
+    char* d = grp_ptr<T>(dst, pix_index(dst, p.n, p.y, p.x), p.g, &par);
+    Grp<T>::store(d, par, m);
 }
 
 template <typename T>
 __global__ void maxpool3x3s2_kernel(TensorRef src, TensorRef dst) {
-    constexpr int VN = V16<T>::N;
-    typedef typename V16<T>::V V;
-    const int groups = dst.C / VN;
-    const size_t total = (size_t)dst.N * dst.H * dst.W * groups;
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int g = (int)(idx % groups);
-    size_t pix = idx / groups;
-    const int x = (int)(pix % dst.W); pix /= dst.W;
-    const int y = (int)(pix % dst.H);
-    const int n = (int)(pix / dst.H);
-    V m;
+    constexpr int GN = Grp<T>::N;
+    const PG p = decode_pg<T>(dst);
+    if (!p.live) return;
+    float m[GN], v[GN];
 #pragma unroll
-    for (int j = 0; j < VN; ++j) m[j] = (T)(-65504.f);
+    for (int j = 0; j < GN; ++j) m[j] = -INFINITY;
+    int par;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
-        const int iy = 2 * y - 1 + ky;
+        const int iy = 2 * p.y - 1 + ky;
         if (iy < 0 || iy >= src.H) continue;
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-            const int ix = 2 * x - 1 + kx;
+            const int ix = 2 * p.x - 1 + kx;
             if (ix < 0 || ix >= src.W) continue;
-            const V v = *reinterpret_cast<const V*>(elem_ptr<T>(src, pix_index(src, n, iy, ix), g * VN));
-            m = __builtin_elementwise_max(m, v);
+            const char* s = grp_ptr<T>(src, pix_index(src, p.n, iy, ix), p.g, &par);
+            Grp<T>::load(s, par, v);
+#pragma unroll
+            for (int j = 0; j < GN; ++j) m[j] = fmaxf(m[j], v[j]);
         }
     }
-    *reinterpret_cast<V*>(elem_ptr<T>(dst, pix_index(dst, n, y, x), g * VN)) = m;
+    char* d = grp_ptr<T>(dst, pix_index(dst, p.n, p.y, p.x), p.g, &par);
+    Grp<T>::store(d, par, m);
 }
 
 // torch upsample_bilinear2d, align_corners=True: src = dst * (in-1)/(out-1); weights (1-l, l) in f32
 template <typename T>
 __global__ void upsample_bilinear2x_kernel(TensorRef src, TensorRef dst) {
-    constexpr int VN = V16<T>::N;
-    typedef typename V16<T>::V V;
-    const int groups = dst.C / VN;
-    const size_t total = (size_t)dst.N * dst.H * dst.W * groups;
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int g = (int)(idx % groups);
-    size_t pix = idx / groups;
-    const int x = (int)(pix % dst.W); pix /= dst.W;
-    const int y = (int)(pix % dst.H);
-    const int n = (int)(pix / dst.H);
+    constexpr int GN = Grp<T>::N;
+    const PG p = decode_pg<T>(dst);
+    if (!p.live) return;
     const float sy = dst.H > 1 ? (float)(src.H - 1) / (float)(dst.H - 1) : 0.f;
     const float sx = dst.W > 1 ? (float)(src.W - 1) / (float)(dst.W - 1) : 0.f;
-    const float fy = sy * (float)y, fx = sx * (float)x;
+    const float fy = sy * (float)p.y, fx = sx * (float)p.x;
     const int y0 = (int)fy, x0 = (int)fx;
     const int y1 = y0 + (y0 < src.H - 1 ? 1 : 0), x1 = x0 + (x0 < src.W - 1 ? 1 : 0);
     const float ly1 = fy - (float)y0, lx1 = fx - (float)x0;
     const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
-    const V v00 = *reinterpret_cast<const V*>(elem_ptr<T>(src, pix_index(src, n, y0, x0), g * VN));
-    const V v01 = *reinterpret_cast<const V*>(elem_ptr<T>(src, pix_index(src, n, y0, x1), g * VN));
-    const V v10 = *reinterpret_cast<const V*>(elem_ptr<T>(src, pix_index(src, n, y1, x0), g * VN));
-    const V v11 = *reinterpret_cast<const V*>(elem_ptr<T>(src, pix_index(src, n, y1, x1), g * VN));
-    V o;
+    float v00[GN], v01[GN], v10[GN], v11[GN], o[GN];
+    int par;
+    Grp<T>::load(grp_ptr<T>(src, pix_index(src, p.n, y0, x0), p.g, &par), par, v00);
+    Grp<T>::load(grp_ptr<T>(src, pix_index(src, p.n, y0, x1), p.g, &par), par, v01);
+    Grp<T>::load(grp_ptr<T>(src, pix_index(src, p.n, y1, x0), p.g, &par), par, v10);
+    Grp<T>::load(grp_ptr<T>(src, pix_index(src, p.n, y1, x1), p.g, &par), par, v11);
 #pragma unroll
-    for (int j = 0; j < VN; ++j) {
-        const float r = ly0 * (lx0 * (float)v00[j] + lx1 * (float)v01[j]) +
-                        ly1 * (lx0 * (float)v10[j] + lx1 * (float)v11[j]);
-        o[j] = (T)r;
-    }
-    *reinterpret_cast<V*>(elem_ptr<T>(dst, pix_index(dst, n, y, x), g * VN)) = o;
+    for (int j = 0; j < GN; ++j)
+        o[j] = ly0 * (lx0 * v00[j] + lx1 * v01[j]) + ly1 * (lx0 * v10[j] + lx1 * v11[j]);
+    char* d = grp_ptr<T>(dst, pix_index(dst, p.n, p.y, p.x), p.g, &par);
+    Grp<T>::store(d, par, o);
 }
 
 // ---- OutConv 1x1 (C -> 1) + bias, fused sigmoid/threshold mask ------------------------------------
-// LPP = C*sizeof(T)/16 lanes share one pixel (each 16 B of its channels); xor-shuffle reduce inside the group.
+// C/N lanes share one pixel (one group each); xor-shuffle reduce inside the lane group.
 template <typename T>
 __global__ void outc_1x1_kernel(TensorRef src, const float* __restrict__ w, const float* __restrict__ bias,
                                 float* __restrict__ logits, uint8_t* __restrict__ mask, float thr) {
-    constexpr int VN = V16<T>::N;
-    typedef typename V16<T>::V V;
-    const int lpp = src.C / VN;                               // power of two, <= 64
+    constexpr int GN = Grp<T>::N;
+    const int lpp = src.C / GN;                               // power of two, <= 64
     const size_t npix = (size_t)src.N * src.H * src.W;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int part = (int)(idx % lpp);
@@ -195,10 +234,12 @@ __global__ void outc_1x1_kernel(TensorRef src, const float* __restrict__ w, cons
     const int x = (int)(r % src.W); r /= src.W;
     const int y = (int)(r % src.H);
     const int n = (int)(r / src.H);
-    const V v = *reinterpret_cast<const V*>(elem_ptr<T>(src, pix_index(src, n, y, x), part * VN));
+    float v[GN];
+    int par;
+    Grp<T>::load(grp_ptr<T>(src, pix_index(src, n, y, x), part, &par), par, v);
     float acc = 0.f;
 #pragma unroll
-    for (int j = 0; j < VN; ++j) acc += (float)v[j] * w[part * VN + j];
+    for (int j = 0; j < GN; ++j) acc += v[j] * w[part * GN + j];
     for (int m = 1; m < lpp; m <<= 1) acc += __shfl_xor(acc, m);
     if (live && part == 0) {
         const float l = acc + bias[0];
@@ -210,13 +251,13 @@ __global__ void outc_1x1_kernel(TensorRef src, const float* __restrict__ w, cons
 // ---- ResNet stem: conv 7x7 s2 p3, 1 -> 64, + BN affine + ReLU -------------------------------------
 // One workgroup per 64x64 square.  The zero-bordered plane sits in LDS; each lane owns one output pixel at
 // a time, holds its 7x7 patch in VGPRs and runs the 64x49 filter bank from the scalar cache (wave-uniform
-// weights -> s_load + v_fma with an SGPR operand), i.e. a pure VALU f32 kernel: K = 49 is too thin and the
-// input too small for the MFMA path to pay.
+// weights -> s_load + v_fma with an SGPR operand), i.e. a pure VALU f32 kernel.
 template <typename T, typename XT>
 __global__ __launch_bounds__(256) void stem7x7_kernel(const XT* __restrict__ x, const float* __restrict__ w,
                                                       const float* __restrict__ scale,
                                                       const float* __restrict__ shift, TensorRef dst) {
     constexpr int IN = 64, P = 3, LD = IN + 2 * P;            // 70
+    constexpr int GN = Grp<T>::N;
     __shared__ float plane[LD * LD];
     const int n = blockIdx.x;
     const int tid = threadIdx.x;
@@ -238,8 +279,7 @@ __global__ __launch_bounds__(256) void stem7x7_kernel(const XT* __restrict__ x, 
         for (int ky = 0; ky < 7; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 7; ++kx) patch[ky * 7 + kx] = plane[(2 * oy + ky) * LD + 2 * ox + kx];
-        T* d = elem_ptr<T>(dst, pix_index(dst, n, oy, ox), 0);
-        constexpr int VN = V16<T>::N;
+        const size_t opix = pix_index(dst, n, oy, ox);
         // 8 output channels per trip: 392 wave-uniform weights stream through SGPRs, results leave as
         // 16-B stores.  Not unrolled on purpose: keeps the scalar loads inside the loop (no LICM hoist).
 #pragma unroll 1
@@ -255,39 +295,48 @@ __global__ __launch_bounds__(256) void stem7x7_kernel(const XT* __restrict__ x, 
                 v[c] = a > 0.f ? a : 0.f;
             }
 #pragma unroll
-            for (int i = 0; i < 8; i += VN) {
-                typename V16<T>::V o;
-#pragma unroll
-                for (int j = 0; j < VN; ++j) o[j] = (T)v[i + j];
-                *reinterpret_cast<typename V16<T>::V*>(d + cb + i) = o;
+            for (int i = 0; i < 8; i += GN) {
+                int par;
+                char* d = grp_ptr<T>(dst, opix, (cb + i) / GN, &par);
+                Grp<T>::store(d, par, v + i);
             }
         }
     }
 }
 
 // ---- head: adaptive_avg_pool2d(1) + Linear(C -> 13) (+ softmax) ------------------------------------
-// One wave per square; lane owns C/64 consecutive channels; 13 wave-wide xor-butterfly reductions.
+// One wave per square; lane owns channel groups lane, lane+64, ...; 13 wave-wide xor-butterfly reductions.
 template <typename T>
 __global__ __launch_bounds__(256) void head_kernel(TensorRef src, const float* __restrict__ w,
                                                    const float* __restrict__ b, float* __restrict__ out,
                                                    int softmax) {
     constexpr int NC = 13;
+    constexpr int GN = Grp<T>::N;
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= src.N) return;                                    // whole wave exits together
-    const int cpl = src.C / 64;                                // channels per lane (8 for C = 512)
     float acc[NC];
 #pragma unroll
     for (int j = 0; j < NC; ++j) acc[j] = 0.f;
     const float inv = 1.f / (float)(src.H * src.W);
-    for (int cc = 0; cc < cpl; ++cc) {
-        const int c = lane * cpl + cc;
-        float s = 0.f;
-        for (int y = 0; y < src.H; ++y)
-            for (int x = 0; x < src.W; ++x) s += (float)*elem_ptr<T>(src, pix_index(src, n, y, x), c);
-        s *= inv;
+    const int groups = src.C / GN;
+    for (int g = lane; g < groups; g += 64) {
+        float s[GN], v[GN];
 #pragma unroll
-        for (int j = 0; j < NC; ++j) acc[j] = __builtin_fmaf(s, w[j * src.C + c], acc[j]);
+        for (int j = 0; j < GN; ++j) s[j] = 0.f;
+        for (int y = 0; y < src.H; ++y)
+            for (int x = 0; x < src.W; ++x) {
+                int par;
+                Grp<T>::load(grp_ptr<T>(src, pix_index(src, n, y, x), g, &par), par, v);
+#pragma unroll
+                for (int j = 0; j < GN; ++j) s[j] += v[j];
+            }
+#pragma unroll
+        for (int j = 0; j < GN; ++j) {
+            const float mean = s[j] * inv;
+#pragma unroll
+            for (int k = 0; k < NC; ++k) acc[k] = __builtin_fmaf(mean, w[k * src.C + g * GN + j], acc[k]);
+        }
     }
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
@@ -351,74 +400,67 @@ __global__ void mfma_probe_f32_kernel(const float* a, const float* b, float* d) 
 }
 
 // ---- host wrappers ----------------------------------------------------------------------------------
-#define CV_LAUNCH(KERN, WORK, ...)                                                           \
-    do {                                                                                     \
-        hipLaunchKernelGGL(KERN, dim3(grid_for(WORK)), dim3(256), 0, s, __VA_ARGS__);        \
-        return hipGetLastError();                                                            \
+#define CV_DISPATCH(KERN, WORK, ...)                                                                         \
+    do {                                                                                                     \
+        const dim3 g_(grid_for(WORK)), b_(256);                                                              \
+        if (dt == kF16) hipLaunchKernelGGL(KERN<half_t>, g_, b_, 0, s, __VA_ARGS__);                         \
+        else if (dt == kSplit) hipLaunchKernelGGL(KERN<split_t>, g_, b_, 0, s, __VA_ARGS__);                 \
+        else hipLaunchKernelGGL(KERN<float>, g_, b_, 0, s, __VA_ARGS__);                                     \
+        return hipGetLastError();                                                                            \
     } while (0)
 
-hipError_t pack_nchw_f32(bool f16, const float* src, int c, const TensorRef& dst, hipStream_t s) {
-    const size_t work = (size_t)dst.N * dst.H * dst.W * (dst.C / (f16 ? 8 : 4));
-    if (f16) CV_LAUNCH(pack_nchw_f32_kernel<half_t>, work, src, c, dst);
-    CV_LAUNCH(pack_nchw_f32_kernel<float>, work, src, c, dst);
+hipError_t pack_nchw_f32(int dt, const float* src, int c, const TensorRef& dst, hipStream_t s) {
+    if (dst.C % dtype_group(dt) || dst.Coff % dtype_group(dt)) return hipErrorInvalidValue;
+    CV_DISPATCH(pack_nchw_f32_kernel, (size_t)dst.N * dst.H * dst.W * (dst.C / dtype_group(dt)), src, c, dst);
 }
-hipError_t pack_hwc3_u8(bool f16, const uint8_t* src, const TensorRef& dst, hipStream_t s) {
-    if (dst.C != 8) return hipErrorInvalidValue;
-    const size_t work = (size_t)dst.N * dst.H * dst.W;
-    if (f16) CV_LAUNCH(pack_hwc3_u8_kernel<half_t>, work, src, dst);
-    CV_LAUNCH(pack_hwc3_u8_kernel<float>, work, src, dst);
+hipError_t pack_hwc3_u8(int dt, const uint8_t* src, const TensorRef& dst, hipStream_t s) {
+    if (dst.C != 8 || dst.Coff % 8) return hipErrorInvalidValue;
+    CV_DISPATCH(pack_hwc3_u8_kernel, (size_t)dst.N * dst.H * dst.W, src, dst);
 }
-hipError_t unpack_nchw_f32(bool f16, const TensorRef& src, float* dst, hipStream_t s) {
-    const size_t work = (size_t)src.N * src.C * src.H * src.W;
-    if (f16) CV_LAUNCH(unpack_nchw_f32_kernel<half_t>, work, src, dst);
-    CV_LAUNCH(unpack_nchw_f32_kernel<float>, work, src, dst);
+hipError_t unpack_nchw_f32(int dt, const TensorRef& src, float* dst, hipStream_t s) {
+    if (src.Coff % dtype_group(dt)) return hipErrorInvalidValue;
+    CV_DISPATCH(unpack_nchw_f32_kernel, (size_t)src.N * src.C * src.H * src.W, src, dst);
 }
-hipError_t maxpool2x2(bool f16, const TensorRef& src, const TensorRef& dst, hipStream_t s) {
-    const size_t work = (size_t)dst.N * dst.H * dst.W * (dst.C / (f16 ? 8 : 4));
-    if (f16) CV_LAUNCH(maxpool2x2_kernel<half_t>, work, src, dst);
-    CV_LAUNCH(maxpool2x2_kernel<float>, work, src, dst);
+hipError_t maxpool2x2(int dt, const TensorRef& src, const TensorRef& dst, hipStream_t s) {
+    CV_DISPATCH(maxpool2x2_kernel, (size_t)dst.N * dst.H * dst.W * (dst.C / dtype_group(dt)), src, dst);
 }
-hipError_t maxpool3x3s2(bool f16, const TensorRef& src, const TensorRef& dst, hipStream_t s) {
-    const size_t work = (size_t)dst.N * dst.H * dst.W * (dst.C / (f16 ? 8 : 4));
-    if (f16) CV_LAUNCH(maxpool3x3s2_kernel<half_t>, work, src, dst);
-    CV_LAUNCH(maxpool3x3s2_kernel<float>, work, src, dst);
+hipError_t maxpool3x3s2(int dt, const TensorRef& src, const TensorRef& dst, hipStream_t s) {
+    CV_DISPATCH(maxpool3x3s2_kernel, (size_t)dst.N * dst.H * dst.W * (dst.C / dtype_group(dt)), src, dst);
 }
-hipError_t upsample_bilinear2x(bool f16, const TensorRef& src, const TensorRef& dst, hipStream_t s) {
-    const size_t work = (size_t)dst.N * dst.H * dst.W * (dst.C / (f16 ? 8 : 4));
-    if (f16) CV_LAUNCH(upsample_bilinear2x_kernel<half_t>, work, src, dst);
-    CV_LAUNCH(upsample_bilinear2x_kernel<float>, work, src, dst);
+hipError_t upsample_bilinear2x(int dt, const TensorRef& src, const TensorRef& dst, hipStream_t s) {
+    CV_DISPATCH(upsample_bilinear2x_kernel, (size_t)dst.N * dst.H * dst.W * (dst.C / dtype_group(dt)), src, dst);
 }
-hipError_t outc_1x1(bool f16, const TensorRef& src, const float* w, const float* bias, float* logits,
+hipError_t outc_1x1(int dt, const TensorRef& src, const float* w, const float* bias, float* logits,
                     uint8_t* mask, float threshold, hipStream_t s) {
-    const int lpp = src.C / (f16 ? 8 : 4);
+    const int lpp = src.C / dtype_group(dt);
     if (lpp < 1 || lpp > 64 || (lpp & (lpp - 1))) return hipErrorInvalidValue;
-    const size_t work = (size_t)src.N * src.H * src.W * lpp;
-    if (f16) CV_LAUNCH(outc_1x1_kernel<half_t>, work, src, w, bias, logits, mask, threshold);
-    CV_LAUNCH(outc_1x1_kernel<float>, work, src, w, bias, logits, mask, threshold);
+    CV_DISPATCH(outc_1x1_kernel, (size_t)src.N * src.H * src.W * lpp, src, w, bias, logits, mask, threshold);
 }
-hipError_t stem7x7(bool f16, const void* x, bool x_is_u8, int n, const float* w, const float* scale,
+hipError_t stem7x7(int dt, const void* x, bool x_is_u8, int n, const float* w, const float* scale,
                    const float* shift, const TensorRef& dst, hipStream_t s) {
     if (dst.C != 64 || dst.H != 32 || dst.W != 32 || dst.Coff != 0) return hipErrorInvalidValue;
     const dim3 g((unsigned)n), b(256);
-    if (f16) {
-        if (x_is_u8) hipLaunchKernelGGL((stem7x7_kernel<half_t, uint8_t>), g, b, 0, s, (const uint8_t*)x, w, scale, shift, dst);
-        else         hipLaunchKernelGGL((stem7x7_kernel<half_t, float>), g, b, 0, s, (const float*)x, w, scale, shift, dst);
-    } else {
-        if (x_is_u8) hipLaunchKernelGGL((stem7x7_kernel<float, uint8_t>), g, b, 0, s, (const uint8_t*)x, w, scale, shift, dst);
-        else         hipLaunchKernelGGL((stem7x7_kernel<float, float>), g, b, 0, s, (const float*)x, w, scale, shift, dst);
-    }
+#define CV_STEM(T)                                                                                                   \
+    do {                                                                                                             \
+        if (x_is_u8) hipLaunchKernelGGL((stem7x7_kernel<T, uint8_t>), g, b, 0, s, (const uint8_t*)x, w, scale, shift, dst); \
+        else hipLaunchKernelGGL((stem7x7_kernel<T, float>), g, b, 0, s, (const float*)x, w, scale, shift, dst);      \
+    } while (0)
+    if (dt == kF16) CV_STEM(half_t); else if (dt == kSplit) CV_STEM(split_t); else CV_STEM(float);
+#undef CV_STEM
     return hipGetLastError();
 }
-hipError_t head_avgpool_fc(bool f16, const TensorRef& src, const float* w, const float* b, float* out,
+hipError_t head_avgpool_fc(int dt, const TensorRef& src, const float* w, const float* b, float* out,
                            int softmax, hipStream_t s) {
-    if (src.C % 64) return hipErrorInvalidValue;
+    if (src.C % dtype_group(dt)) return hipErrorInvalidValue;
     const dim3 g((unsigned)((src.N + 3) / 4)), blk(256);
-    if (f16) hipLaunchKernelGGL(head_kernel<half_t>, g, blk, 0, s, src, w, b, out, softmax);
-    else     hipLaunchKernelGGL(head_kernel<float>, g, blk, 0, s, src, w, b, out, softmax);
+    if (dt == kF16) hipLaunchKernelGGL(head_kernel<half_t>, g, blk, 0, s, src, w, b, out, softmax);
+    else if (dt == kSplit) hipLaunchKernelGGL(head_kernel<split_t>, g, blk, 0, s, src, w, b, out, softmax);
+    else hipLaunchKernelGGL(head_kernel<float>, g, blk, 0, s, src, w, b, out, softmax);
     return hipGetLastError();
 }
 hipError_t softmax13(const float* logits, int n, float* probs, hipStream_t s) {
-    CV_LAUNCH(softmax13_kernel, (size_t)n, logits, n, probs);
+    hipLaunchKernelGGL(softmax13_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, s, logits, n, probs);
+    return hipGetLastError();
 }
 hipError_t mfma_probe_f16(const half_t* a, const half_t* b, float* d, hipStream_t s) {
     hipLaunchKernelGGL(mfma_probe_f16_kernel, dim3(1), dim3(64), 0, s, a, b, d);

@@ -13,7 +13,7 @@
 
 namespace cv {
 
-Status build_conv_bn_public(ConvLayer& L, bool f16, const ParamMap& pm, const std::string& conv_key,
+Status build_conv_bn_public(ConvLayer& L, int dt, const ParamMap& pm, const std::string& conv_key,
                             const std::string& bn_key, int cout, int cin, int k, int stride, int cinPad,
                             int64_t pixels);
 
@@ -29,7 +29,7 @@ static Status need2(const ParamMap& pm, const std::string& key, std::vector<int6
 Status resnet_load(Engine& e, const ParamMap& pm) {
     auto m = std::make_unique<Engine::ResNet>();
     Engine::ResNet& R = *m;
-    const bool f16 = e.f16;
+    const int dt = e.dt;
     R.cap = e.resnet_chunk;
     const int S = R.cap;
 
@@ -46,8 +46,8 @@ Status resnet_load(Engine& e, const ParamMap& pm) {
         CV_TRY(R.stem_scale.upload(sc.data(), 64 * sizeof(float)));
         CV_TRY(R.stem_shift.upload(sh.data(), 64 * sizeof(float)));
     }
-    CV_TRY(R.stem_out.create(S, 32, 32, 64, f16));
-    CV_TRY(R.pool_out.create(S, 16, 16, 64, f16));
+    CV_TRY(R.stem_out.create(S, 32, 32, 64, dt));
+    CV_TRY(R.pool_out.create(S, 16, 16, 64, dt));
     R.taps["act1"] = R.stem_out.ref(S);
     R.taps["maxpool"] = R.pool_out.ref(S);
 
@@ -62,16 +62,16 @@ Status resnet_load(Engine& e, const ParamMap& pm) {
             const int w = widths[l];
             const int stride = (bi == 0 && l > 0) ? 2 : 1;
             const int64_t px = (int64_t)S * res[l] * res[l];
-            CV_TRY(build_conv_bn_public(B.conv1, f16, pm, p + ".conv1", p + ".bn1", w, cin, 3, stride, cin, px));
-            CV_TRY(build_conv_bn_public(B.conv2, f16, pm, p + ".conv2", p + ".bn2", w, w, 3, 1, w, px));
+            CV_TRY(build_conv_bn_public(B.conv1, dt, pm, p + ".conv1", p + ".bn1", w, cin, 3, stride, cin, px));
+            CV_TRY(build_conv_bn_public(B.conv2, dt, pm, p + ".conv2", p + ".bn2", w, w, 3, 1, w, px));
             B.has_down = (stride != 1 || cin != w);
             if (B.has_down) {
-                CV_TRY(build_conv_bn_public(B.down, f16, pm, p + ".downsample.0", p + ".downsample.1", w, cin, 1, stride, cin, px));
-                CV_TRY(B.sc.create(S, res[l], res[l], w, f16));
+                CV_TRY(build_conv_bn_public(B.down, dt, pm, p + ".downsample.0", p + ".downsample.1", w, cin, 1, stride, cin, px));
+                CV_TRY(B.sc.create(S, res[l], res[l], w, dt));
                 macs += (int64_t)cin * w * res[l] * res[l];
             }
-            CV_TRY(B.mid.create(S, res[l], res[l], w, f16));
-            CV_TRY(B.out.create(S, res[l], res[l], w, f16));
+            CV_TRY(B.mid.create(S, res[l], res[l], w, dt));
+            CV_TRY(B.out.create(S, res[l], res[l], w, dt));
             macs += ((int64_t)cin * 9 * w + (int64_t)w * 9 * w) * res[l] * res[l];
             R.taps[p + ".act1"] = B.mid.ref(S);
             R.taps[p] = B.out.ref(S);
@@ -107,7 +107,7 @@ Status resnet_activation(Engine& e, const std::string& name, TensorRef* out) {
 static Status resnet_chunk(Engine& e, const void* x, bool x_u8, int n, float* out, bool softmax, hipStream_t s) {
     Engine::ResNet& R = *e.resnet;
     R.last_n = n;
-    const bool f16 = e.f16;
+    const int dt = e.dt;
     auto begin = [&](const char* name, double macs) { if (e.profiling) e.prof_begin(name, false, macs, s); };
     auto end = [&](const char* name, hipError_t err) -> Status {
         if (e.profiling) e.prof_end(s);
@@ -115,10 +115,10 @@ static Status resnet_chunk(Engine& e, const void* x, bool x_u8, int n, float* ou
         return Status();
     };
     begin("stem7x7", 49.0 * 64 * 1024 * n);
-    CV_TRY(end("stem7x7", stem7x7(f16, x, x_u8, n, (const float*)R.stem_w.ptr, (const float*)R.stem_scale.ptr,
+    CV_TRY(end("stem7x7", stem7x7(dt, x, x_u8, n, (const float*)R.stem_w.ptr, (const float*)R.stem_scale.ptr,
                                    (const float*)R.stem_shift.ptr, R.stem_out.ref(n), s)));
     begin("maxpool3x3s2", 0);
-    CV_TRY(end("maxpool3x3s2", maxpool3x3s2(f16, R.stem_out.ref(n), R.pool_out.ref(n), s)));
+    CV_TRY(end("maxpool3x3s2", maxpool3x3s2(dt, R.stem_out.ref(n), R.pool_out.ref(n), s)));
     TensorRef cur = R.pool_out.ref(n);
     for (int i = 0; i < 8; ++i) {
         Engine::ResNet::Block& B = R.blocks[i];
@@ -132,7 +132,7 @@ static Status resnet_chunk(Engine& e, const void* x, bool x_u8, int n, float* ou
         cur = B.out.ref(n);
     }
     begin("head_avgpool_fc", 13.0 * 512 * n);
-    CV_TRY(end("head_avgpool_fc", head_avgpool_fc(f16, cur, (const float*)R.fc_w.ptr, (const float*)R.fc_b.ptr, out,
+    CV_TRY(end("head_avgpool_fc", head_avgpool_fc(dt, cur, (const float*)R.fc_w.ptr, (const float*)R.fc_b.ptr, out,
                                                    softmax ? 1 : 0, s)));
     return Status();
 }

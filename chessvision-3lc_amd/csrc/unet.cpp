@@ -46,25 +46,25 @@ static Status bn_fold(const ParamMap& pm, const std::string& prefix, int c, std:
     return Status();
 }
 
-static Status build_conv_bn(ConvLayer& L, bool f16, const ParamMap& pm, const std::string& conv_key,
+static Status build_conv_bn(ConvLayer& L, int dt, const ParamMap& pm, const std::string& conv_key,
                             const std::string& bn_key, int cout, int cin, int k, int stride, int cinPad,
                             int64_t pixels) {
     const float* w;
     CV_TRY(need(pm, conv_key + ".weight", {cout, cin, k, k}, &w));
     std::vector<float> sc, sh;
     CV_TRY(bn_fold(pm, bn_key, cout, sc, sh));
-    return L.build_conv(conv_key, f16, w, cout, cin, k, stride, sc.data(), sh.data(), cinPad, choose_cfg(cout, pixels));
+    return L.build_conv(conv_key, dt, w, cout, cin, k, stride, sc.data(), sh.data(), cinPad, choose_cfg(cout, pixels));
 }
-Status build_conv_bn_public(ConvLayer& L, bool f16, const ParamMap& pm, const std::string& conv_key,
+Status build_conv_bn_public(ConvLayer& L, int dt, const ParamMap& pm, const std::string& conv_key,
                             const std::string& bn_key, int cout, int cin, int k, int stride, int cinPad,
                             int64_t pixels) {
-    return build_conv_bn(L, f16, pm, conv_key, bn_key, cout, cin, k, stride, cinPad, pixels);
+    return build_conv_bn(L, dt, pm, conv_key, bn_key, cout, cin, k, stride, cinPad, pixels);
 }
 
 Status unet_load(Engine& e, const ParamMap& pm) {
     auto m = std::make_unique<Engine::UNet>();
     Engine::UNet& U = *m;
-    const bool f16 = e.f16;
+    const int dt = e.dt;
     U.bilinear = pm.find("up1.up.weight") == pm.end();
     U.cap = e.unet_chunk;
     const int S = U.cap;
@@ -75,12 +75,12 @@ Status unet_load(Engine& e, const ParamMap& pm) {
     auto px = [&](int level) { return (int64_t)S * res[level] * res[level]; };
 
     // encoder
-    CV_TRY(build_conv_bn(U.inc0, f16, pm, "inc.double_conv.0", "inc.double_conv.1", 64, 3, 3, 1, 8, px(0)));
-    CV_TRY(build_conv_bn(U.inc1, f16, pm, "inc.double_conv.3", "inc.double_conv.4", 64, 64, 3, 1, 64, px(0)));
+    CV_TRY(build_conv_bn(U.inc0, dt, pm, "inc.double_conv.0", "inc.double_conv.1", 64, 3, 3, 1, 8, px(0)));
+    CV_TRY(build_conv_bn(U.inc1, dt, pm, "inc.double_conv.3", "inc.double_conv.4", 64, 64, 3, 1, 64, px(0)));
     for (int i = 0; i < 4; ++i) {
         const std::string p = "down" + std::to_string(i + 1) + ".maxpool_conv.1.double_conv.";
-        CV_TRY(build_conv_bn(U.d[i][0], f16, pm, p + "0", p + "1", enc_c[i + 1], enc_c[i], 3, 1, enc_c[i], px(i + 1)));
-        CV_TRY(build_conv_bn(U.d[i][1], f16, pm, p + "3", p + "4", enc_c[i + 1], enc_c[i + 1], 3, 1, enc_c[i + 1], px(i + 1)));
+        CV_TRY(build_conv_bn(U.d[i][0], dt, pm, p + "0", p + "1", enc_c[i + 1], enc_c[i], 3, 1, enc_c[i], px(i + 1)));
+        CV_TRY(build_conv_bn(U.d[i][1], dt, pm, p + "3", p + "4", enc_c[i + 1], enc_c[i + 1], 3, 1, enc_c[i + 1], px(i + 1)));
     }
     // decoder: up_i consumes the deeper tensor (channels deep_c) and skip level (3 - i)
     //   transposed: up: deep_c -> deep_c/2 ; conv: cat(skip, up) = deep_c -> out_c -> out_c
@@ -95,7 +95,7 @@ Status unet_load(Engine& e, const ParamMap& pm) {
             const float *w, *b;
             CV_TRY(need(pm, p + ".up.weight", {deep_c, deep_c / 2, 2, 2}, &w));
             CV_TRY(need(pm, p + ".up.bias", {deep_c / 2}, &b));
-            CV_TRY(U.upT[i].build_convT(p + ".up", f16, w, deep_c, deep_c / 2, b, choose_cfg(2 * deep_c, px(lvl + 1))));
+            CV_TRY(U.upT[i].build_convT(p + ".up", dt, w, deep_c, deep_c / 2, b, choose_cfg(2 * deep_c, px(lvl + 1))));
             cat_c = skip_c + deep_c / 2;
             out_c = skip_c;
             mid_c = out_c;
@@ -105,8 +105,8 @@ Status unet_load(Engine& e, const ParamMap& pm) {
             out_c = (i == 3) ? 64 : skip_c / 2;
         }
         const std::string c = p + ".conv.double_conv.";
-        CV_TRY(build_conv_bn(U.u[i][0], f16, pm, c + "0", c + "1", mid_c, cat_c, 3, 1, cat_c, px(lvl)));
-        CV_TRY(build_conv_bn(U.u[i][1], f16, pm, c + "3", c + "4", out_c, mid_c, 3, 1, mid_c, px(lvl)));
+        CV_TRY(build_conv_bn(U.u[i][0], dt, pm, c + "0", c + "1", mid_c, cat_c, 3, 1, cat_c, px(lvl)));
+        CV_TRY(build_conv_bn(U.u[i][1], dt, pm, c + "3", c + "4", out_c, mid_c, 3, 1, mid_c, px(lvl)));
         deep_c = out_c;
     }
     {
@@ -118,21 +118,21 @@ Status unet_load(Engine& e, const ParamMap& pm) {
     }
 
     // activations (dedicated buffers: borders are zeroed once and stay zero)
-    CV_TRY(U.in8.create(S, 256, 256, 8, f16));
-    CV_TRY(U.a_inc0.create(S, 256, 256, 64, f16));
+    CV_TRY(U.in8.create(S, 256, 256, 8, dt));
+    CV_TRY(U.a_inc0.create(S, 256, 256, 64, dt));
     for (int lvl = 0; lvl < 4; ++lvl) {
         const int skip_c = enc_c[lvl];
         const int up_c = U.u[3 - lvl][0].cin - skip_c;
-        CV_TRY(U.cat[lvl].create(S, res[lvl], res[lvl], skip_c + up_c, f16));
-        CV_TRY(U.pool[lvl].create(S, res[lvl + 1], res[lvl + 1], skip_c, f16));
-        if (lvl < 3) CV_TRY(U.dmid[lvl].create(S, res[lvl + 1], res[lvl + 1], enc_c[lvl + 1], f16));
+        CV_TRY(U.cat[lvl].create(S, res[lvl], res[lvl], skip_c + up_c, dt));
+        CV_TRY(U.pool[lvl].create(S, res[lvl + 1], res[lvl + 1], skip_c, dt));
+        if (lvl < 3) CV_TRY(U.dmid[lvl].create(S, res[lvl + 1], res[lvl + 1], enc_c[lvl + 1], dt));
     }
-    CV_TRY(U.dmid[3].create(S, 16, 16, U.c5, f16));
-    CV_TRY(U.bott.create(S, 16, 16, U.c5, f16));
+    CV_TRY(U.dmid[3].create(S, 16, 16, U.c5, dt));
+    CV_TRY(U.bott.create(S, 16, 16, U.c5, dt));
     for (int i = 0; i < 4; ++i) {
         const int lvl = 3 - i;
-        CV_TRY(U.umid[i].create(S, res[lvl], res[lvl], U.u[i][0].cout, f16));
-        CV_TRY(U.uout[i].create(S, res[lvl], res[lvl], U.u[i][1].cout, f16));
+        CV_TRY(U.umid[i].create(S, res[lvl], res[lvl], U.u[i][0].cout, dt));
+        CV_TRY(U.uout[i].create(S, res[lvl], res[lvl], U.u[i][1].cout, dt));
     }
 
     // module-name taps for cv_get_activation (names follow the reference state-dict prefixes)
@@ -189,7 +189,7 @@ static Status unet_chunk(Engine& e, const void* x, bool x_u8, int n, float* logi
                          hipStream_t s) {
     Engine::UNet& U = *e.unet;
     U.last_n = n;
-    const bool f16 = e.f16;
+    const int dt = e.dt;
     const int enc_c[5] = {64, 128, 256, 512, U.c5};
     auto timed = [&](const char* name, hipError_t err) -> Status {
         if (e.profiling) e.prof_end(s);
@@ -199,14 +199,14 @@ static Status unet_chunk(Engine& e, const void* x, bool x_u8, int n, float* logi
     auto begin = [&](const char* name) { if (e.profiling) e.prof_begin(name, false, 0, s); };
 
     begin("pack_input");
-    if (x_u8) CV_TRY(timed("pack_hwc3_u8", pack_hwc3_u8(f16, (const uint8_t*)x, U.in8.ref(n, 0, 8), s)));
-    else      CV_TRY(timed("pack_nchw_f32", pack_nchw_f32(f16, (const float*)x, 3, U.in8.ref(n, 0, 8), s)));
+    if (x_u8) CV_TRY(timed("pack_hwc3_u8", pack_hwc3_u8(dt, (const uint8_t*)x, U.in8.ref(n, 0, 8), s)));
+    else      CV_TRY(timed("pack_nchw_f32", pack_nchw_f32(dt, (const float*)x, 3, U.in8.ref(n, 0, 8), s)));
 
     CV_TRY(e.run_conv(U.inc0, U.in8.ref(n, 0, 8), U.a_inc0.ref(n), nullptr, true, s));
     CV_TRY(e.run_conv(U.inc1, U.a_inc0.ref(n), U.cat[0].ref(n, 0, 64), nullptr, true, s));
     for (int i = 0; i < 4; ++i) {
         begin("maxpool2x2");
-        CV_TRY(timed("maxpool2x2", maxpool2x2(f16, U.cat[i].ref(n, 0, enc_c[i]), U.pool[i].ref(n), s)));
+        CV_TRY(timed("maxpool2x2", maxpool2x2(dt, U.cat[i].ref(n, 0, enc_c[i]), U.pool[i].ref(n), s)));
         CV_TRY(e.run_conv(U.d[i][0], U.pool[i].ref(n), U.dmid[i].ref(n), nullptr, true, s));
         TensorRef out = (i < 3) ? U.cat[i + 1].ref(n, 0, enc_c[i + 1]) : U.bott.ref(n);
         CV_TRY(e.run_conv(U.d[i][1], U.dmid[i].ref(n), out, nullptr, true, s));
@@ -219,14 +219,14 @@ static Status unet_chunk(Engine& e, const void* x, bool x_u8, int n, float* logi
             CV_TRY(e.run_conv(U.upT[i], deep, up, nullptr, false, s));
         } else {
             begin("upsample_bilinear2x");
-            CV_TRY(timed("upsample_bilinear2x", upsample_bilinear2x(f16, deep, up, s)));
+            CV_TRY(timed("upsample_bilinear2x", upsample_bilinear2x(dt, deep, up, s)));
         }
         CV_TRY(e.run_conv(U.u[i][0], U.cat[lvl].ref(n), U.umid[i].ref(n), nullptr, true, s));
         CV_TRY(e.run_conv(U.u[i][1], U.umid[i].ref(n), U.uout[i].ref(n), nullptr, true, s));
         deep = U.uout[i].ref(n);
     }
     begin("outc_1x1");
-    CV_TRY(timed("outc_1x1", outc_1x1(f16, deep, (const float*)U.outc_w.ptr, (const float*)U.outc_b.ptr, logits,
+    CV_TRY(timed("outc_1x1", outc_1x1(dt, deep, (const float*)U.outc_w.ptr, (const float*)U.outc_b.ptr, logits,
                                       mask, thr, s)));
     return Status();
 }

@@ -51,7 +51,10 @@ enum cv_status {
 /* arithmetic type of the convolution path */
 enum cv_precision {
     CV_PREC_F32 = 0,      /* f32 activations/weights, f32-input MFMA (exact f32 products, f32 accumulate) */
-    CV_PREC_F16 = 1       /* f16 activations/weights, f16 MFMA with f32 accumulate, f32 BN/bias epilogue  */
+    CV_PREC_F16 = 1,      /* f16 activations/weights, f16 MFMA with f32 accumulate, f32 BN/bias epilogue  */
+    CV_PREC_F16X3 = 2     /* split-f16: every activation/weight carried as hi + lo f16 (>= 22 significant bits),
+                             products formed as hi*hi + hi*lo + lo*hi on the f16 MFMA with f32 accumulate:
+                             f32-grade results at up to 1/3 of the f16 MFMA rate (5.3x the f32 MFMA rate) */
 };
 
 typedef struct cv_engine cv_engine_t;     /* opaque */

@@ -37,10 +37,10 @@ def pytest_collection_modifyitems(config, items):
 
 @pytest.fixture(scope="session")
 def engines():
-    """{'f32': HipEngine, 'f16': HipEngine} with small chunks (tests use small batches)."""
+    """{'f32' | 'f16' | 'f16x3': HipEngine} with small chunks (tests use small batches)."""
     from chessvision.hip_backend import HipEngine
 
-    made = {p: HipEngine(precision=p, unet_chunk=2, resnet_chunk=128) for p in ("f32", "f16")}
+    made = {p: HipEngine(precision=p, unet_chunk=2, resnet_chunk=128) for p in ("f32", "f16", "f16x3")}
     yield made
     for e in made.values():
         e.close()

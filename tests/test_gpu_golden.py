@@ -12,7 +12,7 @@ from chessvision import synthetic
 
 pytestmark = pytest.mark.gpu
 G = Path(__file__).resolve().parent / "golden"
-TOL = {"f32": 1e-3, "f16": 5e-3}
+TOL = {"f32": 1e-3, "f16": 5e-3, "f16x3": 1e-3}
 
 
 def _fold(bn):
@@ -21,7 +21,7 @@ def _fold(bn):
     return scale, b - m * scale
 
 
-@pytest.mark.parametrize("prec", ["f32", "f16"])
+@pytest.mark.parametrize("prec", ["f32", "f16", "f16x3"])
 def test_op_vectors(engines, prec):
     eng, d, tol = engines[prec], np.load(G / "ops.npz"), TOL[prec]
     T = lambda k: torch.from_numpy(d[k])  # noqa: E731
@@ -49,7 +49,7 @@ def test_op_vectors(engines, prec):
     close(eng.softmax13(T("head_logits")), "head_probs")
 
 
-@pytest.mark.parametrize("prec", ["f32", "f16"])
+@pytest.mark.parametrize("prec", ["f32", "f16", "f16x3"])
 @pytest.mark.parametrize("tag,bilinear", [("convT", False), ("bilinear", True)])
 def test_unet_vectors(prec, tag, bilinear):
     from chessvision.hip_backend import HipEngine
@@ -63,13 +63,13 @@ def test_unet_vectors(prec, tag, bilinear):
     err = np.abs(flat[:, torch.from_numpy(d["sample_idx"])].numpy() - d[f"{tag}_samples"]).max()
     scale = max(1.0, np.abs(d[f"{tag}_samples"]).max()) if prec == "f16" else 1.0
     assert err <= TOL[prec] * scale, err
-    if prec == "f32":
+    if prec != "f16":
         assert np.abs(flat.double().sum(1).numpy() - d[f"{tag}_sum"]).max() <= 2.0          # checksum of 65536 logits
         assert np.abs((mask.cpu() > 0).reshape(2, -1).sum(1).numpy() - d[f"{tag}_mask_count"]).max() <= 4
     eng.close()
 
 
-@pytest.mark.parametrize("prec", ["f32", "f16"])
+@pytest.mark.parametrize("prec", ["f32", "f16", "f16x3"])
 def test_resnet_vectors(prec):
     from chessvision.hip_backend import HipEngine
 
@@ -78,7 +78,7 @@ def test_resnet_vectors(prec):
     eng.load_resnet18(synthetic.resnet18_state_dict(2))
     u8 = synthetic.random_u8(4, "squares_in", (128, 64, 64))
     probs = eng.resnet18_forward_u8(torch.from_numpy(u8)).cpu().numpy()
-    assert np.abs(probs - d["probs"]).max() <= (1e-3 if prec == "f32" else 2e-2)
+    assert np.abs(probs - d["probs"]).max() <= (2e-2 if prec == "f16" else 1e-3)
     x = torch.from_numpy(u8).float().unsqueeze(1)
     x /= 255.0
     logits = eng.resnet18_forward(x).cpu().numpy()
