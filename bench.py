@@ -72,7 +72,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--dtype", default=os.environ.get("CV_BENCH_DTYPE", "f32"), choices=["f32", "f16", "f16x3"])
+    ap.add_argument("--dtype", default=os.environ.get("CV_BENCH_DTYPE", "f16x3"), choices=["f32", "f16", "f16x3"])
     ap.add_argument("--boards", type=int, default=256, help="boards per GPU per step")
     ap.add_argument("--unet-chunk", type=int, default=16)
     ap.add_argument("--resnet-chunk", type=int, default=4096)

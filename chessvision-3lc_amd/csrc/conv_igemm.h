@@ -14,11 +14,15 @@ enum ConvCfg {            // <channel tile> x <pixel tile> of one 256-thread wor
     kCfg64x128 = 1,       // Cout == 64, few pixels
     kCfg128x128 = 2,      // Cout >= 128, few pixels (deep UNet / ResNet stages)
     kCfg128x256 = 3,      // Cout >= 128, many pixels
-    kNumConvCfg = 4
+    kCfg128x256w8 = 4,    // 8 waves (two per SIMD), ring depth 3: the default for Cout >= 128
+    kCfg64x512w8 = 5,     // 8 waves, Cout == 64, ring depth 2
+    kCfg64x256w8 = 6,     // 8 waves, Cout == 64, 64ch x 32px per wave, ring depth 3
+    kNumConvCfg = 7
 };
 
 hipError_t conv_igemm_prepare();                                   // raise dynamic-LDS limits (once per device)
-hipError_t conv_igemm_launch(int cfg, int dt, const ConvParams& p, hipStream_t stream);
+hipError_t conv_igemm_launch(int cfg, int ns, int dt, const ConvParams& p, hipStream_t stream);   // ns = LDS ring depth 2|3
+bool conv_cfg_has_ns(int cfg, int ns);
 int conv_cfg_ct(int cfg);
 int conv_cfg_pt(int cfg);
 

@@ -115,16 +115,17 @@ template <int N> struct OutVec<split_t, N> {
     }
 };
 
-// CT x PT = channel x pixel tile of the workgroup (4 waves as WGC x 4/WGC); every wave owns a 64-channel
-// slab (FC = 4 fragments: the row permutation the host packs for) and PT*WGC/4 pixels.
-template <typename T, int CT, int PT, int WGC, int NS>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
-    constexpr int WGP = 4 / WGC;
+// CT x PT = channel x pixel tile of the workgroup (NW waves as WGC x NW/WGC); every wave owns a 64-channel
+// slab (FC = 4 fragments: the row permutation the host packs for) and PT*WGC/NW pixels.  NW = 8 puts two waves
+// of one workgroup on every SIMD: while one is parked on the stage barrier / its LDS reads, the other issues MFMAs.
+template <typename T, int CT, int PT, int WGC, int NS, int NW>
+__global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvParams p) {
+    constexpr int WGP = NW / WGC;
     constexpr int WCT = CT / WGC, WPT = PT / WGP;
     constexpr int FC = WCT / 16, FP = WPT / 16;
     static_assert(FC == kConvFC, "host weight packing assumes 64-channel wave slabs");
     constexpr int STAGE = (CT + PT) * 128;
-    constexpr int LW = CT / 32, LX = PT / 32;          // DMA wave-instructions per stage
+    constexpr int LW = CT / (8 * NW), LX = PT / (8 * NW);   // DMA wave-instructions per wave per stage
     constexpr int L = LW + LX;
     typedef typename FragT<T>::V V;
 
@@ -134,18 +135,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ctTile = blockIdx.x % p.nCt;
-    const int ptTile = blockIdx.x / p.nCt;
+    // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2).  Remap so each XCD walks a
+    // contiguous range of tiles: vertically adjacent pixel tiles, which read the same input rows, then share
+    // one L2 instead of each pulling their own copy over the fabric.  Bijective for any grid size; affects
+    // speed only.
+    const unsigned nwg = gridDim.x, bid = blockIdx.x;
+    const unsigned xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
+    const unsigned lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    const int ctTile = lid % p.nCt;
+    const int ptTile = lid / p.nCt;
     const int nS = p.nStages;
     const int HoWo = p.Ho * p.Wo;
 
-    for (int i = tid; i < nS * 8; i += 256) koffs[i] = p.koff[i];
+    for (int i = tid; i < nS * 8; i += 64 * NW) koffs[i] = p.koff[i];
 
     // DMA source of this lane's activation rows: row r of the pixel tile <-> output pixel ptTile*PT + r
     unsigned xoff[LX];
 #pragma unroll
     for (int i = 0; i < LX; ++i) {
-        int pix = ptTile * PT + (i * 4 + wave) * 8 + (lane >> 3);
+        int pix = ptTile * PT + (i * NW + wave) * 8 + (lane >> 3);
         pix = pix < p.M ? pix : p.M - 1;
         const int n = pix / HoWo;
         const int rem = pix - n * HoWo;
@@ -163,10 +171,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         char* sX = sW + CT * 128;
         const char* gw = wsrc + (size_t)s * (CT * 128);
 #pragma unroll
-        for (int i = 0; i < LW; ++i) glds16(gw + i * 4096, sW + (i * 4 + wave) * 1024);
+        for (int i = 0; i < LW; ++i) glds16(gw + i * (NW * 1024), sW + (i * NW + wave) * 1024);
         const int ko = koffs[s * 8 + myChunk];
 #pragma unroll
-        for (int i = 0; i < LX; ++i) glds16(p.x + xoff[i] + ko, sX + (i * 4 + wave) * 1024);
+        for (int i = 0; i < LX; ++i) glds16(p.x + xoff[i] + ko, sX + (i * NW + wave) * 1024);
     };
 
     const int wci = wave / WGP, wpi = wave % WGP;
@@ -190,22 +198,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             const int swh = (chi ^ (lane & 7)) * 16, swl = (clo ^ (lane & 7)) * 16;
             V ah[FC], al[FC], bh[FP], bl[FP];
 #pragma unroll
-            for (int f = 0; f < FC; ++f) {
-                ah[f] = *reinterpret_cast<const V*>(s + rowW + f * 2048 + swh);
-                al[f] = *reinterpret_cast<const V*>(s + rowW + f * 2048 + swl);
-            }
+            for (int f = 0; f < FC; ++f) ah[f] = *reinterpret_cast<const V*>(s + rowW + f * 2048 + swh);
 #pragma unroll
-            for (int g = 0; g < FP; ++g) {
-                bh[g] = *reinterpret_cast<const V*>(s + rowX + g * 2048 + swh);
-                bl[g] = *reinterpret_cast<const V*>(s + rowX + g * 2048 + swl);
-            }
+            for (int g = 0; g < FP; ++g) bh[g] = *reinterpret_cast<const V*>(s + rowX + g * 2048 + swh);
+#pragma unroll
+            for (int f = 0; f < FC; ++f) al[f] = *reinterpret_cast<const V*>(s + rowW + f * 2048 + swl);
+#pragma unroll
+            for (int g = 0; g < FP; ++g) bl[g] = *reinterpret_cast<const V*>(s + rowX + g * 2048 + swl);
+            // leading products first: they only need the hi fragments, so the lo reads land under these MFMAs
+#pragma unroll
+            for (int f = 0; f < FC; ++f)
+#pragma unroll
+                for (int g = 0; g < FP; ++g) mma16(acc[f][g], ah[f], bh[g]);
 #pragma unroll
             for (int f = 0; f < FC; ++f)
 #pragma unroll
                 for (int g = 0; g < FP; ++g) {
-                    mma16(acc[f][g], al[f], bh[g]);      // small cross terms first, then the leading product
+                    mma16(acc[f][g], al[f], bh[g]);
                     mma16(acc[f][g], ah[f], bl[g]);
-                    mma16(acc[f][g], ah[f], bh[g]);
                 }
         } else {
 #pragma unroll
@@ -294,33 +304,40 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 }
 
 // ---- host-side launch -------------------------------------------------------------------------------
-template <typename T, int CT, int PT, int WGC, int NS>
+template <typename T, int CT, int PT, int WGC, int NS, int NW>
 static hipError_t launch_one(const ConvParams& p, hipStream_t stream) {
     const size_t lds = (size_t)NS * (CT + PT) * 128 + (((size_t)p.nStages * 8 * 4 + 15) & ~(size_t)15);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const int nPt = (p.M + PT - 1) / PT;
-    auto kern = conv_igemm_kernel<T, CT, PT, WGC, NS>;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(nPt * p.nCt)), dim3(256), lds, stream, p);
+    auto kern = conv_igemm_kernel<T, CT, PT, WGC, NS, NW>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nPt * p.nCt)), dim3(64 * NW), lds, stream, p);
     return hipGetLastError();
 }
 
-template <typename T, int CT, int PT, int WGC, int NS>
+template <typename T, int CT, int PT, int WGC, int NS, int NW>
 static hipError_t prepare_one() {
-    auto kern = conv_igemm_kernel<T, CT, PT, WGC, NS>;
+    auto kern = conv_igemm_kernel<T, CT, PT, WGC, NS, NW>;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
-#define CV_FOR_EACH_CFG(X, T)        \
-    X(T, 64, 256, 1, 3, kCfg64x256)  \
-    X(T, 64, 128, 1, 3, kCfg64x128)  \
-    X(T, 128, 128, 2, 3, kCfg128x128) \
-    X(T, 128, 256, 2, 3, kCfg128x256)
+#define CV_FOR_EACH_CFG(X, T)              \
+    X(T, 64, 256, 1, 3, 4, kCfg64x256)     \
+    X(T, 64, 128, 1, 3, 4, kCfg64x128)     \
+    X(T, 128, 128, 2, 3, 4, kCfg128x128)   \
+    X(T, 128, 256, 2, 3, 4, kCfg128x256)   \
+    X(T, 64, 256, 1, 2, 4, kCfg64x256)     \
+    X(T, 64, 128, 1, 2, 4, kCfg64x128)     \
+    X(T, 128, 128, 2, 2, 4, kCfg128x128)   \
+    X(T, 128, 256, 2, 2, 4, kCfg128x256)   \
+    X(T, 128, 256, 2, 3, 8, kCfg128x256w8) \
+    X(T, 64, 512, 1, 2, 8, kCfg64x512w8)   \
+    X(T, 64, 256, 1, 3, 8, kCfg64x256w8)
 
 hipError_t conv_igemm_prepare() {
     hipError_t e;
-#define X(T, CT, PT, WGC, NS, ID) \
-    if ((e = prepare_one<T, CT, PT, WGC, NS>()) != hipSuccess) return e;
+#define X(T, CT, PT, WGC, NS, NW, ID) \
+    if ((e = prepare_one<T, CT, PT, WGC, NS, NW>()) != hipSuccess) return e;
     CV_FOR_EACH_CFG(X, half_t)
     CV_FOR_EACH_CFG(X, float)
     CV_FOR_EACH_CFG(X, split_t)
@@ -328,15 +345,23 @@ hipError_t conv_igemm_prepare() {
     return hipSuccess;
 }
 
-hipError_t conv_igemm_launch(int cfg, int dt, const ConvParams& p, hipStream_t stream) {
-#define X(T, CT, PT, WGC, NS, ID) \
-    if (cfg == ID) return launch_one<T, CT, PT, WGC, NS>(p, stream);
+hipError_t conv_igemm_launch(int cfg, int ns, int dt, const ConvParams& p, hipStream_t stream) {
+#define X(T, CT, PT, WGC, NS, NW, ID) \
+    if (cfg == ID && ns == NS) return launch_one<T, CT, PT, WGC, NS, NW>(p, stream);
     if (dt == kF16) { CV_FOR_EACH_CFG(X, half_t) } else if (dt == kSplit) { CV_FOR_EACH_CFG(X, split_t) } else { CV_FOR_EACH_CFG(X, float) }
 #undef X
     return hipErrorInvalidValue;
 }
 
-int conv_cfg_ct(int cfg) { return (cfg == kCfg64x256 || cfg == kCfg64x128) ? 64 : 128; }
-int conv_cfg_pt(int cfg) { return (cfg == kCfg64x256 || cfg == kCfg128x256) ? 256 : 128; }
+bool conv_cfg_has_ns(int cfg, int ns) {
+    if (cfg == kCfg128x256w8 || cfg == kCfg64x256w8) return ns == 3;
+    if (cfg == kCfg64x512w8) return ns == 2;
+    return ns == 2 || ns == 3;
+}
+int conv_cfg_ct(int cfg) { return (cfg == kCfg64x256 || cfg == kCfg64x128 || cfg == kCfg64x512w8 || cfg == kCfg64x256w8) ? 64 : 128; }
+int conv_cfg_pt(int cfg) {
+    if (cfg == kCfg64x512w8) return 512;
+    return (cfg == kCfg64x128 || cfg == kCfg128x128) ? 128 : 256;
+}
 
 }  // namespace cv

@@ -3,6 +3,7 @@
 #include "models.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace cv {
@@ -92,7 +93,7 @@ static void pack_rows(int dt, std::vector<char>& out, int CT, int nCt, int nStag
 
 static Status finish_layer(ConvLayer& L, const std::vector<float>& Wk, int K, const std::vector<float>& scale,
                            const std::vector<float>& shift) {
-    const int CT = conv_cfg_ct(L.cfg);
+    const int CT = L.ct = choose_ct(L.rows);
     L.nStages = (chunks_for(L.dt, K) + 7) / 8;
     L.nCt = (L.rows + CT - 1) / CT;
     L.rowsPad = L.nCt * CT;
@@ -108,31 +109,50 @@ static Status finish_layer(ConvLayer& L, const std::vector<float>& Wk, int K, co
     return Status();
 }
 
+// K ordering of a k x k convolution: K = [channel block cb][tap][channel inside the block], with blocks of
+// kgroup = one 128-byte line of input channels (32 f32/split values, 64 f16 values).  All k*k taps of a channel
+// block are therefore read in consecutive stages: the 9-fold re-read of an input line by the implicit GEMM hits
+// L2 instead of going back to the fabric (measured r01: 7.6x algorithmic fetch traffic with tap-major order).
+static int kgroup_for(int dt, int cinPad) {
+    const int line = 128 / dtype_size(dt);
+    return cinPad % line == 0 ? line : cinPad;
+}
+static inline int k_index(int kgroup, int ntaps, int tap, int ci) {
+    return ((ci / kgroup) * ntaps + tap) * kgroup + ci % kgroup;
+}
+static inline void k_decode(int kgroup, int ntaps, int kk, int* tap, int* ci) {
+    const int cb = kk / (ntaps * kgroup), rem = kk % (ntaps * kgroup);
+    *tap = rem / kgroup;
+    *ci = cb * kgroup + rem % kgroup;
+}
+
 Status ConvLayer::build_conv(const std::string& name_, int dt_, const float* w_oihw, int cout_, int cin_, int k_,
-                             int stride_, const float* scale_, const float* shift_, int cinPad_, int cfg_) {
+                             int stride_, const float* scale_, const float* shift_, int cinPad_) {
     name = name_; dt = dt_; cin = cin_; cinPad = cinPad_; cout = cout_; k = k_; stride = stride_;
-    shuffle = false; rows = cout_; cfg = cfg_;
+    shuffle = false; rows = cout_;
     if (cinPad % 8 || cinPad < cin) return fail(1, name + ": input channel padding must be a multiple of 8");
     if (k != 1 && k != 3) return fail(1, name + ": implicit-GEMM path supports 1x1 and 3x3 kernels");
     if (cout % 16) return fail(1, name + ": output channels must be a multiple of 16");
     const int K = k * k * cinPad;
+    kgroup = kgroup_for(dt, cinPad);
     std::vector<float> Wk((size_t)rows * K, 0.f);
     for (int co = 0; co < cout; ++co)
         for (int ci = 0; ci < cin; ++ci)
             for (int ky = 0; ky < k; ++ky)
                 for (int kx = 0; kx < k; ++kx)
-                    Wk[(size_t)co * K + (ky * k + kx) * cinPad + ci] = w_oihw[(((size_t)co * cin + ci) * k + ky) * k + kx];
+                    Wk[(size_t)co * K + k_index(kgroup, k * k, ky * k + kx, ci)] = w_oihw[(((size_t)co * cin + ci) * k + ky) * k + kx];
     std::vector<float> sc(scale_, scale_ + cout), sh(shift_, shift_ + cout);
     return finish_layer(*this, Wk, K, sc, sh);
 }
 
 Status ConvLayer::build_convT(const std::string& name_, int dt_, const float* w_iohw, int cin_, int cout_,
-                              const float* bias, int cfg_) {
+                              const float* bias) {
     name = name_; dt = dt_; cin = cin_; cinPad = cin_; cout = cout_; k = 1; stride = 1;
-    shuffle = true; rows = 4 * cout_; cfg = cfg_;
+    shuffle = true; rows = 4 * cout_;
     if (cin % 8) return fail(1, name + ": transposed-conv input channels must be a multiple of 8");
     if (cout % 16) return fail(1, name + ": transposed-conv output channels must be a multiple of 16");
     const int K = cin;
+    kgroup = cin;
     std::vector<float> Wk((size_t)rows * K, 0.f), sc(rows, 1.f), sh(rows, 0.f);
     for (int ci = 0; ci < cin; ++ci)
         for (int co = 0; co < cout; ++co)
@@ -155,7 +175,8 @@ Status ConvLayer::get_koff(const TensorRef& x, const int** out) {
         for (int kc = 0; kc < nStages * 8; ++kc) {
             int kk = chunk_k0(dt, kc);
             if (kk >= K) kk = 0;                         // zero weights there; keep the gather on real data
-            const int tap = kk / cinPad, ci = kk % cinPad;
+            int tap, ci;
+            k_decode(kgroup, k * k, kk, &tap, &ci);
             const int ky = tap / k, kx = tap % k;
             long long off = ((long long)((ky + 1 - pad) * key.xWp + (kx + 1 - pad)) * x.Cs + x.Coff + ci) * esz;
             if (dt == kSplit) {                          // pick the hi or lo chunk of the 32-byte channel group
@@ -173,13 +194,49 @@ Status ConvLayer::get_koff(const TensorRef& x, const int** out) {
     return Status();
 }
 
+static int env_int(const char* name, int dflt) {
+    const char* v = std::getenv(name);
+    return v && *v ? std::atoi(v) : dflt;
+}
+
+// Tile / ring-depth choice, from the r01 sweeps on MI355X (profiles/r01_tuning.md):
+//   Cout % 128 == 0, >= 256 workgroups of 128x256 : 8-wave 128x256 tile, ring 3 (two waves per SIMD in ONE workgroup)
+//   Cout % 128 == 0, fewer pixels                 : 4-wave 128x128 tile; ring 3 at <= 1 workgroup per CU, else ring 2
+//   Cout == 64 (full-resolution UNet, ResNet layer1): 4-wave 64x128 tile, ring 3 (72 KB -> two workgroups per CU)
+// CV_CONV_W8 / CV_CONV_PT / CV_CONV_NS override for experiments.
+static int64_t blocks_for(int rows, int64_t pixels, int ct, int pt) {
+    return ((pixels + pt - 1) / pt) * ((rows + ct - 1) / ct);
+}
+
+static int env_cached(int idx) {                      // 0: CV_CONV_W8, 1: CV_CONV_PT, 2: CV_CONV_NS
+    static const int v[3] = {env_int("CV_CONV_W8", -1), env_int("CV_CONV_PT", 0), env_int("CV_CONV_NS", 0)};
+    return v[idx];
+}
+
+// channel-tile height of a layer: fixed at pack time (weights are packed per channel tile)
+int choose_ct(int rows) { return rows % 128 == 0 ? 128 : 64; }
+
+// per-launch tile choice among the configurations that share the layer's channel tile
 int choose_cfg(int rows, int64_t pixels) {
-    const bool wide = rows % 128 == 0;
-    const int ct = wide ? 128 : 64;
-    const int64_t blocks256 = ((pixels + 255) / 256) * ((rows + ct - 1) / ct);
-    const bool big = blocks256 >= 2 * 256;              // >= two full waves of workgroups at PT = 256
-    if (wide) return big ? kCfg128x256 : kCfg128x128;
-    return big ? kCfg64x256 : kCfg64x128;
+    const bool wide = choose_ct(rows) == 128;
+    const int w8 = env_cached(0), force_pt = env_cached(1);
+    if (force_pt == 128 || force_pt == 256)
+        return force_pt == 256 ? (wide ? kCfg128x256 : kCfg64x256) : (wide ? kCfg128x128 : kCfg64x128);
+    if (!wide) {
+        if (w8 == 1) return kCfg64x512w8;
+        if (w8 == 2) return kCfg64x256w8;
+        return kCfg64x128;
+    }
+    if (w8 != 0 && blocks_for(rows, pixels, 128, 256) >= 256) return kCfg128x256w8;
+    return kCfg128x128;
+}
+
+int choose_ns(int cfg, int dt, int rows, int64_t pixels) {
+    (void)dt;
+    const int forced = env_cached(2);
+    if ((forced == 2 || forced == 3) && conv_cfg_has_ns(cfg, forced)) return forced;
+    if (cfg == kCfg128x128) return blocks_for(rows, pixels, 128, 128) > 256 ? 2 : 3;
+    return conv_cfg_has_ns(cfg, 3) ? 3 : 2;
 }
 
 // ---- engine --------------------------------------------------------------------------------------
@@ -221,8 +278,11 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
     p.xHp = x.H + 2; p.xWp = x.W + 2; p.stride = L.stride; p.xCs = x.Cs;
     p.yHp = y.H + 2; p.yWp = y.W + 2; p.yCs = y.Cs; p.yCoff = y.Coff;
     p.Cout = L.cout; p.rows = L.rows; p.nStages = L.nStages; p.nCt = L.nCt; p.relu = relu ? 1 : 0; p.shuffle = L.shuffle ? 1 : 0;
+    const int cfg = choose_cfg(L.rows, p.M);
+    const int ns = choose_ns(cfg, dt, L.rows, p.M);
+    p.nCt = (L.rows + conv_cfg_ct(cfg) - 1) / conv_cfg_ct(cfg);
     if (profiling) prof_begin(L.name, true, (double)L.macs_per_out_pixel() * (double)p.M, s);
-    hipError_t e = conv_igemm_launch(L.cfg, dt, p, s);
+    hipError_t e = conv_igemm_launch(cfg, ns, dt, p, s);
     if (profiling) prof_end(s);
     if (e != hipSuccess) return hip_fail(e, ("conv launch " + L.name).c_str());
     return Status();

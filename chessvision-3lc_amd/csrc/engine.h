@@ -74,7 +74,9 @@ struct ConvLayer {
     std::string name;
     int cin = 0, cinPad = 0, cout = 0, k = 1, stride = 1;
     bool shuffle = false;
-    int rows = 0, rowsPad = 0, nStages = 0, nCt = 0, cfg = 0;
+    int rows = 0, rowsPad = 0, nStages = 0, nCt = 0;
+    int ct = 64;                                    // channel-tile height the weights are packed for (64 | 128)
+    int kgroup = 8;                                 // input channels per K block (see engine.cpp: K ordering)
     int dt = kF16;
     DeviceBuffer w, scale, shift;
     // koff tables are geometry dependent: keyed by (xWp, xCs, xCoff)
@@ -84,10 +86,10 @@ struct ConvLayer {
 
     // w_oihw: (cout, cin, k, k); scale/shift: (cout)
     Status build_conv(const std::string& name_, int dt_, const float* w_oihw, int cout_, int cin_, int k_,
-                      int stride_, const float* scale_, const float* shift_, int cinPad_, int cfg_);
+                      int stride_, const float* scale_, const float* shift_, int cinPad_);
     // w_iohw: (cin, cout, 2, 2); bias: (cout)
     Status build_convT(const std::string& name_, int dt_, const float* w_iohw, int cin_, int cout_,
-                       const float* bias, int cfg_);
+                       const float* bias);
     Status get_koff(const TensorRef& x, const int** out);
     int64_t macs_per_out_pixel() const { return shuffle ? (int64_t)cin * cout * 4 : (int64_t)cin * k * k * cout; }
 };
@@ -128,7 +130,9 @@ class Engine {
     void prof_clear();
 };
 
+int choose_ct(int rows);
 int choose_cfg(int rows, int64_t pixels);
+int choose_ns(int cfg, int dt, int rows, int64_t pixels);
 
 Status unet_load(Engine& e, const ParamMap& pm);
 Status unet_forward(Engine& e, const void* x, bool x_u8, int batch, float* logits, uint8_t* mask, float thr,
