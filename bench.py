@@ -28,9 +28,25 @@ sys.path.insert(0, str(ROOT))
 
 import torch  # noqa: E402
 
-# MI355X dense MFMA peaks (MI355X_MICROARCH.md, chip table).  f16x3 runs on the f16 MFMA and issues 3 MFMAs per
-# algorithmic MAC, so its reachable ceiling is 2500/3 = 833; the roofline is still priced against the f16 peak.
-PEAK_TFLOPS = {"f32": 157.3, "f16": 2500.0, "f16x3": 2500.0}
+# MI355X dense MFMA peaks (MI355X_MICROARCH.md, chip table): f32-input MFMA 157.3 TF, f16 MFMA ~2500 TF.
+# f16x3 computes every algorithmic MAC with THREE f16 MFMA products (hi*hi + hi*lo + lo*hi), so the dense peak of
+# that arithmetic type is 2500 / 3 algorithmic TFLOP/s; the line also carries the fraction of the raw f16 peak.
+PEAK_TFLOPS = {"f32": 157.3, "f16": 2500.0, "f16x3": 2500.0 / 3.0}
+MFMA_PER_MAC = {"f32": 1, "f16": 1, "f16x3": 3}
+
+
+def pmc_traffic(dtype, unet_chunk, resnet_chunk, unet_launches, resnet_launches):
+    """Per-launch HBM bytes of the conv family from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json:
+    separate --pmc FETCH_SIZE / WRITE_SIZE runs of the same chunk sizes, gfx950-corrected); None if not collected."""
+    path = ROOT / "profiles" / "r01_pmc_traffic.json"
+    if not path.exists() or (unet_chunk, resnet_chunk) != (16, 4096):
+        return None
+    t = json.load(open(path))
+    u, r = t.get(f"{dtype}_unet"), t.get(f"{dtype}_resnet18")
+    if not u or not r:
+        return None
+    total = u["hbm_bytes_per_launch"] * unet_launches + r["hbm_bytes_per_launch"] * resnet_launches
+    return total / max(1, unet_launches + resnet_launches)
 
 
 def log(*a):
@@ -131,9 +147,11 @@ def main():
     conv_flop = 0.0
     all_ms = 0.0
     table = {}
+    launches = {}
     for model, inp in (("unet", x), ("resnet18", sq)):
         c_ms, c_n, a_ms, entries = eng.profile(model, inp, iters=1)
         conv_ms += c_ms; conv_n += c_n; all_ms += a_ms
+        launches[model] = c_n
         for e in entries:
             if e["conv"]:
                 conv_flop += 2.0 * e["macs"]
@@ -158,10 +176,15 @@ def main():
                    "resnet_chunk": args.resnet_chunk, "parallelism": f"replicas x{world}, boards sharded, weights RCCL-broadcast once",
                    "gflop_per_board": round(2 * macs_board / 1e9, 3)},
         "e2e_tflops": round(2 * macs_board * value / 1e12, 2),
-        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                     "frac": round(achieved / peak, 4), "traffic": None,
+        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                     "frac": round(achieved / peak, 4),
+                     "traffic": pmc_traffic(args.dtype, args.unet_chunk, args.resnet_chunk, launches["unet"], launches["resnet18"]),
                      "kernel": "cv::conv_igemm_kernel (all instantiations)", "launches_per_step": conv_n,
-                     "avg_launch_ms": round(conv_ms / max(conv_n, 1), 4), "algorithmic_gflop_per_step": round(conv_flop / 1e9, 2)},
+                     "avg_launch_ms": round(conv_ms / max(conv_n, 1), 4), "algorithmic_gflop_per_step": round(conv_flop / 1e9, 2),
+                     "mfma_products_per_mac": MFMA_PER_MAC[args.dtype],
+                     "mfma_issued_tflops": round(achieved * MFMA_PER_MAC[args.dtype], 2),
+                     "frac_of_raw_mfma_peak": round(achieved * MFMA_PER_MAC[args.dtype] / (157.3 if args.dtype == "f32" else 2500.0), 4),
+                     "traffic_unit": "HBM bytes per conv launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)"},
     }
     if world == 1 and not args.no_cpu_baseline:
         nchk = min(B, 64)
