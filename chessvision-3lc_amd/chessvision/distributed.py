@@ -30,7 +30,8 @@ def init_process_group(backend: str | None = None) -> tuple[int, int, torch.devi
     if use_gpu:
         torch.cuda.set_device(local)
     device = torch.device("cuda", local) if use_gpu else torch.device("cpu")
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("CV_FORCE_DIST", "0") == "1"          # exercise the RCCL path on one GPU (tests)
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -74,7 +75,7 @@ def broadcast_state_dict(state: Mapping[str, np.ndarray] | None, spec: Sequence[
                          src: int = 0) -> "OrderedDict[str, np.ndarray]":
     """Rank `src` supplies `state`; every rank returns an identical copy (one flat-buffer broadcast)."""
     world = dist.get_world_size() if dist.is_initialized() else 1
-    if world == 1:
+    if world == 1 and not dist.is_initialized():
         assert state is not None
         return OrderedDict((k, np.ascontiguousarray(state[k], dtype=np.float32)) for k, _, _ in spec)
     total = sum(int(np.prod(s)) for _, s, _ in spec)
@@ -104,7 +105,7 @@ def interleave_shards(gathered: torch.Tensor, world: int) -> torch.Tensor:
 
 
 def max_over_ranks(value: float, device: torch.device) -> float:
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return value
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -112,7 +113,7 @@ def max_over_ranks(value: float, device: torch.device) -> float:
 
 
 def barrier(device: torch.device) -> None:
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         if device.type == "cuda":
             dist.barrier(device_ids=[device.index])
         else:

@@ -21,7 +21,7 @@ struct Engine::UNet {
 struct Engine::ResNet {
     int cap = 0;
     int last_n = 0;
-    DeviceBuffer stem_w, stem_scale, stem_shift, fc_w, fc_b;
+    DeviceBuffer stem_w, stem_wpk, stem_scale, stem_shift, fc_w, fc_b;
     struct Block {
         ConvLayer conv1, conv2, down;
         bool has_down = false;

@@ -25,6 +25,11 @@ hipError_t outc_1x1(int dt, const TensorRef& src, const float* w, const float* b
 hipError_t stem7x7(int dt, const void* x, bool x_is_u8, int n, const float* w, const float* scale,
                    const float* shift, const TensorRef& dst, hipStream_t s);
 
+// Fused stem for the f16 / split-f16 engines: conv 7x7 s2 p3 + BN + ReLU + max_pool2d(3,2,1) on the MFMA.
+// wpk: packed filter bank [hi|lo][k-step 2][fragment 4][lane 64] x half8 (resnet.cpp: pack_stem_mfma).  dst: 64 ch @ 16x16.
+hipError_t stem_pool_mfma(int dt, const void* x, bool x_is_u8, int n, const void* wpk, const float* scale,
+                          const float* shift, const TensorRef& dst, hipStream_t s);
+
 // global average pool + Linear(C -> 13) (+ optional softmax).  w: [13][C] f32, b: [13]
 hipError_t head_avgpool_fc(int dt, const TensorRef& src, const float* w, const float* b, float* out,
                            int softmax, hipStream_t s);

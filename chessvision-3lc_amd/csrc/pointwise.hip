@@ -304,6 +304,102 @@ __global__ __launch_bounds__(256) void stem7x7_kernel(const XT* __restrict__ x, 
     }
 }
 
+// ---- ResNet stem on the matrix cores, fused with the 3x3/s2/p1 max-pool (f16 and split-f16 engines) ----------
+// conv 7x7 s2 p3 (1 -> 64) + BN + ReLU + max_pool2d(3, 2, 1):  (n,1,64,64) -> 64 ch @ 16x16, one pass, nothing but the
+// pooled result leaves the CU.  GEMM view per square: D[ch][pix] = sum_k W[ch][k] * patch[pix][k], K = 7 rows x 8
+// (kx padded 7 -> 8, ky padded 7 -> 8) = 64 = two 16x16x32 MFMA k-steps; lane group q of k-step ks owns filter row
+// ky = 4*ks + q, whose 8 taps are 4 consecutive LDS dwords of the zero-bordered input plane -> the B fragment is four
+// ds_read_b32, no packing.  One 16-lane pixel fragment = one pooled output row; the 9 pool-window positions are
+// computed one after the other (2.25x recompute of the tiny conv instead of staging 32x32x64 outputs in LDS) and
+// max-reduced in registers.  Out-of-range window positions contribute 0, which equals -inf padding after ReLU.
+template <typename T, typename XT>
+__global__ __launch_bounds__(256) void stem_pool_mfma_kernel(const XT* __restrict__ x, int n,
+                                                             const half8* __restrict__ wpk,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, TensorRef dst) {
+    constexpr bool SPLIT = sizeof(T) == 4;
+    constexpr int LD = 98, ROWS = 72, PAD = 5;              // LD/2 = 49 dwords: odd rows land on the other bank half
+    __shared__ __attribute__((aligned(16))) half_t plane[SPLIT ? 2 : 1][ROWS * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, l15 = lane & 15;
+
+    half8 ah[2][4], al[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            ah[ks][f] = wpk[((0 * 2 + ks) * 4 + f) * 64 + lane];
+            al[ks][f] = SPLIT ? wpk[((1 * 2 + ks) * 4 + f) * 64 + lane] : ah[ks][f];
+        }
+    float sc[16], sh[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { sc[i] = scale[q * 16 + i]; sh[i] = shift[q * 16 + i]; }
+
+    for (int i = tid; i < (SPLIT ? 2 : 1) * ROWS * LD; i += 256) (&plane[0][0])[i] = (half_t)0.f;
+    const unsigned* p32h = reinterpret_cast<const unsigned*>(&plane[0][0]);
+    const unsigned* p32l = reinterpret_cast<const unsigned*>(&plane[SPLIT ? 1 : 0][0]);
+
+    for (int sq = blockIdx.x; sq < n; sq += gridDim.x) {
+        __syncthreads();                                     // all fragment reads of the previous square are done
+        const XT* xs = x + (size_t)sq * 4096;
+        for (int i = tid; i < 4096; i += 256) {
+            float v = (float)xs[i];
+            if (sizeof(XT) == 1) v = v / 255.f;
+            const half_t hi = (half_t)v;
+            const int at = ((i >> 6) + PAD) * LD + (i & 63) + PAD;
+            plane[0][at] = hi;
+            if (SPLIT) plane[1][at] = (half_t)(v - (float)hi);
+        }
+        __syncthreads();
+        for (int py = wave; py < 16; py += 4) {              // one pooled row (16 pixels) per fragment
+            float best[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) best[i] = 0.f;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int cy = 2 * py - 1 + dy, cx = 2 * l15 - 1 + dx;      // conv-output pixel of this window slot
+                    const bool valid = cy >= 0 && cx >= 0;
+                    f4 acc[4];
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) acc[f] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const int row = 2 * cy + 2 + ks * 4 + q;               // plane row of filter row ky = 4*ks+q
+                        const int dw = (row * LD + 2 * cx + 2) >> 1;
+                        union { unsigned u[4]; half8 h; } bh, bl;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { bh.u[j] = p32h[dw + j]; bl.u[j] = SPLIT ? p32l[dw + j] : 0u; }
+#pragma unroll
+                        for (int f = 0; f < 4; ++f) {
+                            acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks][f], bh.h, acc[f], 0, 0, 0);
+                            if (SPLIT) {
+                                acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ks][f], bh.h, acc[f], 0, 0, 0);
+                                acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks][f], bl.h, acc[f], 0, 0, 0);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int f = 0; f < 4; ++f)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float v = acc[f][r] * sc[f * 4 + r] + sh[f * 4 + r];
+                            v = valid && v > 0.f ? v : 0.f;
+                            best[f * 4 + r] = fmaxf(best[f * 4 + r], v);
+                        }
+                }
+            const size_t opix = pix_index(dst, sq, py, l15);
+#pragma unroll
+            for (int i = 0; i < 16; i += Grp<T>::N) {
+                int par;
+                char* d = grp_ptr<T>(dst, opix, (q * 16 + i) / Grp<T>::N, &par);
+                Grp<T>::store(d, par, best + i);
+            }
+        }
+    }
+}
+
 // ---- head: adaptive_avg_pool2d(1) + Linear(C -> 13) (+ softmax) ------------------------------------
 // One wave per square; lane owns channel groups lane, lane+64, ...; 13 wave-wide xor-butterfly reductions.
 template <typename T>
@@ -447,6 +543,20 @@ hipError_t stem7x7(int dt, const void* x, bool x_is_u8, int n, const float* w, c
     } while (0)
     if (dt == kF16) CV_STEM(half_t); else if (dt == kSplit) CV_STEM(split_t); else CV_STEM(float);
 #undef CV_STEM
+    return hipGetLastError();
+}
+hipError_t stem_pool_mfma(int dt, const void* x, bool x_is_u8, int n, const void* wpk, const float* scale,
+                          const float* shift, const TensorRef& dst, hipStream_t s) {
+    if (dt == kF32 || dst.C != 64 || dst.H != 16 || dst.W != 16 || dst.Coff != 0) return hipErrorInvalidValue;
+    const dim3 g((unsigned)(n < 2048 ? n : 2048)), b(256);
+    const half8* w = reinterpret_cast<const half8*>(wpk);
+    if (dt == kF16) {
+        if (x_is_u8) hipLaunchKernelGGL((stem_pool_mfma_kernel<half_t, uint8_t>), g, b, 0, s, (const uint8_t*)x, n, w, scale, shift, dst);
+        else hipLaunchKernelGGL((stem_pool_mfma_kernel<half_t, float>), g, b, 0, s, (const float*)x, n, w, scale, shift, dst);
+    } else {
+        if (x_is_u8) hipLaunchKernelGGL((stem_pool_mfma_kernel<split_t, uint8_t>), g, b, 0, s, (const uint8_t*)x, n, w, scale, shift, dst);
+        else hipLaunchKernelGGL((stem_pool_mfma_kernel<split_t, float>), g, b, 0, s, (const float*)x, n, w, scale, shift, dst);
+    }
     return hipGetLastError();
 }
 hipError_t head_avgpool_fc(int dt, const TensorRef& src, const float* w, const float* b, float* out,

@@ -43,12 +43,30 @@ Status resnet_load(Engine& e, const ParamMap& pm) {
         std::vector<float> sc(64), sh(64);
         for (int i = 0; i < 64; ++i) { sc[i] = g[i] / std::sqrt(var[i] + 1e-5f); sh[i] = b[i] - mu[i] * sc[i]; }
         CV_TRY(R.stem_w.upload(w, 64 * 49 * sizeof(float)));
+        if (dt != kF32) {
+            // MFMA A-operand image of the 64x(7x7) filter bank: k-slot (ks, q, j) = filter tap (ky = 4*ks + q, kx = j),
+            // MFMA row i of fragment f = channel 16*(i/4) + 4*f + i%4 (the conv epilogue's lane-contiguous order)
+            std::vector<_Float16> pk((size_t)2 * 2 * 4 * 64 * 8);
+            for (int hl = 0; hl < 2; ++hl)
+                for (int ks = 0; ks < 2; ++ks)
+                    for (int f = 0; f < 4; ++f)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int i = lane & 15, q = lane >> 4, ky = ks * 4 + q;
+                            const int ch = 16 * (i / 4) + 4 * f + (i % 4);
+                            for (int j = 0; j < 8; ++j) {
+                                const float v = (ky < 7 && j < 7) ? w[ch * 49 + ky * 7 + j] : 0.f;
+                                const _Float16 hi = (_Float16)v;
+                                pk[((((size_t)hl * 2 + ks) * 4 + f) * 64 + lane) * 8 + j] = hl ? (_Float16)(v - (float)hi) : hi;
+                            }
+                        }
+            CV_TRY(R.stem_wpk.upload(pk.data(), pk.size() * sizeof(_Float16)));
+        }
         CV_TRY(R.stem_scale.upload(sc.data(), 64 * sizeof(float)));
         CV_TRY(R.stem_shift.upload(sh.data(), 64 * sizeof(float)));
     }
-    CV_TRY(R.stem_out.create(S, 32, 32, 64, dt));
+    if (dt == kF32) CV_TRY(R.stem_out.create(S, 32, 32, 64, dt));   // other engines fuse stem + pool
     CV_TRY(R.pool_out.create(S, 16, 16, 64, dt));
-    R.taps["act1"] = R.stem_out.ref(S);
+    if (dt == kF32) R.taps["act1"] = R.stem_out.ref(S);
     R.taps["maxpool"] = R.pool_out.ref(S);
 
     const int widths[4] = {64, 128, 256, 512};
@@ -114,11 +132,17 @@ static Status resnet_chunk(Engine& e, const void* x, bool x_u8, int n, float* ou
         if (err != hipSuccess) return hip_fail(err, name);
         return Status();
     };
-    begin("stem7x7", 49.0 * 64 * 1024 * n);
-    CV_TRY(end("stem7x7", stem7x7(dt, x, x_u8, n, (const float*)R.stem_w.ptr, (const float*)R.stem_scale.ptr,
-                                   (const float*)R.stem_shift.ptr, R.stem_out.ref(n), s)));
-    begin("maxpool3x3s2", 0);
-    CV_TRY(end("maxpool3x3s2", maxpool3x3s2(dt, R.stem_out.ref(n), R.pool_out.ref(n), s)));
+    if (dt == kF32) {
+        begin("stem7x7", 49.0 * 64 * 1024 * n);
+        CV_TRY(end("stem7x7", stem7x7(dt, x, x_u8, n, (const float*)R.stem_w.ptr, (const float*)R.stem_scale.ptr,
+                                       (const float*)R.stem_shift.ptr, R.stem_out.ref(n), s)));
+        begin("maxpool3x3s2", 0);
+        CV_TRY(end("maxpool3x3s2", maxpool3x3s2(dt, R.stem_out.ref(n), R.pool_out.ref(n), s)));
+    } else {
+        begin("stem7x7+maxpool (mfma)", 49.0 * 64 * 1024 * n);
+        CV_TRY(end("stem_pool_mfma", stem_pool_mfma(dt, x, x_u8, n, R.stem_wpk.ptr, (const float*)R.stem_scale.ptr,
+                                                     (const float*)R.stem_shift.ptr, R.pool_out.ref(n), s)));
+    }
     TensorRef cur = R.pool_out.ref(n);
     for (int i = 0; i < 8; ++i) {
         Engine::ResNet::Block& B = R.blocks[i];

@@ -113,6 +113,8 @@ def test_resnet18_forward_matches_oracle(prec):
     assert out.shape == (200, 13)
     layer_err = {}
     for name in RESNET_TAPS:
+        if name == "act1" and prec != "f32":
+            continue                    # f16 / f16x3 engines fuse stem + max-pool: the 32x32 stem output never exists
         a = torch.from_numpy(eng.activation("resnet18", name))
         r = got_ref[name][128:200]
         layer_err[name] = [float((a - r).abs().max()), float(r.abs().max())]
