@@ -170,32 +170,65 @@ class ChessVision:
 
     def process_images(self, images: Sequence[NDArray[np.uint8]], threshold: float = 0.5,
                        flip: bool = False) -> list[ChessVisionResult]:
-        """Batched pipeline (new; the reference processes one image per call): one UNet pass over all images with
-        the u8 -> /255 packing and the sigmoid/threshold mask on device, host contour/warp per board, then ONE
-        classifier pass over every found board's 64 squares with softmax on device."""
+        """Batched pipeline (new; the reference processes one image per call).  Images stay on the device between
+        the two CNNs: INTER_AREA resize -> UNet (u8 in, logits + thresholded mask out) run per group of equally
+        sized images; only the 64 KB masks come back for the C++ contour stage; the quadrangles go back as 3x3 maps
+        and ONE fused warp+gray+flip+split kernel writes the classifier input; ONE classifier pass with softmax on
+        device covers every found board.  Results are identical in layout to ``process_image``'s."""
         started = time.time()
         for image in images:
             assert isinstance(image, np.ndarray) and image.dtype == np.uint8 and image.ndim == 3
         if not images:
             return []
         _ = self.board_extractor, self.classifier
+        from .hip_backend import find_quadrangle
+
         eng = self._get_engine()
-        small = np.stack([classical.resize_area(im, constants.INPUT_SIZE) for im in images])
-        logits_dev, _mask = eng.unet_forward_u8(torch.from_numpy(small), threshold=threshold, want_mask=False)
-        logits = logits_dev[:, 0].cpu().numpy()
-        boards = [self.process_board_extraction_logits(logits[i], images[i], threshold) for i in range(len(images))]
-        found = [i for i, b in enumerate(boards) if b.board_image is not None]
+        n = len(images)
+        logits = np.empty((n, 256, 256), dtype=np.float32)
+        masks = np.empty((n, 256, 256), dtype=np.uint8)
+        device_images: dict[int, torch.Tensor] = {}
+        groups: dict[tuple, list[int]] = {}
+        for i, im in enumerate(images):
+            groups.setdefault(im.shape, []).append(i)
+        for shape, ids in groups.items():
+            batch = torch.from_numpy(np.stack([images[i] for i in ids])).to(self.device)
+            small = eng.resize_area_u8(batch, (constants.INPUT_SIZE[1], constants.INPUT_SIZE[0]))
+            lg, mk = eng.unet_forward_u8(small, threshold=threshold, want_mask=True)
+            logits[ids] = lg[:, 0].cpu().numpy()
+            masks[ids] = mk.cpu().numpy()
+            for k, i in enumerate(ids):
+                device_images[i] = batch[k]
+        quads: list[NDArray[np.float32] | None] = []
+        for i in range(n):
+            q = find_quadrangle(masks[i])
+            quads.append(None if q is None else self._scale_quadrangle(q, (images[i].shape[0], images[i].shape[1])))
+        found = [i for i in range(n) if quads[i] is not None]
+        boards: dict[int, NDArray[np.uint8]] = {}
         positions: dict[int, PositionResult] = {}
-        if found:
-            squares = [self.extract_squares(boards[i].board_image) for i in found]
-            flat = torch.from_numpy(np.concatenate(squares)[..., 0])                  # (64*n, 64, 64) uint8
-            probs = eng.resnet18_forward_u8(flat).cpu().numpy().reshape(len(found), 64, constants.NUM_CLASSES)
-            names = constants.SQUARE_NAMES_FLIPPED if flip else constants.SQUARE_NAMES_NORMAL
-            for k, i in enumerate(found):
-                positions[i] = self.process_position_probabilities(probs[k], names, squares[k])
-        per_image = (time.time() - started) / len(images)
-        return [ChessVisionResult(board_extraction=boards[i], position=positions.get(i), processing_time=per_image)
-                for i in range(len(images))]
+        names = constants.SQUARE_NAMES_FLIPPED if flip else constants.SQUARE_NAMES_NORMAL
+        w, h = constants.BOARD_SIZE
+        dest = np.array(((0, 0), (w, 0), (w, h), (0, h)), np.float32)
+        by_shape: dict[tuple, list[int]] = {}
+        for i in found:
+            by_shape.setdefault(images[i].shape, []).append(i)
+        for shape, ids in by_shape.items():
+            inv = np.stack([np.linalg.inv(classical.get_perspective_transform(quads[i].reshape(4, 2), dest)) for i in ids])
+            squares_dev, boards_dev = eng.extract_squares_u8(torch.stack([device_images[i] for i in ids]), inv)
+            probs = eng.resnet18_forward_u8(squares_dev).cpu().numpy().reshape(len(ids), 64, constants.NUM_CLASSES)
+            squares_host = squares_dev.cpu().numpy().reshape(len(ids), 64, 64, 64, 1)
+            boards_host = boards_dev.cpu().numpy()
+            for k, i in enumerate(ids):
+                boards[i] = boards_host[k]
+                positions[i] = self.process_position_probabilities(probs[k], names, squares_host[k])
+        per_image = (time.time() - started) / n
+        results = []
+        for i in range(n):
+            extraction = BoardExtractionResult(board_image=boards.get(i), binary_mask=masks[i], quadrangle=quads[i],
+                                               probabilities=logits[i])
+            results.append(ChessVisionResult(board_extraction=extraction, position=positions.get(i),
+                                             processing_time=per_image))
+        return results
 
     # ---- host-side post-processing (static, usable without models) ----------------------------------
     @staticmethod

@@ -76,6 +76,9 @@ SYMBOLS = [
     ("cv_op_maxpool3x3s2", _i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     ("cv_op_upsample_bilinear2x", _i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     ("cv_selftest_mfma", _i, [_vp, ctypes.POINTER(_f), ctypes.POINTER(_f)]),
+    ("cv_find_quadrangle", _i, [_vp, _i, _i, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(_i)]),
+    ("cv_resize_area_u8", _i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
+    ("cv_extract_squares_u8", _i, [_vp, _vp, _i, _i, _i, ctypes.POINTER(ctypes.c_double), _vp, _vp, _vp]),
 ]
 
 
@@ -134,6 +137,22 @@ def _as_param_table(state_dict: Mapping[str, object]):
         entries.append(_Param(key.encode(), arr.ctypes.data_as(_fp), arr.ndim, shape))
     table = (_Param * len(entries))(*entries)
     return table, len(entries), keep
+
+
+def find_quadrangle(mask: np.ndarray):
+    """Binary mask (H, W) uint8 -> (4,1,2) int32 quadrangle in the reference's vertex order, or None.
+    Host-side C++ (csrc/contour.cpp); needs neither a GPU nor an engine.  Same result as
+    ``ChessVision._find_quadrangle`` (which stays the readable numpy restatement and the test checker)."""
+    lib = load_library()
+    m = np.ascontiguousarray(mask, dtype=np.uint8)
+    if m.ndim != 2:
+        raise HipBackendError("find_quadrangle expects a 2-D uint8 mask")
+    quad = (ctypes.c_int32 * 8)()
+    found = _i(0)
+    _check(lib.cv_find_quadrangle(m.ctypes.data_as(_vp), m.shape[0], m.shape[1], quad, ctypes.byref(found)))
+    if not found.value:
+        return None
+    return np.array(list(quad), dtype=np.int32).reshape(4, 1, 2)
 
 
 class HipEngine:
@@ -234,6 +253,33 @@ class HipEngine:
         out = torch.empty_like(logits)
         _check(self._lib.cv_softmax13(self._h, _ptr(logits), logits.shape[0], _ptr(out), _stream_ptr(self.device)))
         return out
+
+    # -- classical stages on the device ------------------------------------------
+    def resize_area_u8(self, images: torch.Tensor, out_hw=(256, 256)) -> torch.Tensor:
+        """(N,H,W,C) uint8 -> (N,out_h,out_w,C) uint8 with INTER_AREA semantics (reference core.py:212)."""
+        if images.dtype != torch.uint8 or images.dim() != 4:
+            raise HipBackendError("resize_area_u8 expects (N,H,W,C) uint8")
+        images = images.to(self.device).contiguous()
+        n, h, w, c = images.shape
+        out = torch.empty((n, out_hw[0], out_hw[1], c), dtype=torch.uint8, device=self.device)
+        _check(self._lib.cv_resize_area_u8(self._h, _ptr(images), n, h, w, c, _ptr(out), out_hw[0], out_hw[1],
+                                           _stream_ptr(self.device)))
+        return out
+
+    def extract_squares_u8(self, images: torch.Tensor, inverse_maps: np.ndarray, want_boards: bool = True):
+        """images (N,H,W,3) uint8 BGR on the device + N inverse homographies (board pixel -> source pixel) ->
+        (squares (N*64,64,64) uint8, boards (N,512,512) uint8 | None): warp + gray + flip + split, fused."""
+        if images.dtype != torch.uint8 or images.dim() != 4 or images.shape[3] != 3:
+            raise HipBackendError("extract_squares_u8 expects (N,H,W,3) uint8")
+        images = images.to(self.device).contiguous()
+        n, h, w, _ = images.shape
+        inv = np.ascontiguousarray(inverse_maps, dtype=np.float64).reshape(n, 9)
+        squares = torch.empty((n * 64, 64, 64), dtype=torch.uint8, device=self.device)
+        boards = torch.empty((n, 512, 512), dtype=torch.uint8, device=self.device) if want_boards else None
+        _check(self._lib.cv_extract_squares_u8(self._h, _ptr(images), n, h, w,
+                                               inv.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), _ptr(squares),
+                                               _ptr(boards) if want_boards else None, _stream_ptr(self.device)))
+        return squares, boards
 
     # -- introspection ----------------------------------------------------------------------------
     def activation(self, model: str, name: str) -> np.ndarray:

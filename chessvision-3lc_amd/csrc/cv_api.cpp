@@ -9,6 +9,13 @@
 #include "models.h"
 #include "pointwise.h"
 
+namespace cv {
+bool find_quadrangle(const uint8_t* mask, int h, int w, int32_t quad[8]);
+hipError_t resize_area_u8(const uint8_t* src, int n, int h, int w, int c, uint8_t* dst, int oh, int ow, hipStream_t s);
+hipError_t extract_squares_u8(const uint8_t* images, int n, int h, int w, const double* inv, uint8_t* squares,
+                              uint8_t* boards, hipStream_t s);
+}  // namespace cv
+
 using namespace cv;
 
 struct cv_engine {
@@ -340,6 +347,44 @@ int cv_op_maxpool3x3s2(cv_engine_t* eng, const float* x, int n, int c, int h, in
 }
 int cv_op_upsample_bilinear2x(cv_engine_t* eng, const float* x, int n, int c, int h, int w_, float* y, void* stream) {
     return pool_like(eng, x, n, c, h, w_, 2 * h, 2 * w_, y, stream, upsample_bilinear2x, "cv_op_upsample_bilinear2x");
+}
+
+// ---- classical stages either side of the CNNs -----------------------------------------
+int cv_find_quadrangle(const uint8_t* mask, int h, int w, int32_t quad[8], int* found) {
+    if (!mask || !quad || !found || h <= 0 || w <= 0) return finish(fail(CV_ERR_INVALID, "cv_find_quadrangle: bad argument"));
+    *found = find_quadrangle(mask, h, w, quad) ? 1 : 0;
+    return CV_OK;
+}
+
+int cv_resize_area_u8(cv_engine_t* eng, const uint8_t* src, int n, int h, int w_, int channels, uint8_t* dst, int out_h,
+                      int out_w, void* stream) {
+    Status s = check_engine(eng);
+    if (!s.ok()) return finish(s);
+    if (!src || !dst || n <= 0 || h <= 0 || w_ <= 0 || channels <= 0 || out_h <= 0 || out_w <= 0)
+        return finish(fail(CV_ERR_INVALID, "cv_resize_area_u8: bad argument"));
+    DeviceGuard g(eng->impl.device);
+    hipError_t e = resize_area_u8(src, n, h, w_, channels, dst, out_h, out_w, (hipStream_t)stream);
+    if (e != hipSuccess) return finish(hip_fail(e, "resize_area_u8"));
+    return CV_OK;
+}
+
+int cv_extract_squares_u8(cv_engine_t* eng, const uint8_t* images, int n, int h, int w_, const double* inv_host,
+                          uint8_t* squares, uint8_t* boards, void* stream) {
+    Status s = check_engine(eng);
+    if (!s.ok()) return finish(s);
+    if (!images || !inv_host || !squares || n <= 0 || h <= 0 || w_ <= 0)
+        return finish(fail(CV_ERR_INVALID, "cv_extract_squares_u8: bad argument"));
+    std::lock_guard<std::mutex> lk(eng->impl.mu);
+    DeviceGuard g(eng->impl.device);
+    Engine& e = eng->impl;
+    const size_t bytes = (size_t)n * 9 * sizeof(double);
+    if (e.scratch.bytes < bytes) { s = e.scratch.alloc(bytes, false); if (!s.ok()) return finish(s); }
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t err = hipMemcpyAsync(e.scratch.ptr, inv_host, bytes, hipMemcpyHostToDevice, st);
+    if (err == hipSuccess) err = extract_squares_u8(images, n, h, w_, (const double*)e.scratch.ptr, squares, boards, st);
+    if (err == hipSuccess) err = hipStreamSynchronize(st);       // inv_host may be reused by the caller; scratch by the next call
+    if (err != hipSuccess) return finish(hip_fail(err, "extract_squares_u8"));
+    return CV_OK;
 }
 
 int cv_selftest_mfma(cv_engine_t* eng, float* max_err_f16, float* max_err_f32) {

@@ -115,6 +115,8 @@ class Engine {
     std::unique_ptr<UNet> unet;
     std::unique_ptr<ResNet> resnet;
 
+    DeviceBuffer scratch;                               // small per-call parameter blocks (homographies)
+
     // profiling (cv_profile_convs)
     bool profiling = false;
     std::vector<ProfileEntry> prof;

@@ -149,6 +149,27 @@ int cv_op_maxpool3x3s2(cv_engine_t* eng, const float* x, int n, int c, int h, in
 int cv_op_upsample_bilinear2x(cv_engine_t* eng, const float* x, int n, int c, int h, int w_, float* y,
                               void* stream);
 
+/* ---- classical stages either side of the CNNs (SURVEY.md section 8f "next" rows) ------------------------------ */
+/* Binary mask (h*w uint8, 0 / non-0) -> board quadrangle, host-side C++: contours (outer + holes), the reference's
+ * area / bounding-box filter when more than one contour, closed-curve Douglas-Peucker at 10 % of the perimeter, first
+ * 4-vertex result, reference vertex rotation.  Replaces ChessVision._find_quadrangle (core.py:357-411: cv2.findContours,
+ * contourArea, boundingRect, arcLength, approxPolyDP).  quad = 4 x (x, y) in mask pixels; *found = 0 when none.
+ * Needs no GPU and no engine. */
+int cv_find_quadrangle(const uint8_t* mask, int h, int w, int32_t quad[8], int* found);
+
+/* (n,h,w,channels) uint8 -> (n,out_h,out_w,channels) uint8, INTER_AREA semantics (cv2.resize at core.py:212): exact
+ * box mean with round-half-up for integer shrink factors, coverage-weighted mean otherwise.  DEVICE pointers. */
+int cv_resize_area_u8(cv_engine_t* eng, const uint8_t* src, int n, int h, int w, int channels, uint8_t* dst,
+                      int out_h, int out_w, void* stream);
+
+/* Per board: perspective warp to 512x512 (bilinear, zero border) + BGR->gray + horizontal flip + split into 64 squares
+ * (utils.py:131-132, core.py:298-300, 419-439), fused.  images: DEVICE (n,h,w,3) uint8 BGR; inv_host: HOST n x 9
+ * doubles = inverse of the getPerspectiveTransform matrix (board pixel -> source pixel); squares: DEVICE (n*64,64,64)
+ * uint8 in a8..h1 order = the input of cv_resnet18_forward_u8; boards (nullable): DEVICE (n,512,512) uint8 gray board.
+ * Synchronises `stream` before returning. */
+int cv_extract_squares_u8(cv_engine_t* eng, const uint8_t* images, int n, int h, int w, const double* inv_host,
+                          uint8_t* squares, uint8_t* boards, void* stream);
+
 /* MFMA lane-map self test: computes D = A(16xK) * B(Kx16) with the kernels' fragment loaders for both
  * precisions and returns the max abs error against a host reference (used by tests; 0 expected). */
 int cv_selftest_mfma(cv_engine_t* eng, float* max_err_f16, float* max_err_f32);
