@@ -168,8 +168,8 @@ class ChessVision:
         return self.process_position_probabilities(probabilities=probabilities_np, square_names=square_names,
                                                    square_crops=squares)
 
-    def process_images(self, images: Sequence[NDArray[np.uint8]], threshold: float = 0.5,
-                       flip: bool = False) -> list[ChessVisionResult]:
+    def process_images(self, images: Sequence[NDArray[np.uint8]], threshold: float = 0.5, flip: bool = False,
+                       fallback_quad: bool = False) -> list[ChessVisionResult]:
         """Batched pipeline (new; the reference processes one image per call).  Images stay on the device between
         the two CNNs: INTER_AREA resize -> UNet (u8 in, logits + thresholded mask out) run per group of equally
         sized images; only the 64 KB masks come back for the C++ contour stage; the quadrangles go back as 3x3 maps
@@ -202,6 +202,8 @@ class ChessVision:
         quads: list[NDArray[np.float32] | None] = []
         for i in range(n):
             q = find_quadrangle(masks[i])
+            if q is None and fallback_quad:
+                q = np.array([[[255, 0]], [[0, 0]], [[0, 255]], [[255, 255]]], dtype=np.int32)   # TR, TL, BL, BR
             quads.append(None if q is None else self._scale_quadrangle(q, (images[i].shape[0], images[i].shape[1])))
         found = [i for i in range(n) if quads[i] is not None]
         boards: dict[int, NDArray[np.uint8]] = {}
