@@ -181,7 +181,7 @@ class ChessVision:
         if not images:
             return []
         _ = self.board_extractor, self.classifier
-        from .hip_backend import find_quadrangle
+        from .hip_backend import find_quadrangles
 
         eng = self._get_engine()
         n = len(images)
@@ -200,8 +200,7 @@ class ChessVision:
             for k, i in enumerate(ids):
                 device_images[i] = batch[k]
         quads: list[NDArray[np.float32] | None] = []
-        for i in range(n):
-            q = find_quadrangle(masks[i])
+        for i, q in enumerate(find_quadrangles(masks)):
             if q is None and fallback_quad:
                 q = np.array([[[255, 0]], [[0, 0]], [[0, 255]], [[255, 255]]], dtype=np.int32)   # TR, TL, BL, BR
             quads.append(None if q is None else self._scale_quadrangle(q, (images[i].shape[0], images[i].shape[1])))

@@ -77,6 +77,7 @@ SYMBOLS = [
     ("cv_op_upsample_bilinear2x", _i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     ("cv_selftest_mfma", _i, [_vp, ctypes.POINTER(_f), ctypes.POINTER(_f)]),
     ("cv_find_quadrangle", _i, [_vp, _i, _i, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(_i)]),
+    ("cv_find_quadrangles", _i, [_vp, _i, _i, _i, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), _i]),
     ("cv_resize_area_u8", _i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     ("cv_extract_squares_u8", _i, [_vp, _vp, _i, _i, _i, ctypes.POINTER(ctypes.c_double), _vp, _vp, _vp]),
 ]
@@ -153,6 +154,22 @@ def find_quadrangle(mask: np.ndarray):
     if not found.value:
         return None
     return np.array(list(quad), dtype=np.int32).reshape(4, 1, 2)
+
+
+def find_quadrangles(masks: np.ndarray, n_threads: int = 0) -> list:
+    """(N,H,W) uint8 masks -> list of (4,1,2) int32 quadrangles / None, on native host threads (GIL released)."""
+    lib = load_library()
+    m = np.ascontiguousarray(masks, dtype=np.uint8)
+    if m.ndim != 3:
+        raise HipBackendError("find_quadrangles expects (N,H,W) uint8 masks")
+    n = m.shape[0]
+    quads = np.zeros((n, 8), dtype=np.int32)
+    found = np.zeros(n, dtype=np.int32)
+    if n:
+        _check(lib.cv_find_quadrangles(m.ctypes.data_as(_vp), n, m.shape[1], m.shape[2],
+                                       quads.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                                       found.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), int(n_threads)))
+    return [quads[i].reshape(4, 1, 2).copy() if found[i] else None for i in range(n)]
 
 
 class HipEngine:

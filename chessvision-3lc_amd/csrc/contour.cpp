@@ -60,11 +60,13 @@ Contour trace_border(const Image& f, int si, int sj, int pi, int pj) {
     return pts;
 }
 
+struct Comp { int y, x; int bw, bh; };             // first raster pixel and bounding-box extent of a component
+
 // connected components by flood fill; returns the first raster pixel of every component (label order = raster order)
-std::vector<std::pair<int, int>> component_starts(const std::vector<uint8_t>& on, int h, int w, bool eight,
-                                                  bool skip_frame_touching) {
+std::vector<Comp> component_starts(const std::vector<uint8_t>& on, int h, int w, bool eight,
+                                   bool skip_frame_touching) {
     std::vector<int> lab((size_t)h * w, 0);
-    std::vector<std::pair<int, int>> starts;
+    std::vector<Comp> starts;
     std::vector<int> stack;
     int next = 0;
     for (int y = 0; y < h; ++y)
@@ -72,6 +74,7 @@ std::vector<std::pair<int, int>> component_starts(const std::vector<uint8_t>& on
             if (!on[(size_t)y * w + x] || lab[(size_t)y * w + x]) continue;
             ++next;
             bool touches = false;
+            int x0 = x, x1 = x, y0 = y, y1 = y;
             stack.clear();
             stack.push_back(y * w + x);
             lab[(size_t)y * w + x] = next;
@@ -79,6 +82,7 @@ std::vector<std::pair<int, int>> component_starts(const std::vector<uint8_t>& on
                 const int p = stack.back(); stack.pop_back();
                 const int cy = p / w, cx = p % w;
                 if (cy == 0 || cx == 0 || cy == h - 1 || cx == w - 1) touches = true;
+                x0 = std::min(x0, cx); x1 = std::max(x1, cx); y0 = std::min(y0, cy); y1 = std::max(y1, cy);
                 for (int k = 0; k < 8; ++k) {
                     if (!eight && (k & 1)) continue;                    // odd entries are the diagonals
                     const int ny = cy + kDy[k], nx = cx + kDx[k];
@@ -87,18 +91,28 @@ std::vector<std::pair<int, int>> component_starts(const std::vector<uint8_t>& on
                     if (on[q] && !lab[q]) { lab[q] = next; stack.push_back((int)q); }
                 }
             }
-            if (!(skip_frame_touching && touches)) starts.push_back({y, x});
+            if (!(skip_frame_touching && touches)) starts.push_back({y, x, x1 - x0 + 1, y1 - y0 + 1});
         }
     return starts;
 }
 
-std::vector<Contour> find_contours(const uint8_t* mask, int h, int w) {
+// All borders (outer, then holes).  `*total` receives the number of contours the image has; when it exceeds one the
+// reference filters by area share >= 0.35, and since a border polygon's area is below its bounding-box area, borders
+// whose box is smaller than that can never pass: they are counted but not traced (noisy masks have thousands).
+std::vector<Contour> find_contours(const uint8_t* mask, int h, int w, size_t* total) {
     const Image f{mask, h, w};
     std::vector<uint8_t> fg((size_t)h * w), bg((size_t)h * w);
     for (size_t i = 0; i < fg.size(); ++i) { fg[i] = mask[i] != 0; bg[i] = !fg[i]; }
+    const std::vector<Comp> outer = component_starts(fg, h, w, true, false);
+    const std::vector<Comp> holes = component_starts(bg, h, w, false, true);
+    *total = outer.size() + holes.size();
+    const bool prune = *total > 1;
+    const double need = 0.35 * (double)h * w;
     std::vector<Contour> out;
-    for (auto& s : component_starts(fg, h, w, true, false)) out.push_back(trace_border(f, s.first, s.second, s.first, s.second - 1));
-    for (auto& s : component_starts(bg, h, w, false, true)) out.push_back(trace_border(f, s.first, s.second - 1, s.first, s.second));
+    for (auto& s : outer)
+        if (!prune || (double)s.bw * s.bh >= need) out.push_back(trace_border(f, s.y, s.x, s.y, s.x - 1));
+    for (auto& s : holes)       // a hole border runs on the foreground pixels around the hole: box is 2 wider/taller
+        if (!prune || (double)(s.bw + 2) * (s.bh + 2) >= need) out.push_back(trace_border(f, s.y, s.x - 1, s.y, s.x));
     return out;
 }
 
@@ -181,8 +195,9 @@ Contour approx_poly_dp(const Contour& src, double epsilon) {
 
 // quad: 4 x (x, y) in mask pixels after the reference's rotation rule; returns true when a quadrangle was found
 bool find_quadrangle(const uint8_t* mask, int h, int w, int32_t quad[8]) {
-    std::vector<Contour> contours = find_contours(mask, h, w);
-    if (contours.size() > 1) {                         // reference core.py:362-366, 381-404
+    size_t total = 0;
+    std::vector<Contour> contours = find_contours(mask, h, w, &total);
+    if (total > 1) {                                   // reference core.py:362-366, 381-404
         std::vector<Contour> kept;
         const double area = (double)h * w;
         for (auto& c : contours) {

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <thread>
 
 #include "engine.h"
 #include "models.h"
@@ -353,6 +354,21 @@ int cv_op_upsample_bilinear2x(cv_engine_t* eng, const float* x, int n, int c, in
 int cv_find_quadrangle(const uint8_t* mask, int h, int w, int32_t quad[8], int* found) {
     if (!mask || !quad || !found || h <= 0 || w <= 0) return finish(fail(CV_ERR_INVALID, "cv_find_quadrangle: bad argument"));
     *found = find_quadrangle(mask, h, w, quad) ? 1 : 0;
+    return CV_OK;
+}
+
+int cv_find_quadrangles(const uint8_t* masks, int n, int h, int w, int32_t* quads, int32_t* found, int n_threads) {
+    if (!masks || !quads || !found || n < 0 || h <= 0 || w <= 0) return finish(fail(CV_ERR_INVALID, "cv_find_quadrangles: bad argument"));
+    int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    nt = std::max(1, std::min(nt, std::min(n, 32)));
+    auto work = [&](int t) {
+        for (int i = t; i < n; i += nt)
+            found[i] = find_quadrangle(masks + (size_t)i * h * w, h, w, quads + (size_t)i * 8) ? 1 : 0;
+    };
+    if (nt == 1) { work(0); return CV_OK; }
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nt; ++t) pool.emplace_back(work, t);
+    for (auto& th : pool) th.join();
     return CV_OK;
 }
 

@@ -156,6 +156,9 @@ int cv_op_upsample_bilinear2x(cv_engine_t* eng, const float* x, int n, int c, in
  * contourArea, boundingRect, arcLength, approxPolyDP).  quad = 4 x (x, y) in mask pixels; *found = 0 when none.
  * Needs no GPU and no engine. */
 int cv_find_quadrangle(const uint8_t* mask, int h, int w, int32_t quad[8], int* found);
+/* The same for n masks (n,h,w) on n_threads host threads (0 = hardware concurrency, capped at 32);
+ * quads: n x 8 int32, found: n x int32. */
+int cv_find_quadrangles(const uint8_t* masks, int n, int h, int w, int32_t* quads, int32_t* found, int n_threads);
 
 /* (n,h,w,channels) uint8 -> (n,out_h,out_w,channels) uint8, INTER_AREA semantics (cv2.resize at core.py:212): exact
  * box mean with round-half-up for integer shrink factors, coverage-weighted mean otherwise.  DEVICE pointers. */

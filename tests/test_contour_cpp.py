@@ -76,6 +76,18 @@ def test_random_masks_agree_with_numpy_restatement(find_quadrangle):
     assert found >= 20
 
 
+def test_batched_threads_equal_single(find_quadrangle):
+    from chessvision.hip_backend import find_quadrangles
+
+    rng = np.random.default_rng(9)
+    masks = np.stack([_polygon_mask(rng) for _ in range(24)] + [np.where(rng.random((256, 256)) < 0.5, 255, 0).astype(np.uint8)])
+    many = find_quadrangles(masks, n_threads=4)
+    for m, q in zip(masks, many):
+        assert _same(q, find_quadrangle(m))
+    assert _same(many[-1], ChessVision._find_quadrangle(masks[-1]))      # pure noise: thousands of specks
+    assert find_quadrangles(np.zeros((0, 8, 8), np.uint8)) == []
+
+
 def test_degenerate_masks(find_quadrangle):
     assert find_quadrangle(np.zeros((256, 256), np.uint8)) is None
     full = np.full((64, 64), 255, np.uint8)
