@@ -277,27 +277,45 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvParams p)
     }
     T* const ybase = reinterpret_cast<T*>(p.y);
     const T* const rbase = reinterpret_cast<const T*>(p.res);
+    float hw[NV];
+    if (p.head_w) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) hw[i] = p.head_w[row0 + i];
+    }
 #pragma unroll
     for (int g = 0; g < FP; ++g) {
         const int pix = ptTile * PT + wpi * WPT + g * 16 + l15;
-        if (pix < p.M && row0 < p.rows) {
-            const int n = pix / HoWo;
-            const int rem = pix - n * HoWo;
-            const int oy = rem / p.Wo;
-            const int ox = rem - oy * p.Wo;
-            const size_t opix = p.shuffle
-                ? (size_t)(n * p.yHp + 2 * oy + dy + 1) * p.yWp + (2 * ox + dx + 1)
-                : (size_t)(n * p.yHp + oy + 1) * p.yWp + (ox + 1);
-            float v[NV];
+        const bool live = pix < p.M && row0 < p.rows;
+        const int cp = pix < p.M ? pix : p.M - 1;
+        const int n = cp / HoWo;
+        const int rem = cp - n * HoWo;
+        const int oy = rem / p.Wo;
+        const int ox = rem - oy * p.Wo;
+        const size_t opix = p.shuffle
+            ? (size_t)(n * p.yHp + 2 * oy + dy + 1) * p.yWp + (2 * ox + dx + 1)
+            : (size_t)(n * p.yHp + oy + 1) * p.yWp + (ox + 1);
+        float v[NV];
 #pragma unroll
-            for (int f = 0; f < FC; ++f)
+        for (int f = 0; f < FC; ++f)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[f * 4 + r] = acc[f][g][r] * sc[f * 4 + r] + sh[f * 4 + r];
-            if (rbase) OutVec<T, NV>::add(rbase + opix * p.rCs + p.rCoff + co0, p.rCoff + co0, v);
-            if (p.relu) {
+            for (int r = 0; r < 4; ++r) v[f * 4 + r] = acc[f][g][r] * sc[f * 4 + r] + sh[f * 4 + r];
+        if (rbase && live) OutVec<T, NV>::add(rbase + opix * p.rCs + p.rCoff + co0, p.rCoff + co0, v);
+        if (p.relu) {
 #pragma unroll
-                for (int i = 0; i < NV; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+            for (int i = 0; i < NV; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+        }
+        if (p.head_w) {                                  // fused OutConv: 4 lanes (q = 0..3) hold the pixel's 64 channels
+            float part = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) part = __builtin_fmaf(v[i], hw[i], part);
+            part += __shfl_xor(part, 16);
+            part += __shfl_xor(part, 32);
+            if (live && q == 0) {
+                const float l = part + p.head_b[0];
+                p.head_logits[pix] = l;
+                if (p.head_mask) p.head_mask[pix] = (1.f / (1.f + __expf(-l))) > p.head_thr ? 255 : 0;
             }
+        } else if (live) {
             OutVec<T, NV>::store(ybase + opix * p.yCs + p.yCoff + co0, p.yCoff + co0, v);
         }
     }

@@ -63,6 +63,14 @@ struct ConvParams {
     int nCt;                  // channel tiles
     int relu;
     int shuffle;              // 1: rows = (dy,dx,co) of a k2 s2 transposed conv -> pixel-shuffle store
+    // optional fused 1x1 head (UNet OutConv, Cout == 64 == one channel tile): logit = sum_c relu(bn(conv))[c] * head_w[c]
+    // + head_b is written to head_logits[pixel] (f32, (N,1,H,W)) INSTEAD of the activation tensor; head_mask (nullable)
+    // receives sigmoid(logit) > head_thr ? 255 : 0.
+    const float* head_w;
+    const float* head_b;
+    float* head_logits;
+    uint8_t* head_mask;
+    float head_thr;
 };
 
 }  // namespace cv

@@ -217,7 +217,7 @@ static int env_cached(int idx) {                      // 0: CV_CONV_W8, 1: CV_CO
 int choose_ct(int rows) { return rows % 128 == 0 ? 128 : 64; }
 
 // per-launch tile choice among the configurations that share the layer's channel tile
-int choose_cfg(int rows, int64_t pixels) {
+int choose_cfg(int rows, int64_t pixels, int n_stages) {
     const bool wide = choose_ct(rows) == 128;
     const int w8 = env_cached(0), force_pt = env_cached(1);
     if (force_pt == 128 || force_pt == 256)
@@ -225,6 +225,7 @@ int choose_cfg(int rows, int64_t pixels) {
     if (!wide) {
         if (w8 == 1) return kCfg64x512w8;
         if (w8 == 2) return kCfg64x256w8;
+        if (n_stages <= env_int("CV_SHORTK", 0)) return kCfg64x256;      // experiment: short-K layers, fewer/larger workgroups
         return kCfg64x128;
     }
     if (w8 != 0 && blocks_for(rows, pixels, 128, 256) >= 256) return kCfg128x256w8;
@@ -244,7 +245,7 @@ Engine::Engine() {}
 Engine::~Engine() { prof_clear(); }
 
 Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, const TensorRef* res, bool relu,
-                        hipStream_t s) {
+                        hipStream_t s, const Head* head) {
     if (x.C != L.cinPad) return fail(1, L.name + ": input slice has " + std::to_string(x.C) + " channels, layer packs " + std::to_string(L.cinPad));
     const int esz = dtype_size(dt);
     if (dt == kSplit && (x.Coff % 8 || y.Coff % 8 || (res && res->Coff % 8)))
@@ -278,7 +279,11 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
     p.xHp = x.H + 2; p.xWp = x.W + 2; p.stride = L.stride; p.xCs = x.Cs;
     p.yHp = y.H + 2; p.yWp = y.W + 2; p.yCs = y.Cs; p.yCoff = y.Coff;
     p.Cout = L.cout; p.rows = L.rows; p.nStages = L.nStages; p.nCt = L.nCt; p.relu = relu ? 1 : 0; p.shuffle = L.shuffle ? 1 : 0;
-    const int cfg = choose_cfg(L.rows, p.M);
+    if (head) {
+        if (L.rows != 64 || L.shuffle) return fail(1, L.name + ": the fused 1x1 head needs a 64-channel layer");
+        p.head_w = head->w; p.head_b = head->b; p.head_logits = head->logits; p.head_mask = head->mask; p.head_thr = head->thr;
+    }
+    const int cfg = choose_cfg(L.rows, p.M, L.nStages);
     const int ns = choose_ns(cfg, dt, L.rows, p.M);
     p.nCt = (L.rows + conv_cfg_ct(cfg) - 1) / conv_cfg_ct(cfg);
     if (profiling) prof_begin(L.name, true, (double)L.macs_per_out_pixel() * (double)p.M, s);

@@ -124,8 +124,9 @@ class Engine {
     Engine();
     ~Engine();
 
+    struct Head { const float* w; const float* b; float* logits; uint8_t* mask; float thr; };
     Status run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, const TensorRef* res, bool relu,
-                    hipStream_t s);
+                    hipStream_t s, const Head* head = nullptr);
     void prof_begin(const std::string& name, bool is_conv, double macs, hipStream_t s);
     void prof_end(hipStream_t s);
     Status prof_collect();
@@ -133,7 +134,7 @@ class Engine {
 };
 
 int choose_ct(int rows);
-int choose_cfg(int rows, int64_t pixels);
+int choose_cfg(int rows, int64_t pixels, int n_stages);
 int choose_ns(int cfg, int dt, int rows, int64_t pixels);
 
 Status unet_load(Engine& e, const ParamMap& pm);

@@ -6,6 +6,7 @@ namespace cv {
 
 struct Engine::UNet {
     bool bilinear = false;
+    bool fuse_head = true;                          // OutConv fused into up4's last conv epilogue
     int cap = 0;                                    // images per chunk
     int last_n = 0;                                 // images in the most recent chunk
     // channel plan

@@ -8,6 +8,7 @@
 // no-op at 256x256 and is not materialised; the batch is processed in chunks that keep every layer's grid
 // at >= one full wave of workgroups while bounding the live working set.
 #include <cmath>
+#include <cstdlib>
 
 #include "engine.h"
 #include "models.h"
@@ -66,6 +67,10 @@ Status unet_load(Engine& e, const ParamMap& pm) {
     Engine::UNet& U = *m;
     const int dt = e.dt;
     U.bilinear = pm.find("up1.up.weight") == pm.end();
+    {   // CV_FUSE_HEAD=0 keeps OutConv a separate kernel (then the up4 output tensor can be read back)
+        const char* v = std::getenv("CV_FUSE_HEAD");
+        U.fuse_head = !(v && v[0] == '0');
+    }
     U.cap = e.unet_chunk;
     const int S = U.cap;
     const int f = U.bilinear ? 2 : 1;
@@ -153,8 +158,10 @@ Status unet_load(Engine& e, const ParamMap& pm) {
         const std::string p = "up" + std::to_string(i + 1);
         U.taps[p + ".up"] = U.cat[lvl].ref(S, enc_c[lvl], U.cat[lvl].C - enc_c[lvl]);
         U.taps[p + ".conv.double_conv.2"] = U.umid[i].ref(S);
-        U.taps[p + ".conv.double_conv.5"] = U.uout[i].ref(S);
-        U.taps[p] = U.uout[i].ref(S);
+        if (!(i == 3 && U.fuse_head)) {                  // with the fused head the up4 output never reaches memory
+            U.taps[p + ".conv.double_conv.5"] = U.uout[i].ref(S);
+            U.taps[p] = U.uout[i].ref(S);
+        }
     }
 
     // algorithmic multiply-accumulates per image (conv / conv-transpose / outc), true channel counts
@@ -222,6 +229,13 @@ static Status unet_chunk(Engine& e, const void* x, bool x_u8, int n, float* logi
             CV_TRY(timed("upsample_bilinear2x", upsample_bilinear2x(dt, deep, up, s)));
         }
         CV_TRY(e.run_conv(U.u[i][0], U.cat[lvl].ref(n), U.umid[i].ref(n), nullptr, true, s));
+        if (i == 3 && U.fuse_head) {
+            // OutConv (1x1, 64 -> 1, + bias) and the sigmoid/threshold mask ride in the epilogue of the last 3x3 conv:
+            // the 64-channel full-resolution tensor is never written or re-read.
+            const Engine::Head head{(const float*)U.outc_w.ptr, (const float*)U.outc_b.ptr, logits, mask, thr};
+            CV_TRY(e.run_conv(U.u[i][1], U.umid[i].ref(n), U.uout[i].ref(n), nullptr, true, s, &head));
+            return Status();
+        }
         CV_TRY(e.run_conv(U.u[i][1], U.umid[i].ref(n), U.uout[i].ref(n), nullptr, true, s));
         deep = U.uout[i].ref(n);
     }
