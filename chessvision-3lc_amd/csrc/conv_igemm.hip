@@ -118,7 +118,10 @@ template <int N> struct OutVec<split_t, N> {
 // CT x PT = channel x pixel tile of the workgroup (NW waves as WGC x NW/WGC); every wave owns a 64-channel
 // slab (FC = 4 fragments: the row permutation the host packs for) and PT*WGC/NW pixels.  NW = 8 puts two waves
 // of one workgroup on every SIMD: while one is parked on the stage barrier / its LDS reads, the other issues MFMAs.
-template <typename T, int CT, int PT, int WGC, int NS, int NW>
+// SEP: every stage's 8 K chunks are one contiguous 128-byte line of a pixel (all layers with Cin a multiple of the
+// line), so the gather offset is kbase[stage] + 16 * chunk: the per-stage base comes through the scalar cache and no
+// LDS is spent on the offset table (lets two 80 KB workgroups share a CU).
+template <typename T, int CT, int PT, int WGC, int NS, int NW, bool SEP>
 __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvParams p) {
     constexpr int WGP = NW / WGC;
     constexpr int WCT = CT / WGC, WPT = PT / WGP;
@@ -147,7 +150,8 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvParams p)
     const int nS = p.nStages;
     const int HoWo = p.Ho * p.Wo;
 
-    for (int i = tid; i < nS * 8; i += 64 * NW) koffs[i] = p.koff[i];
+    if constexpr (!SEP)
+        for (int i = tid; i < nS * 8; i += 64 * NW) koffs[i] = p.koff[i];
 
     // DMA source of this lane's activation rows: row r of the pixel tile <-> output pixel ptTile*PT + r
     unsigned xoff[LX];
@@ -172,7 +176,15 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvParams p)
         const char* gw = wsrc + (size_t)s * (CT * 128);
 #pragma unroll
         for (int i = 0; i < LW; ++i) glds16(gw + i * (NW * 1024), sW + (i * NW + wave) * 1024);
-        const int ko = koffs[s * 8 + myChunk];
+        int ko;
+        if constexpr (SEP) {
+            // constant address space => s_load through the scalar cache (a VGPR load here would make the compiler
+            // drain vmcnt, i.e. the whole DMA ring, every stage)
+            typedef const __attribute__((address_space(4))) int* cptr_t;
+            ko = reinterpret_cast<cptr_t>(reinterpret_cast<uintptr_t>(p.kbase))[s] + myChunk * 16;
+        } else {
+            ko = koffs[s * 8 + myChunk];
+        }
 #pragma unroll
         for (int i = 0; i < LX; ++i) glds16(p.x + xoff[i] + ko, sX + (i * NW + wave) * 1024);
     };
@@ -322,20 +334,22 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvParams p)
 }
 
 // ---- host-side launch -------------------------------------------------------------------------------
-template <typename T, int CT, int PT, int WGC, int NS, int NW>
+template <typename T, int CT, int PT, int WGC, int NS, int NW, bool SEP>
 static hipError_t launch_one(const ConvParams& p, hipStream_t stream) {
-    const size_t lds = (size_t)NS * (CT + PT) * 128 + (((size_t)p.nStages * 8 * 4 + 15) & ~(size_t)15);
+    const size_t lds = (size_t)NS * (CT + PT) * 128 + (SEP ? 0 : (((size_t)p.nStages * 8 * 4 + 15) & ~(size_t)15));
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const int nPt = (p.M + PT - 1) / PT;
-    auto kern = conv_igemm_kernel<T, CT, PT, WGC, NS, NW>;
+    auto kern = conv_igemm_kernel<T, CT, PT, WGC, NS, NW, SEP>;
     hipLaunchKernelGGL(kern, dim3((unsigned)(nPt * p.nCt)), dim3(64 * NW), lds, stream, p);
     return hipGetLastError();
 }
 
 template <typename T, int CT, int PT, int WGC, int NS, int NW>
 static hipError_t prepare_one() {
-    auto kern = conv_igemm_kernel<T, CT, PT, WGC, NS, NW>;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, CT, PT, WGC, NS, NW, false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, CT, PT, WGC, NS, NW, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -364,8 +378,9 @@ hipError_t conv_igemm_prepare() {
 }
 
 hipError_t conv_igemm_launch(int cfg, int ns, int dt, const ConvParams& p, hipStream_t stream) {
-#define X(T, CT, PT, WGC, NS, NW, ID) \
-    if (cfg == ID && ns == NS) return launch_one<T, CT, PT, WGC, NS, NW>(p, stream);
+#define X(T, CT, PT, WGC, NS, NW, ID)                                                        \
+    if (cfg == ID && ns == NS)                                                                \
+        return p.kbase ? launch_one<T, CT, PT, WGC, NS, NW, true>(p, stream) : launch_one<T, CT, PT, WGC, NS, NW, false>(p, stream);
     if (dt == kF16) { CV_FOR_EACH_CFG(X, half_t) } else if (dt == kSplit) { CV_FOR_EACH_CFG(X, split_t) } else { CV_FOR_EACH_CFG(X, float) }
 #undef X
     return hipErrorInvalidValue;

@@ -45,6 +45,7 @@ struct ConvParams {
     const char* x;            // input PHWC base
     const char* w;            // packed weights: [ctTile][stage][CT rows][8 x 16 B, XOR-swizzled]
     const int* koff;          // [nStages*8] byte offset of each 16-B K chunk relative to a pixel's base
+    const int* kbase;         // [nStages] or null: per-stage base when koff[s*8+c] == kbase[s] + 16*c for every stage
     const float* scale;       // [rows] epilogue scale  (BN gamma / sqrt(var + eps), or 1)
     const float* shift;       // [rows] epilogue shift  (BN beta - mean*scale, or conv bias)
     const char* res;          // optional residual PHWC base (same pixel grid as the output), or null

@@ -164,7 +164,7 @@ Status ConvLayer::build_convT(const std::string& name_, int dt_, const float* w_
 }
 
 // byte offset of every 16-B K chunk relative to the address of the pixel's top-left tap
-Status ConvLayer::get_koff(const TensorRef& x, const int** out) {
+Status ConvLayer::get_koff(const TensorRef& x, const int** chunks, const int** bases) {
     const KoffKey key{x.W + 2, x.Cs, x.Coff};
     auto it = koff.find(key);
     if (it == koff.end()) {
@@ -186,11 +186,19 @@ Status ConvLayer::get_koff(const TensorRef& x, const int** out) {
             }
             tab[kc] = (int)off;
         }
-        auto buf = std::make_unique<DeviceBuffer>();
-        CV_TRY(buf->upload(tab.data(), tab.size() * sizeof(int)));
-        it = koff.emplace(key, std::move(buf)).first;
+        auto kt = std::make_unique<KoffTab>();
+        CV_TRY(kt->chunks.upload(tab.data(), tab.size() * sizeof(int)));
+        std::vector<int> base((size_t)nStages);
+        kt->separable = true;
+        for (int s = 0; s < nStages; ++s) {
+            base[s] = tab[(size_t)s * 8];
+            for (int c = 0; c < 8; ++c) kt->separable = kt->separable && tab[(size_t)s * 8 + c] == base[s] + 16 * c;
+        }
+        if (kt->separable) CV_TRY(kt->bases.upload(base.data(), base.size() * sizeof(int)));
+        it = koff.emplace(key, std::move(kt)).first;
     }
-    *out = reinterpret_cast<const int*>(it->second->ptr);
+    *chunks = reinterpret_cast<const int*>(it->second->chunks.ptr);
+    *bases = it->second->separable ? reinterpret_cast<const int*>(it->second->bases.ptr) : nullptr;
     return Status();
 }
 
@@ -202,7 +210,8 @@ static int env_int(const char* name, int dflt) {
 // Tile / ring-depth choice, from the r01 sweeps on MI355X (profiles/r01_tuning.md):
 //   Cout % 128 == 0, >= 256 workgroups of 128x256 : 8-wave 128x256 tile, ring 3 (two waves per SIMD in ONE workgroup)
 //   Cout % 128 == 0, fewer pixels                 : 4-wave 128x128 tile; ring 3 at <= 1 workgroup per CU, else ring 2
-//   Cout == 64 (full-resolution UNet, ResNet layer1): 4-wave 64x128 tile, ring 3 (72 KB -> two workgroups per CU)
+//   Cout == 64 (full-resolution UNet, ResNet layer1): 4-wave 64x256 tile, ring 2, table-free offsets (80 KB -> two
+//                                                   workgroups per CU); 64x128 ring 3 for short K or few pixels
 // CV_CONV_W8 / CV_CONV_PT / CV_CONV_NS override for experiments.
 static int64_t blocks_for(int rows, int64_t pixels, int ct, int pt) {
     return ((pixels + pt - 1) / pt) * ((rows + ct - 1) / ct);
@@ -225,7 +234,7 @@ int choose_cfg(int rows, int64_t pixels, int n_stages) {
     if (!wide) {
         if (w8 == 1) return kCfg64x512w8;
         if (w8 == 2) return kCfg64x256w8;
-        if (n_stages <= env_int("CV_SHORTK", 0)) return kCfg64x256;      // experiment: short-K layers, fewer/larger workgroups
+        if (env_int("CV_N64", 1) == 1 && n_stages > 4 && blocks_for(rows, pixels, 64, 256) >= 512) return kCfg64x256;
         return kCfg64x128;
     }
     if (w8 != 0 && blocks_for(rows, pixels, 128, 256) >= 256) return kCfg128x256w8;
@@ -237,6 +246,7 @@ int choose_ns(int cfg, int dt, int rows, int64_t pixels) {
     const int forced = env_cached(2);
     if ((forced == 2 || forced == 3) && conv_cfg_has_ns(cfg, forced)) return forced;
     if (cfg == kCfg128x128) return blocks_for(rows, pixels, 128, 128) > 256 ? 2 : 3;
+    if (cfg == kCfg64x256) return 2;                    // 80 KB table-free -> two workgroups per CU
     return conv_cfg_has_ns(cfg, 3) ? 3 : 2;
 }
 
@@ -263,10 +273,12 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
     }
     if (y.C != L.cout || y.N != x.N) return fail(1, L.name + ": output slice mismatch");
     const int* koff = nullptr;
-    CV_TRY(L.get_koff(x, &koff));
+    const int* kbase = nullptr;
+    CV_TRY(L.get_koff(x, &koff, &kbase));
     p.x = reinterpret_cast<const char*>(x.base);
     p.w = reinterpret_cast<const char*>(L.w.ptr);
     p.koff = koff;
+    p.kbase = env_int("CV_CONV_SEP", 1) ? kbase : nullptr;
     p.scale = reinterpret_cast<const float*>(L.scale.ptr);
     p.shift = reinterpret_cast<const float*>(L.shift.ptr);
     p.res = nullptr;

@@ -82,7 +82,8 @@ struct ConvLayer {
     // koff tables are geometry dependent: keyed by (xWp, xCs, xCoff)
     struct KoffKey { int xWp, xCs, xCoff; bool operator<(const KoffKey& o) const {
         if (xWp != o.xWp) return xWp < o.xWp; if (xCs != o.xCs) return xCs < o.xCs; return xCoff < o.xCoff; } };
-    std::map<KoffKey, std::unique_ptr<DeviceBuffer>> koff;
+    struct KoffTab { DeviceBuffer chunks, bases; bool separable = false; };
+    std::map<KoffKey, std::unique_ptr<KoffTab>> koff;
 
     // w_oihw: (cout, cin, k, k); scale/shift: (cout)
     Status build_conv(const std::string& name_, int dt_, const float* w_oihw, int cout_, int cin_, int k_,
@@ -90,7 +91,7 @@ struct ConvLayer {
     // w_iohw: (cin, cout, 2, 2); bias: (cout)
     Status build_convT(const std::string& name_, int dt_, const float* w_iohw, int cin_, int cout_,
                        const float* bias);
-    Status get_koff(const TensorRef& x, const int** out);
+    Status get_koff(const TensorRef& x, const int** chunks, const int** bases);
     int64_t macs_per_out_pixel() const { return shuffle ? (int64_t)cin * cout * 4 : (int64_t)cin * k * k * cout; }
 };
 
