@@ -12,7 +12,7 @@ Deliberate deviations, all on the permissive side:
   * model ids ``""`` / ``"unet"`` / ``"hip"`` select the UNet, ``""`` / ``"resnet18"`` the ResNet-18
     (``evaluate.py:212,214`` passes ``""``); ``"yolo"`` raises ImportError -- that model family is out of scope.
   * lazy initialisation is guarded by a lock (Flask request threads share one instance, ``cv_endpoint.py:131-133``).
-  * extras: ``precision=`` kwarg (env ``CHESSVISION_HIP_PRECISION``, default "f32"), ``process_images`` (batched),
+  * extras: ``precision=`` kwarg (env ``CHESSVISION_HIP_PRECISION``: "f16x3" (default) | "f32" | "f16"), ``process_images`` (batched),
     ``predict`` alias.
 """
 from __future__ import annotations
@@ -57,7 +57,7 @@ class ChessVision:
         self._board_extractor_model_id = board_extractor_model_id
         self._classifier_weights = classifier_weights
         self._classifier_model_id = classifier_model_id
-        self._precision = precision or os.environ.get("CHESSVISION_HIP_PRECISION", "f32")
+        self._precision = precision or os.environ.get("CHESSVISION_HIP_PRECISION", "f16x3")
         self._engine = None
         self._init_lock = threading.RLock()
         if not lazy_load:
