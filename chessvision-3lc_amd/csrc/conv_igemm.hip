@@ -289,47 +289,98 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvParams p)
     }
     T* const ybase = reinterpret_cast<T*>(p.y);
     const T* const rbase = reinterpret_cast<const T*>(p.res);
-    float hw[NV];
+
     if (p.head_w) {
+        // fused OutConv (UNet outc): 4 lanes (q = 0..3) hold a pixel's 64 channels; nothing is stored but the logit
+        float hw[NV];
 #pragma unroll
         for (int i = 0; i < NV; ++i) hw[i] = p.head_w[row0 + i];
+#pragma unroll
+        for (int g = 0; g < FP; ++g) {
+            const int pix = ptTile * PT + wpi * WPT + g * 16 + l15;
+            float part = 0.f;
+#pragma unroll
+            for (int f = 0; f < FC; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[f][g][r] * sc[f * 4 + r] + sh[f * 4 + r];
+                    v = (p.relu && v < 0.f) ? 0.f : v;
+                    part = __builtin_fmaf(v, hw[f * 4 + r], part);
+                }
+            part += __shfl_xor(part, 16);
+            part += __shfl_xor(part, 32);
+            if (pix < p.M && q == 0) {
+                const float l = part + p.head_b[0];
+                p.head_logits[pix] = l;
+                if (p.head_mask) p.head_mask[pix] = (1.f / (1.f + __expf(-l))) > p.head_thr ? 255 : 0;
+            }
+        }
+        return;
     }
+
+    // Staged store: the MFMA leaves each lane with 16 channels of one pixel, i.e. 64 scattered 16-byte pieces per
+    // store instruction.  Each wave instead parks one 16-pixel x 64-channel fragment (f32, rows padded to 272 B so
+    // the b128 writes spread over all banks) in its own corner of the now idle LDS ring and reads it back so that
+    // consecutive lanes hold consecutive bytes: a quarter-wave then writes (and reads the residual of) one pixel's
+    // whole channel slab as full 128-byte lines.  Wave-private staging: DS ops of a wave execute in order, so only
+    // compiler barriers separate the write and read phases.
+    constexpr int UN = __is_same(T, float) ? 4 : 8;     // channels per store unit (16 B; 32 B for split-f16)
+    constexpr int UPP = 64 / UN;                         // units per pixel of the wave's 64-channel slab
+    constexpr int UPL = 16 * UPP / 64;                   // units per lane per 16-pixel fragment
+    constexpr int SROW = 272;
+    static_assert(NW * 16 * SROW <= NS * STAGE, "staging must fit in the ring");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave is done reading the ring
+    char* const stg = smem + wave * (16 * SROW);
+    const int slab0 = ctTile * CT + wci * WCT;
+    (void)co0; (void)dy; (void)dx;
 #pragma unroll
     for (int g = 0; g < FP; ++g) {
         const int pix = ptTile * PT + wpi * WPT + g * 16 + l15;
-        const bool live = pix < p.M && row0 < p.rows;
         const int cp = pix < p.M ? pix : p.M - 1;
         const int n = cp / HoWo;
         const int rem = cp - n * HoWo;
         const int oy = rem / p.Wo;
         const int ox = rem - oy * p.Wo;
-        const size_t opix = p.shuffle
-            ? (size_t)(n * p.yHp + 2 * oy + dy + 1) * p.yWp + (2 * ox + dx + 1)
-            : (size_t)(n * p.yHp + oy + 1) * p.yWp + (ox + 1);
-        float v[NV];
+        const unsigned obase = p.shuffle ? (unsigned)((n * p.yHp + 2 * oy + 1) * p.yWp + 2 * ox + 1)
+                                         : (unsigned)((n * p.yHp + oy + 1) * p.yWp + ox + 1);
+        const int plive = pix < p.M ? 1 : 0;
 #pragma unroll
-        for (int f = 0; f < FC; ++f)
+        for (int f = 0; f < FC; ++f) {
+            f4 t;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[f * 4 + r] = acc[f][g][r] * sc[f * 4 + r] + sh[f * 4 + r];
-        if (rbase && live) OutVec<T, NV>::add(rbase + opix * p.rCs + p.rCoff + co0, p.rCoff + co0, v);
-        if (p.relu) {
-#pragma unroll
-            for (int i = 0; i < NV; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+            for (int r = 0; r < 4; ++r) t[r] = acc[f][g][r] * sc[f * 4 + r] + sh[f * 4 + r];
+            *reinterpret_cast<f4*>(stg + l15 * SROW + (q * NV + f * 4) * 4) = t;
         }
-        if (p.head_w) {                                  // fused OutConv: 4 lanes (q = 0..3) hold the pixel's 64 channels
-            float part = 0.f;
+        asm volatile("" ::: "memory");
 #pragma unroll
-            for (int i = 0; i < NV; ++i) part = __builtin_fmaf(v[i], hw[i], part);
-            part += __shfl_xor(part, 16);
-            part += __shfl_xor(part, 32);
-            if (live && q == 0) {
-                const float l = part + p.head_b[0];
-                p.head_logits[pix] = l;
-                if (p.head_mask) p.head_mask[pix] = (1.f / (1.f + __expf(-l))) > p.head_thr ? 255 : 0;
+        for (int i = 0; i < UPL; ++i) {
+            const int unit = lane + 64 * i;
+            const int px = unit / UPP, cu = unit % UPP;
+            float w[UN];
+#pragma unroll
+            for (int j = 0; j < UN; j += 4) {
+                const f4 t = *reinterpret_cast<const f4*>(stg + px * SROW + (cu * UN + j) * 4);
+                w[j] = t[0]; w[j + 1] = t[1]; w[j + 2] = t[2]; w[j + 3] = t[3];
             }
-        } else if (live) {
-            OutVec<T, NV>::store(ybase + opix * p.yCs + p.yCoff + co0, p.yCoff + co0, v);
+            unsigned ob = __shfl(obase, px);
+            const int lv = __shfl(plive, px);
+            const int row = slab0 + cu * UN;
+            int co = row;
+            if (p.shuffle) {                             // rows are (dy, dx, co): k2 s2 transposed conv
+                const int grp = row / p.Cout;
+                co = row - grp * p.Cout;
+                ob += (unsigned)((grp >> 1) * p.yWp + (grp & 1));
+            }
+            if (lv && row < p.rows) {
+                if (rbase) OutVec<T, UN>::add(rbase + (size_t)ob * p.rCs + p.rCoff + co, p.rCoff + co, w);
+                if (p.relu) {
+#pragma unroll
+                    for (int j = 0; j < UN; ++j) w[j] = w[j] > 0.f ? w[j] : 0.f;
+                }
+                OutVec<T, UN>::store(ybase + (size_t)ob * p.yCs + p.yCoff + co, p.yCoff + co, w);
+            }
         }
+        asm volatile("" ::: "memory");
     }
 }
 
