@@ -22,7 +22,18 @@
 #include "cv_kernels.h"
 #include "conv_igemm.h"
 
+#include <type_traits>
+
 namespace cv {
+
+#ifndef CV_SETPRIO
+#define CV_SETPRIO 1
+#endif
+constexpr bool kSetPrio = CV_SETPRIO != 0;
+#ifndef CV_STAGGER
+#define CV_STAGGER 0      // measured r01: -3 % with the late-wave schedule on (same-box A/B), kept as a build option
+#endif
+constexpr bool kStagger = CV_STAGGER != 0;
 
 template <typename T> struct FragT;
 template <> struct FragT<half_t> { typedef half8 V; };
@@ -201,72 +212,106 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvParams p)
 #pragma unroll
         for (int g = 0; g < FP; ++g) acc[f][g] = f4{0.f, 0.f, 0.f, 0.f};
 
-    auto compute = [&](int buf) {
+    constexpr bool kSplit16 = sizeof(T) == 4 && !__is_same(T, float);
+    // Stagger (8-wave split-f16 tiles): the two waves sharing a SIMD would otherwise run in lockstep -- both reading
+    // LDS, then both queueing on the matrix pipe.  Waves 4-7 ("late") defer the 32 cross-term MFMAs of every stage
+    // to the start of the next one (operands stay in registers across the barrier), so they occupy the matrix pipe
+    // exactly while waves 0-3 issue their DMA and fragment reads, and read their own fragments while waves 0-3
+    // compute.  Same products, same accumulation targets; only the order of additions into an accumulator differs.
+    const bool late = kSplit16 && NW == 8 && kStagger && wave >= 4;
+
+    // split-f16 fragment state (persists across iterations for the late waves)
+    V ah[FC], al[FC], bh[FP], bl[FP];
+    const int chi = 2 * q + (q & 1), clo = 2 * q + 1 - (q & 1);   // lane group q: hi chunk / lo chunk of K-group q
+    const int swh = (chi ^ (lane & 7)) * 16, swl = (clo ^ (lane & 7)) * 16;
+    auto load_split = [&](int buf) {
         const char* s = smem + buf * STAGE;
-        if constexpr (sizeof(T) == 4 && !__is_same(T, float)) {
-            // split-f16: one 32-deep k-step per stage.  Lane group q owns K-group q of the stage: its hi chunk sits
-            // at logical chunk 2q + (q&1), its lo chunk at 2q + 1 - (q&1) (alternating LDS bank halves).
-            const int chi = 2 * q + (q & 1), clo = 2 * q + 1 - (q & 1);
-            const int swh = (chi ^ (lane & 7)) * 16, swl = (clo ^ (lane & 7)) * 16;
-            V ah[FC], al[FC], bh[FP], bl[FP];
 #pragma unroll
-            for (int f = 0; f < FC; ++f) ah[f] = *reinterpret_cast<const V*>(s + rowW + f * 2048 + swh);
+        for (int f = 0; f < FC; ++f) ah[f] = *reinterpret_cast<const V*>(s + rowW + f * 2048 + swh);
 #pragma unroll
-            for (int g = 0; g < FP; ++g) bh[g] = *reinterpret_cast<const V*>(s + rowX + g * 2048 + swh);
+        for (int g = 0; g < FP; ++g) bh[g] = *reinterpret_cast<const V*>(s + rowX + g * 2048 + swh);
 #pragma unroll
-            for (int f = 0; f < FC; ++f) al[f] = *reinterpret_cast<const V*>(s + rowW + f * 2048 + swl);
+        for (int f = 0; f < FC; ++f) al[f] = *reinterpret_cast<const V*>(s + rowW + f * 2048 + swl);
 #pragma unroll
-            for (int g = 0; g < FP; ++g) bl[g] = *reinterpret_cast<const V*>(s + rowX + g * 2048 + swl);
-            // leading products first: they only need the hi fragments, so the lo reads land under these MFMAs
+        for (int g = 0; g < FP; ++g) bl[g] = *reinterpret_cast<const V*>(s + rowX + g * 2048 + swl);
+    };
+    auto lead = [&]() {                                  // hi*hi: needs only the hi fragments
+        if (kSetPrio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int f = 0; f < FC; ++f)
+        for (int f = 0; f < FC; ++f)
 #pragma unroll
-                for (int g = 0; g < FP; ++g) mma16(acc[f][g], ah[f], bh[g]);
+            for (int g = 0; g < FP; ++g) mma16(acc[f][g], ah[f], bh[g]);
+        if (kSetPrio) __builtin_amdgcn_s_setprio(0);
+    };
+    auto cross = [&]() {                                 // lo*hi + hi*lo
+        if (kSetPrio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int f = 0; f < FC; ++f)
+        for (int f = 0; f < FC; ++f)
 #pragma unroll
-                for (int g = 0; g < FP; ++g) {
-                    mma16(acc[f][g], al[f], bh[g]);
-                    mma16(acc[f][g], ah[f], bl[g]);
-                }
-        } else {
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub) {
-                const int sw = sw0 ^ (sub * 64);
-                V a[FC], b[FP];
-#pragma unroll
-                for (int f = 0; f < FC; ++f) a[f] = *reinterpret_cast<const V*>(s + rowW + f * 2048 + sw);
-#pragma unroll
-                for (int g = 0; g < FP; ++g) b[g] = *reinterpret_cast<const V*>(s + rowX + g * 2048 + sw);
-#pragma unroll
-                for (int f = 0; f < FC; ++f)
-#pragma unroll
-                    for (int g = 0; g < FP; ++g) mma16(acc[f][g], a[f], b[g]);
+            for (int g = 0; g < FP; ++g) {
+                mma16(acc[f][g], al[f], bh[g]);
+                mma16(acc[f][g], ah[f], bl[g]);
             }
+        if (kSetPrio) __builtin_amdgcn_s_setprio(0);
+    };
+
+    auto compute_plain = [&](int buf) {                  // f16 / f32: two k-steps per stage
+        const char* s = smem + buf * STAGE;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int sw = sw0 ^ (sub * 64);
+            V a[FC], b[FP];
+#pragma unroll
+            for (int f = 0; f < FC; ++f) a[f] = *reinterpret_cast<const V*>(s + rowW + f * 2048 + sw);
+#pragma unroll
+            for (int g = 0; g < FP; ++g) b[g] = *reinterpret_cast<const V*>(s + rowX + g * 2048 + sw);
+#pragma unroll
+            for (int f = 0; f < FC; ++f)
+#pragma unroll
+                for (int g = 0; g < FP; ++g) mma16(acc[f][g], a[f], b[g]);
         }
     };
 
-    if constexpr (NS == 2) {
-        issue(0, 0);
-        int buf = 0;
-        for (int t = 0; t < nS; ++t) {
-            wait_vm_barrier<0>();
-            if (t + 1 < nS) issue(t + 1, buf ^ 1);
-            compute(buf);
-            buf ^= 1;
+    // The main loop exists twice (wave-uniform branch) so that each copy is straight-line code for the register
+    // allocator: MODE 0 = plain dtypes, 1 = split-f16 in stage order, 2 = split-f16 late waves (cross terms deferred).
+    auto main_loop = [&](auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        auto body = [&](int buf, int t) {
+            if constexpr (MODE == 0) { compute_plain(buf); }
+            else if constexpr (MODE == 1) { load_split(buf); lead(); cross(); }
+            else { if (t > 0) cross(); load_split(buf); lead(); }
+        };
+        if constexpr (NS == 2) {
+            issue(0, 0);
+            int buf = 0;
+            for (int t = 0; t < nS; ++t) {
+                wait_vm_barrier<0>();
+                if (t + 1 < nS) issue(t + 1, buf ^ 1);
+                body(buf, t);
+                buf ^= 1;
+            }
+        } else {
+            static_assert(NS == 3, "ring depth 2 or 3");
+            issue(0, 0);
+            if (nS > 1) issue(1, 1);
+            int bufC = 0, bufI = 2;
+            for (int t = 0; t < nS; ++t) {
+                if (t + 1 < nS) wait_vm_barrier<L>(); else wait_vm_barrier<0>();
+                if (t + 2 < nS) issue(t + 2, bufI);
+                body(bufC, t);
+                bufC = bufC == 2 ? 0 : bufC + 1;
+                bufI = bufI == 2 ? 0 : bufI + 1;
+            }
         }
+        if constexpr (MODE == 2) cross();                // the last stage's deferred cross terms
+    };
+    if constexpr (!kSplit16) {
+        main_loop(std::integral_constant<int, 0>{});
+    } else if constexpr (NW == 8 && kStagger) {
+        if (late) main_loop(std::integral_constant<int, 2>{});
+        else      main_loop(std::integral_constant<int, 1>{});
     } else {
-        static_assert(NS == 3, "ring depth 2 or 3");
-        issue(0, 0);
-        if (nS > 1) issue(1, 1);
-        int bufC = 0, bufI = 2;
-        for (int t = 0; t < nS; ++t) {
-            if (t + 1 < nS) wait_vm_barrier<L>(); else wait_vm_barrier<0>();
-            if (t + 2 < nS) issue(t + 2, bufI);
-            compute(bufC);
-            bufC = bufC == 2 ? 0 : bufC + 1;
-            bufI = bufI == 2 ? 0 : bufI + 1;
-        }
+        main_loop(std::integral_constant<int, 1>{});
     }
 
     // ---- epilogue: BN affine (+ residual) (+ ReLU), convert, 16-B NHWC stores -------------------------
