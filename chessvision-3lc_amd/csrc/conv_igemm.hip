@@ -34,6 +34,10 @@ constexpr bool kSetPrio = CV_SETPRIO != 0;
 #define CV_STAGGER 0      // measured r01: -3 % with the late-wave schedule on (same-box A/B), kept as a build option
 #endif
 constexpr bool kStagger = CV_STAGGER != 0;
+#ifndef CV_INTERLEAVE
+#define CV_INTERLEAVE 0   // measured r01: -2.5 % (same-box A/B): issuing the prefetch right after the barrier wins
+#endif
+constexpr bool kInterleave = CV_INTERLEAVE != 0;   // deal the next stage's DMA issue out between MFMA clusters
 
 template <typename T> struct FragT;
 template <> struct FragT<half_t> { typedef half8 V; };
@@ -181,6 +185,25 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvParams p)
     const char* wsrc = p.w + (size_t)ctTile * nS * (CT * 128) + wave * 1024 + lane * 16;
     __syncthreads();                                    // koffs visible
 
+    // gather offset of this lane's K chunk in stage s
+    auto stage_koff = [&](int s) -> int {
+        if constexpr (SEP) {
+            typedef const __attribute__((address_space(4))) int* cptr_t;     // scalar-cache load, see `issue`
+            return reinterpret_cast<cptr_t>(reinterpret_cast<uintptr_t>(p.kbase))[s] + myChunk * 16;
+        } else {
+            return koffs[s * 8 + myChunk];
+        }
+    };
+    // DMA instruction j (0 .. L-1) of stage s: the first LW fetch weights, the rest activations.  Issued one by one
+    // from inside the MFMA clusters (kInterleave) so that their issue cost (~60-180 cycles each) is not serialised
+    // behind the stage barrier in every wave at once.
+    auto issue_one = [&](int s, int buf, int ko, int j) {
+        char* sW = smem + buf * STAGE;
+        char* sX = sW + CT * 128;
+        if (j < LW) glds16(wsrc + (size_t)s * (CT * 128) + j * (NW * 1024), sW + (j * NW + wave) * 1024);
+        else        glds16(p.x + xoff[j - LW] + ko, sX + ((j - LW) * NW + wave) * 1024);
+    };
+
     auto issue = [&](int s, int buf) {
         char* sW = smem + buf * STAGE;
         char* sX = sW + CT * 128;
@@ -243,16 +266,23 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvParams p)
             for (int g = 0; g < FP; ++g) mma16(acc[f][g], ah[f], bh[g]);
         if (kSetPrio) __builtin_amdgcn_s_setprio(0);
     };
-    auto cross = [&]() {                                 // lo*hi + hi*lo
-        if (kSetPrio) __builtin_amdgcn_s_setprio(1);
+    // lo*hi + hi*lo; with a pending stage (sn >= 0) its L DMA instructions are dealt out between the FC row groups
+    auto cross = [&](int sn, int bufn) {
+        const int ko = sn >= 0 ? stage_koff(sn) : 0;
 #pragma unroll
-        for (int f = 0; f < FC; ++f)
+        for (int f = 0; f < FC; ++f) {
+            if (sn >= 0) {
+#pragma unroll
+                for (int j = f * L / FC; j < (f + 1) * L / FC; ++j) issue_one(sn, bufn, ko, j);
+            }
+            if (kSetPrio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int g = 0; g < FP; ++g) {
                 mma16(acc[f][g], al[f], bh[g]);
                 mma16(acc[f][g], ah[f], bl[g]);
             }
-        if (kSetPrio) __builtin_amdgcn_s_setprio(0);
+            if (kSetPrio) __builtin_amdgcn_s_setprio(0);
+        }
     };
 
     auto compute_plain = [&](int buf) {                  // f16 / f32: two k-steps per stage
@@ -276,18 +306,27 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvParams p)
     // allocator: MODE 0 = plain dtypes, 1 = split-f16 in stage order, 2 = split-f16 late waves (cross terms deferred).
     auto main_loop = [&](auto mode_tag) {
         constexpr int MODE = decltype(mode_tag)::value;
-        auto body = [&](int buf, int t) {
-            if constexpr (MODE == 0) { compute_plain(buf); }
-            else if constexpr (MODE == 1) { load_split(buf); lead(); cross(); }
-            else { if (t > 0) cross(); load_split(buf); lead(); }
+        // body(buf, t, sn, bufn): compute stage t from ring slot buf; sn/bufn = stage to prefetch now (or -1)
+        auto body = [&](int buf, int t, int sn, int bufn) {
+            if constexpr (MODE == 0) {
+                if (sn >= 0) issue(sn, bufn);
+                compute_plain(buf);
+            } else if constexpr (MODE == 1) {
+                if constexpr (kInterleave) { load_split(buf); lead(); cross(sn, bufn); }
+                else { if (sn >= 0) issue(sn, bufn); load_split(buf); lead(); cross(-1, 0); }
+            } else {
+                if (sn >= 0) issue(sn, bufn);
+                if (t > 0) cross(-1, 0);
+                load_split(buf);
+                lead();
+            }
         };
         if constexpr (NS == 2) {
             issue(0, 0);
             int buf = 0;
             for (int t = 0; t < nS; ++t) {
                 wait_vm_barrier<0>();
-                if (t + 1 < nS) issue(t + 1, buf ^ 1);
-                body(buf, t);
+                body(buf, t, t + 1 < nS ? t + 1 : -1, buf ^ 1);
                 buf ^= 1;
             }
         } else {
@@ -297,13 +336,12 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvParams p)
             int bufC = 0, bufI = 2;
             for (int t = 0; t < nS; ++t) {
                 if (t + 1 < nS) wait_vm_barrier<L>(); else wait_vm_barrier<0>();
-                if (t + 2 < nS) issue(t + 2, bufI);
-                body(bufC, t);
+                body(bufC, t, t + 2 < nS ? t + 2 : -1, bufI);
                 bufC = bufC == 2 ? 0 : bufC + 1;
                 bufI = bufI == 2 ? 0 : bufI + 1;
             }
         }
-        if constexpr (MODE == 2) cross();                // the last stage's deferred cross terms
+        if constexpr (MODE == 2) cross(-1, 0);           // the last stage's deferred cross terms
     };
     if constexpr (!kSplit16) {
         main_loop(std::integral_constant<int, 0>{});
