@@ -39,7 +39,7 @@ def pmc_traffic(dtype, unet_chunk, resnet_chunk, unet_launches, resnet_launches)
     """Per-launch HBM bytes of the conv family from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json:
     separate --pmc FETCH_SIZE / WRITE_SIZE runs of the same chunk sizes, gfx950-corrected); None if not collected."""
     path = ROOT / "profiles" / "r01_pmc_traffic.json"
-    if not path.exists() or (unet_chunk, resnet_chunk) != (16, 4096):
+    if not path.exists() or (unet_chunk, resnet_chunk) != (32, 8192):
         return None
     t = json.load(open(path))
     u, r = t.get(f"{dtype}_unet"), t.get(f"{dtype}_resnet18")
@@ -115,8 +115,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--dtype", default=os.environ.get("CV_BENCH_DTYPE", "f16x3"), choices=["f32", "f16", "f16x3"])
     ap.add_argument("--boards", type=int, default=256, help="boards per GPU per step")
-    ap.add_argument("--unet-chunk", type=int, default=16)
-    ap.add_argument("--resnet-chunk", type=int, default=4096)
+    ap.add_argument("--unet-chunk", type=int, default=32)
+    ap.add_argument("--resnet-chunk", type=int, default=8192)
     ap.add_argument("--overlap", type=int, default=int(os.environ.get("CV_BENCH_OVERLAP", "0")),
                     help="1: enqueue the UNet pass and the ResNet pass of a step on two HIP streams (they are independent)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -26,6 +26,9 @@
 
 namespace cv {
 
+#ifndef CV_ABLATE
+#define CV_ABLATE 0       // timing experiments only (wrong results): 1 = no steady-state DMA, 2 = no MFMA
+#endif
 #ifndef CV_SETPRIO
 #define CV_SETPRIO 1
 #endif
@@ -34,6 +37,9 @@ constexpr bool kSetPrio = CV_SETPRIO != 0;
 #define CV_STAGGER 0      // measured r01: -3 % with the late-wave schedule on (same-box A/B), kept as a build option
 #endif
 constexpr bool kStagger = CV_STAGGER != 0;
+#ifndef CV_ABLATE
+#define CV_ABLATE 0       // timing experiments only (wrong results): 1 = no steady-state DMA, 2 = no MFMA
+#endif
 #ifndef CV_INTERLEAVE
 #define CV_INTERLEAVE 0   // measured r01: -2.5 % (same-box A/B): issuing the prefetch right after the barrier wins
 #endif
@@ -45,7 +51,11 @@ template <> struct FragT<float>  { typedef f4 V; };
 template <> struct FragT<split_t> { typedef half8 V; };
 
 __device__ __forceinline__ void mma16(f4& acc, const half8& a, const half8& b) {
+#if CV_ABLATE == 2
+    asm volatile("" ::"v"(a), "v"(b));                 // keep the fragment loads alive, issue no MFMA
+#else
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+#endif
 }
 // f32: one 16-B chunk = 4 k-values per lane; lane group q owns chunk (sub*4+q), MFMA j contracts the
 // j-th value of all four groups.  The k order inside a stage is permuted identically for A and B.
@@ -244,26 +254,32 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvParams p)
     const bool late = kSplit16 && NW == 8 && kStagger && wave >= 4;
 
     // split-f16 fragment state (persists across iterations for the late waves)
-    V ah[FC], al[FC], bh[FP], bl[FP];
+    constexpr int FPH = FP > 4 ? 4 : FP;               // pixel fragments processed per pass (bounds VGPR use at FP = 8)
+    V ah[FC], al[FC], bh[FPH], bl[FPH];
     const int chi = 2 * q + (q & 1), clo = 2 * q + 1 - (q & 1);   // lane group q: hi chunk / lo chunk of K-group q
     const int swh = (chi ^ (lane & 7)) * 16, swl = (clo ^ (lane & 7)) * 16;
-    auto load_split = [&](int buf) {
+    int g0 = 0;                                          // first pixel fragment of the current pass
+    auto load_split_a = [&](int buf) {
         const char* s = smem + buf * STAGE;
 #pragma unroll
         for (int f = 0; f < FC; ++f) ah[f] = *reinterpret_cast<const V*>(s + rowW + f * 2048 + swh);
 #pragma unroll
-        for (int g = 0; g < FP; ++g) bh[g] = *reinterpret_cast<const V*>(s + rowX + g * 2048 + swh);
-#pragma unroll
         for (int f = 0; f < FC; ++f) al[f] = *reinterpret_cast<const V*>(s + rowW + f * 2048 + swl);
-#pragma unroll
-        for (int g = 0; g < FP; ++g) bl[g] = *reinterpret_cast<const V*>(s + rowX + g * 2048 + swl);
     };
+    auto load_split_b = [&](int buf, int gbase) {
+        const char* s = smem + buf * STAGE;
+#pragma unroll
+        for (int g = 0; g < FPH; ++g) bh[g] = *reinterpret_cast<const V*>(s + rowX + (gbase + g) * 2048 + swh);
+#pragma unroll
+        for (int g = 0; g < FPH; ++g) bl[g] = *reinterpret_cast<const V*>(s + rowX + (gbase + g) * 2048 + swl);
+    };
+    auto load_split = [&](int buf) { load_split_a(buf); load_split_b(buf, 0); };
     auto lead = [&]() {                                  // hi*hi: needs only the hi fragments
         if (kSetPrio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int f = 0; f < FC; ++f)
 #pragma unroll
-            for (int g = 0; g < FP; ++g) mma16(acc[f][g], ah[f], bh[g]);
+            for (int g = 0; g < FPH; ++g) mma16(acc[f][g0 + g], ah[f], bh[g]);
         if (kSetPrio) __builtin_amdgcn_s_setprio(0);
     };
     // lo*hi + hi*lo; with a pending stage (sn >= 0) its L DMA instructions are dealt out between the FC row groups
@@ -277,9 +293,9 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvParams p)
             }
             if (kSetPrio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int g = 0; g < FP; ++g) {
-                mma16(acc[f][g], al[f], bh[g]);
-                mma16(acc[f][g], ah[f], bl[g]);
+            for (int g = 0; g < FPH; ++g) {
+                mma16(acc[f][g0 + g], al[f], bh[g]);
+                mma16(acc[f][g0 + g], ah[f], bl[g]);
             }
             if (kSetPrio) __builtin_amdgcn_s_setprio(0);
         }
@@ -312,7 +328,15 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvParams p)
                 if (sn >= 0) issue(sn, bufn);
                 compute_plain(buf);
             } else if constexpr (MODE == 1) {
-                if constexpr (kInterleave) { load_split(buf); lead(); cross(sn, bufn); }
+                if constexpr (FP > 4) {                  // two passes over the pixel fragments (64ch x 128px wave tile)
+                    if (sn >= 0) issue(sn, bufn);
+                    load_split_a(buf);
+                    load_split_b(buf, 0);
+                    g0 = 0; lead(); cross(-1, 0);
+                    load_split_b(buf, 4);
+                    g0 = 4; lead(); cross(-1, 0);
+                    g0 = 0;
+                } else if constexpr (kInterleave) { load_split(buf); lead(); cross(sn, bufn); }
                 else { if (sn >= 0) issue(sn, bufn); load_split(buf); lead(); cross(-1, 0); }
             } else {
                 if (sn >= 0) issue(sn, bufn);
@@ -326,7 +350,7 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvParams p)
             int buf = 0;
             for (int t = 0; t < nS; ++t) {
                 wait_vm_barrier<0>();
-                body(buf, t, t + 1 < nS ? t + 1 : -1, buf ^ 1);
+                body(buf, t, (CV_ABLATE != 1 && t + 1 < nS) ? t + 1 : -1, buf ^ 1);
                 buf ^= 1;
             }
         } else {
@@ -336,7 +360,7 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvParams p)
             int bufC = 0, bufI = 2;
             for (int t = 0; t < nS; ++t) {
                 if (t + 1 < nS) wait_vm_barrier<L>(); else wait_vm_barrier<0>();
-                body(bufC, t, t + 2 < nS ? t + 2 : -1, bufI);
+                body(bufC, t, (CV_ABLATE != 1 && t + 2 < nS) ? t + 2 : -1, bufI);
                 bufC = bufC == 2 ? 0 : bufC + 1;
                 bufI = bufI == 2 ? 0 : bufI + 1;
             }
@@ -498,7 +522,8 @@ static hipError_t prepare_one() {
     X(T, 128, 256, 2, 2, 4, kCfg128x256)   \
     X(T, 128, 256, 2, 3, 8, kCfg128x256w8) \
     X(T, 64, 512, 1, 2, 8, kCfg64x512w8)   \
-    X(T, 64, 256, 1, 3, 8, kCfg64x256w8)
+    X(T, 64, 256, 1, 3, 8, kCfg64x256w8)   \
+    X(T, 256, 256, 4, 2, 8, kCfg256x256w8)
 
 hipError_t conv_igemm_prepare() {
     hipError_t e;
@@ -522,10 +547,13 @@ hipError_t conv_igemm_launch(int cfg, int ns, int dt, const ConvParams& p, hipSt
 
 bool conv_cfg_has_ns(int cfg, int ns) {
     if (cfg == kCfg128x256w8 || cfg == kCfg64x256w8) return ns == 3;
-    if (cfg == kCfg64x512w8) return ns == 2;
+    if (cfg == kCfg64x512w8 || cfg == kCfg256x256w8) return ns == 2;
     return ns == 2 || ns == 3;
 }
-int conv_cfg_ct(int cfg) { return (cfg == kCfg64x256 || cfg == kCfg64x128 || cfg == kCfg64x512w8 || cfg == kCfg64x256w8) ? 64 : 128; }
+int conv_cfg_ct(int cfg) {
+    if (cfg == kCfg256x256w8) return 256;
+    return (cfg == kCfg64x256 || cfg == kCfg64x128 || cfg == kCfg64x512w8 || cfg == kCfg64x256w8) ? 64 : 128;
+}
 int conv_cfg_pt(int cfg) {
     if (cfg == kCfg64x512w8) return 512;
     return (cfg == kCfg64x128 || cfg == kCfg128x128) ? 128 : 256;

@@ -277,7 +277,7 @@ int cv_op_conv2d(cv_engine_t* eng, const float* x, int n, int cin, int h, int w_
     std::vector<float> ones(cout, 1.f), zeros(cout, 0.f);
     ConvLayer L;
     s = L.build_conv("op_conv2d", e.dt, w_host, cout, cin, k, stride, scale_host ? scale_host : ones.data(),
-                     shift_host ? shift_host : zeros.data(), cinPad);
+                     shift_host ? shift_host : zeros.data(), cinPad, (int64_t)n * ho * wo);
     if (!s.ok()) return finish(s);
     Activation ax, ay, ar;
     if ((s = ax.create(n, h, w_, cinPad, e.dt)).ok() && (s = ay.create(n, ho, wo, cout, e.dt)).ok()) {
@@ -305,7 +305,7 @@ int cv_op_conv_transpose2x2(cv_engine_t* eng, const float* x, int n, int cin, in
     Engine& e = eng->impl;
     hipStream_t st = (hipStream_t)stream;
     ConvLayer L;
-    s = L.build_convT("op_convT", e.dt, w_host, cin, cout, bias_host);
+    s = L.build_convT("op_convT", e.dt, w_host, cin, cout, bias_host, (int64_t)n * h * w_);
     if (!s.ok()) return finish(s);
     Activation ax, ay;
     if ((s = ax.create(n, h, w_, cin, e.dt)).ok() && (s = ay.create(n, 2 * h, 2 * w_, cout, e.dt)).ok()) {

@@ -93,7 +93,7 @@ static void pack_rows(int dt, std::vector<char>& out, int CT, int nCt, int nStag
 
 static Status finish_layer(ConvLayer& L, const std::vector<float>& Wk, int K, const std::vector<float>& scale,
                            const std::vector<float>& shift) {
-    const int CT = L.ct = choose_ct(L.rows);
+    const int CT = L.ct = choose_ct(L.rows, L.pixels_hint);
     L.nStages = (chunks_for(L.dt, K) + 7) / 8;
     L.nCt = (L.rows + CT - 1) / CT;
     L.rowsPad = L.nCt * CT;
@@ -127,9 +127,9 @@ static inline void k_decode(int kgroup, int ntaps, int kk, int* tap, int* ci) {
 }
 
 Status ConvLayer::build_conv(const std::string& name_, int dt_, const float* w_oihw, int cout_, int cin_, int k_,
-                             int stride_, const float* scale_, const float* shift_, int cinPad_) {
+                             int stride_, const float* scale_, const float* shift_, int cinPad_, int64_t pixels_hint_) {
     name = name_; dt = dt_; cin = cin_; cinPad = cinPad_; cout = cout_; k = k_; stride = stride_;
-    shuffle = false; rows = cout_;
+    shuffle = false; rows = cout_; pixels_hint = pixels_hint_;
     if (cinPad % 8 || cinPad < cin) return fail(1, name + ": input channel padding must be a multiple of 8");
     if (k != 1 && k != 3) return fail(1, name + ": implicit-GEMM path supports 1x1 and 3x3 kernels");
     if (cout % 16) return fail(1, name + ": output channels must be a multiple of 16");
@@ -146,9 +146,9 @@ Status ConvLayer::build_conv(const std::string& name_, int dt_, const float* w_o
 }
 
 Status ConvLayer::build_convT(const std::string& name_, int dt_, const float* w_iohw, int cin_, int cout_,
-                              const float* bias) {
+                              const float* bias, int64_t pixels_hint_) {
     name = name_; dt = dt_; cin = cin_; cinPad = cin_; cout = cout_; k = 1; stride = 1;
-    shuffle = true; rows = 4 * cout_;
+    shuffle = true; rows = 4 * cout_; pixels_hint = pixels_hint_;
     if (cin % 8) return fail(1, name + ": transposed-conv input channels must be a multiple of 8");
     if (cout % 16) return fail(1, name + ": transposed-conv output channels must be a multiple of 16");
     const int K = cin;
@@ -222,12 +222,19 @@ static int env_cached(int idx) {                      // 0: CV_CONV_W8, 1: CV_CO
     return v[idx];
 }
 
-// channel-tile height of a layer: fixed at pack time (weights are packed per channel tile)
-int choose_ct(int rows) { return rows % 128 == 0 ? 128 : 64; }
+// channel-tile height of a layer: fixed at pack time (weights are packed per channel tile).  256-row tiles (fewest
+// L2->LDS bytes per MFMA: the r01 ablation shows the DMA side alone costs 60-85 % of a layer's time) are used when
+// the layer still fills the chip with 256x256 workgroups at the engine's chunk size.
+int choose_ct(int rows, int64_t pixels_hint) {
+    if (rows % 256 == 0 && env_int("CV_CT256", 1) && blocks_for(rows, pixels_hint, 256, 256) >= env_int("CV_CT256_MIN_BLOCKS", 256))
+        return 256;
+    return rows % 128 == 0 ? 128 : 64;
+}
 
 // per-launch tile choice among the configurations that share the layer's channel tile
-int choose_cfg(int rows, int64_t pixels, int n_stages) {
-    const bool wide = choose_ct(rows) == 128;
+int choose_cfg(int ct, int rows, int64_t pixels, int n_stages) {
+    if (ct == 256) return kCfg256x256w8;
+    const bool wide = ct == 128;
     const int w8 = env_cached(0), force_pt = env_cached(1);
     if (force_pt == 128 || force_pt == 256)
         return force_pt == 256 ? (wide ? kCfg128x256 : kCfg64x256) : (wide ? kCfg128x128 : kCfg64x128);
@@ -295,7 +302,7 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
         if (L.rows != 64 || L.shuffle) return fail(1, L.name + ": the fused 1x1 head needs a 64-channel layer");
         p.head_w = head->w; p.head_b = head->b; p.head_logits = head->logits; p.head_mask = head->mask; p.head_thr = head->thr;
     }
-    const int cfg = choose_cfg(L.rows, p.M, L.nStages);
+    const int cfg = choose_cfg(L.ct, L.rows, p.M, L.nStages);
     const int ns = choose_ns(cfg, dt, L.rows, p.M);
     p.nCt = (L.rows + conv_cfg_ct(cfg) - 1) / conv_cfg_ct(cfg);
     if (profiling) prof_begin(L.name, true, (double)L.macs_per_out_pixel() * (double)p.M, s);

@@ -76,6 +76,7 @@ struct ConvLayer {
     bool shuffle = false;
     int rows = 0, rowsPad = 0, nStages = 0, nCt = 0;
     int ct = 64;                                    // channel-tile height the weights are packed for (64 | 128)
+    int64_t pixels_hint = 0;                        // output pixels per launch at the engine's chunk size (tile choice)
     int kgroup = 8;                                 // input channels per K block (see engine.cpp: K ordering)
     int dt = kF16;
     DeviceBuffer w, scale, shift;
@@ -87,10 +88,10 @@ struct ConvLayer {
 
     // w_oihw: (cout, cin, k, k); scale/shift: (cout)
     Status build_conv(const std::string& name_, int dt_, const float* w_oihw, int cout_, int cin_, int k_,
-                      int stride_, const float* scale_, const float* shift_, int cinPad_);
+                      int stride_, const float* scale_, const float* shift_, int cinPad_, int64_t pixels_hint_ = 0);
     // w_iohw: (cin, cout, 2, 2); bias: (cout)
     Status build_convT(const std::string& name_, int dt_, const float* w_iohw, int cin_, int cout_,
-                       const float* bias);
+                       const float* bias, int64_t pixels_hint_ = 0);
     Status get_koff(const TensorRef& x, const int** chunks, const int** bases);
     int64_t macs_per_out_pixel() const { return shuffle ? (int64_t)cin * cout * 4 : (int64_t)cin * k * k * cout; }
 };
@@ -108,8 +109,8 @@ class Engine {
     int device = 0;
     int dt = kF16;
     std::mutex mu;
-    int unet_chunk = 16;
-    int resnet_chunk = 4096;
+    int unet_chunk = 32;          // images per pass: every layer still launches >= 256 workgroups of 256x256 / 128x256
+    int resnet_chunk = 8192;      // squares per pass
 
     struct UNet;
     struct ResNet;
@@ -134,8 +135,8 @@ class Engine {
     void prof_clear();
 };
 
-int choose_ct(int rows);
-int choose_cfg(int rows, int64_t pixels, int n_stages);
+int choose_ct(int rows, int64_t pixels_hint);
+int choose_cfg(int ct, int rows, int64_t pixels, int n_stages);
 int choose_ns(int cfg, int dt, int rows, int64_t pixels);
 
 Status unet_load(Engine& e, const ParamMap& pm);

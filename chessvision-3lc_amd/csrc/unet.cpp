@@ -54,7 +54,7 @@ static Status build_conv_bn(ConvLayer& L, int dt, const ParamMap& pm, const std:
     CV_TRY(need(pm, conv_key + ".weight", {cout, cin, k, k}, &w));
     std::vector<float> sc, sh;
     CV_TRY(bn_fold(pm, bn_key, cout, sc, sh));
-    return L.build_conv(conv_key, dt, w, cout, cin, k, stride, sc.data(), sh.data(), cinPad);
+    return L.build_conv(conv_key, dt, w, cout, cin, k, stride, sc.data(), sh.data(), cinPad, pixels);
 }
 Status build_conv_bn_public(ConvLayer& L, int dt, const ParamMap& pm, const std::string& conv_key,
                             const std::string& bn_key, int cout, int cin, int k, int stride, int cinPad,
@@ -100,7 +100,7 @@ Status unet_load(Engine& e, const ParamMap& pm) {
             const float *w, *b;
             CV_TRY(need(pm, p + ".up.weight", {deep_c, deep_c / 2, 2, 2}, &w));
             CV_TRY(need(pm, p + ".up.bias", {deep_c / 2}, &b));
-            CV_TRY(U.upT[i].build_convT(p + ".up", dt, w, deep_c, deep_c / 2, b));
+            CV_TRY(U.upT[i].build_convT(p + ".up", dt, w, deep_c, deep_c / 2, b, px(lvl + 1)));
             cat_c = skip_c + deep_c / 2;
             out_c = skip_c;
             mid_c = out_c;

@@ -62,6 +62,8 @@ CONV_CASES = [
     ("cout_16_cin_8", 1, 8, 16, 16, 16, 3, 1, False, False),
     ("many_pixels_64x256cfg", 8, 64, 64, 64, 64, 3, 1, True, False),
     ("many_pixels_128x256cfg", 8, 64, 64, 64, 128, 3, 1, True, False),
+    ("tile_256x256cfg", 8, 64, 64, 64, 512, 3, 1, True, False),
+    ("tile_256x256_residual_tail", 9, 128, 60, 60, 256, 3, 1, True, True),
 ]
 
 
@@ -86,7 +88,7 @@ def test_conv_bn_relu(engines, prec, case):
 
 
 @pytest.mark.parametrize("prec", PRECS)
-@pytest.mark.parametrize("shape", [(2, 64, 8, 8, 32), (1, 128, 16, 16, 64), (2, 1024, 4, 4, 512)])
+@pytest.mark.parametrize("shape", [(2, 64, 8, 8, 32), (1, 128, 16, 16, 64), (2, 1024, 4, 4, 512), (16, 128, 64, 64, 64)])
 def test_conv_transpose_k2s2(engines, prec, shape):
     n, cin, h, w, cout = shape
     x = _t(21, "ctx", (n, cin, h, w))
