@@ -25,6 +25,11 @@ hipError_t conv_igemm_prepare();                                   // raise dyna
 hipError_t conv_igemm_launch(int cfg, int ns, int dt, const ConvParams& p, hipStream_t stream);   // ns = LDS ring depth 2|3
 bool conv_cfg_has_ns(int cfg, int ns);
 int conv_cfg_ct(int cfg);
+
+// conv_halo.hip: 3x3 / stride-1 layers with the input patch (+halo) resident in LDS across the nine taps
+hipError_t conv_halo_prepare();
+bool conv_halo_supported(int ct, int Ho, int Wo);
+hipError_t conv_halo_launch(int ct, int dt, const ConvParams& p, int n_images, hipStream_t stream);
 int conv_cfg_pt(int cfg);
 
 }  // namespace cv

@@ -21,124 +21,9 @@
 //   The activation gather needs no bounds checks: tensors carry a zero border (cv_kernels.h).
 #include "cv_kernels.h"
 #include "conv_igemm.h"
-
-#include <type_traits>
+#include "conv_device.h"
 
 namespace cv {
-
-#ifndef CV_ABLATE
-#define CV_ABLATE 0       // timing experiments only (wrong results): 1 = no steady-state DMA, 2 = no MFMA
-#endif
-#ifndef CV_SETPRIO
-#define CV_SETPRIO 1
-#endif
-constexpr bool kSetPrio = CV_SETPRIO != 0;
-#ifndef CV_STAGGER
-#define CV_STAGGER 0      // measured r01: -3 % with the late-wave schedule on (same-box A/B), kept as a build option
-#endif
-constexpr bool kStagger = CV_STAGGER != 0;
-#ifndef CV_ABLATE
-#define CV_ABLATE 0       // timing experiments only (wrong results): 1 = no steady-state DMA, 2 = no MFMA
-#endif
-#ifndef CV_INTERLEAVE
-#define CV_INTERLEAVE 0   // measured r01: -2.5 % (same-box A/B): issuing the prefetch right after the barrier wins
-#endif
-constexpr bool kInterleave = CV_INTERLEAVE != 0;   // deal the next stage's DMA issue out between MFMA clusters
-
-template <typename T> struct FragT;
-template <> struct FragT<half_t> { typedef half8 V; };
-template <> struct FragT<float>  { typedef f4 V; };
-template <> struct FragT<split_t> { typedef half8 V; };
-
-__device__ __forceinline__ void mma16(f4& acc, const half8& a, const half8& b) {
-#if CV_ABLATE == 2
-    asm volatile("" ::"v"(a), "v"(b));                 // keep the fragment loads alive, issue no MFMA
-#else
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
-#endif
-}
-// f32: one 16-B chunk = 4 k-values per lane; lane group q owns chunk (sub*4+q), MFMA j contracts the
-// j-th value of all four groups.  The k order inside a stage is permuted identically for A and B.
-__device__ __forceinline__ void mma16(f4& acc, const f4& a, const f4& b) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc, 0, 0, 0);
-}
-
-__device__ __forceinline__ void glds16(const char* g, char* l) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-}
-
-template <int N> __device__ __forceinline__ void wait_vm_barrier() {
-    // every wave: its own DMA of the stage about to be read has landed (all but N younger ones), its
-    // LDS reads of the stage about to be overwritten have returned; then the workgroup rendezvous.
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
-}
-
-// N consecutive channels of one pixel -> 16-B stores.  ch0 = absolute index of the first channel in the buffer
-// (selects the [hi,lo] / [lo,hi] chunk order of split-f16 groups; unused otherwise).
-template <typename T, int N> struct OutVec;
-template <int N> struct OutVec<half_t, N> {
-    static __device__ __forceinline__ void store(half_t* dst, int, const float* v) {
-#pragma unroll
-        for (int i = 0; i < N; i += 8) {
-            half8 h;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) h[j] = (half_t)v[i + j];
-            *reinterpret_cast<half8*>(dst + i) = h;
-        }
-    }
-    static __device__ __forceinline__ void add(const half_t* src, int, float* v) {
-#pragma unroll
-        for (int i = 0; i < N; i += 8) {
-            const half8 h = *reinterpret_cast<const half8*>(src + i);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[i + j] += (float)h[j];
-        }
-    }
-};
-template <int N> struct OutVec<float, N> {
-    static __device__ __forceinline__ void store(float* dst, int, const float* v) {
-#pragma unroll
-        for (int i = 0; i < N; i += 4) {
-            f4 o = {v[i], v[i + 1], v[i + 2], v[i + 3]};
-            *reinterpret_cast<f4*>(dst + i) = o;
-        }
-    }
-    static __device__ __forceinline__ void add(const float* src, int, float* v) {
-#pragma unroll
-        for (int i = 0; i < N; i += 4) {
-            const f4 o = *reinterpret_cast<const f4*>(src + i);
-            v[i] += o[0]; v[i + 1] += o[1]; v[i + 2] += o[2]; v[i + 3] += o[3];
-        }
-    }
-};
-template <int N> struct OutVec<split_t, N> {
-    static __device__ __forceinline__ void store(split_t* dst, int ch0, const float* v) {
-        char* p = reinterpret_cast<char*>(dst);
-#pragma unroll
-        for (int i = 0; i < N; i += 8) {
-            const int par = ((ch0 + i) >> 3) & 1;
-            half8 hi, lo;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { hi[j] = (half_t)v[i + j]; lo[j] = (half_t)(v[i + j] - (float)hi[j]); }
-            *reinterpret_cast<half8*>(p + i * 4 + (par ? 16 : 0)) = hi;
-            *reinterpret_cast<half8*>(p + i * 4 + (par ? 0 : 16)) = lo;
-        }
-    }
-    static __device__ __forceinline__ void add(const split_t* src, int ch0, float* v) {
-        const char* p = reinterpret_cast<const char*>(src);
-#pragma unroll
-        for (int i = 0; i < N; i += 8) {
-            const half8 a = *reinterpret_cast<const half8*>(p + i * 4);
-            const half8 b = *reinterpret_cast<const half8*>(p + i * 4 + 16);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[i + j] += (float)a[j] + (float)b[j];
-        }
-    }
-};
 
 // CT x PT = channel x pixel tile of the workgroup (NW waves as WGC x NW/WGC); every wave owns a 64-channel
 // slab (FC = 4 fragments: the row permutation the host packs for) and PT*WGC/NW pixels.  NW = 8 puts two waves

@@ -82,6 +82,7 @@ int cv_engine_create(int device, int precision, cv_engine_t** out) {
     if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
         return finish(fail(CV_ERR_STATE, std::string("libchessvision_hip is built for gfx950 (MI355X); device is ") + prop.gcnArchName));
     if ((e = conv_igemm_prepare()) != hipSuccess) return finish(hip_fail(e, "conv_igemm_prepare"));
+    if ((e = conv_halo_prepare()) != hipSuccess) return finish(hip_fail(e, "conv_halo_prepare"));
     cv_engine* eng = new (std::nothrow) cv_engine();
     if (!eng) return finish(fail(CV_ERR_NOMEM, "out of host memory"));
     eng->impl.device = device;
@@ -277,7 +278,7 @@ int cv_op_conv2d(cv_engine_t* eng, const float* x, int n, int cin, int h, int w_
     std::vector<float> ones(cout, 1.f), zeros(cout, 0.f);
     ConvLayer L;
     s = L.build_conv("op_conv2d", e.dt, w_host, cout, cin, k, stride, scale_host ? scale_host : ones.data(),
-                     shift_host ? shift_host : zeros.data(), cinPad, (int64_t)n * ho * wo);
+                     shift_host ? shift_host : zeros.data(), cinPad, (int64_t)n * ho * wo, (ho == wo) ? ho : 0);
     if (!s.ok()) return finish(s);
     Activation ax, ay, ar;
     if ((s = ax.create(n, h, w_, cinPad, e.dt)).ok() && (s = ay.create(n, ho, wo, cout, e.dt)).ok()) {

@@ -55,6 +55,7 @@ struct ConvParams {
     int xHp, xWp;             // input padded dims (Hi+2, Wi+2)
     int stride;               // convolution stride
     int xCs;                  // input channel stride (elements)
+    int xCoffBytes;           // byte offset of the input slice's first channel (conv_halo.hip; conv_igemm folds it into koff)
     int yHp, yWp;             // output padded dims
     int yCs, yCoff;           // output channel stride / first channel
     int rCs, rCoff;           // residual channel stride / first channel

@@ -93,7 +93,7 @@ static void pack_rows(int dt, std::vector<char>& out, int CT, int nCt, int nStag
 
 static Status finish_layer(ConvLayer& L, const std::vector<float>& Wk, int K, const std::vector<float>& scale,
                            const std::vector<float>& shift) {
-    const int CT = L.ct = choose_ct(L.rows, L.pixels_hint);
+    const int CT = L.ct = choose_ct(L.rows, L.pixels_hint, L.halo_ok);
     L.nStages = (chunks_for(L.dt, K) + 7) / 8;
     L.nCt = (L.rows + CT - 1) / CT;
     L.rowsPad = L.nCt * CT;
@@ -127,9 +127,10 @@ static inline void k_decode(int kgroup, int ntaps, int kk, int* tap, int* ci) {
 }
 
 Status ConvLayer::build_conv(const std::string& name_, int dt_, const float* w_oihw, int cout_, int cin_, int k_,
-                             int stride_, const float* scale_, const float* shift_, int cinPad_, int64_t pixels_hint_) {
+                             int stride_, const float* scale_, const float* shift_, int cinPad_, int64_t pixels_hint_, int out_hw_) {
     name = name_; dt = dt_; cin = cin_; cinPad = cinPad_; cout = cout_; k = k_; stride = stride_;
     shuffle = false; rows = cout_; pixels_hint = pixels_hint_;
+    halo_ok = k_ == 3 && stride_ == 1 && out_hw_ > 0 && out_hw_ % 16 == 0 && cinPad_ % (128 / dtype_size(dt_)) == 0;
     if (cinPad % 8 || cinPad < cin) return fail(1, name + ": input channel padding must be a multiple of 8");
     if (k != 1 && k != 3) return fail(1, name + ": implicit-GEMM path supports 1x1 and 3x3 kernels");
     if (cout % 16) return fail(1, name + ": output channels must be a multiple of 16");
@@ -225,7 +226,8 @@ static int env_cached(int idx) {                      // 0: CV_CONV_W8, 1: CV_CO
 // channel-tile height of a layer: fixed at pack time (weights are packed per channel tile).  256-row tiles (fewest
 // L2->LDS bytes per MFMA: the r01 ablation shows the DMA side alone costs 60-85 % of a layer's time) are used when
 // the layer still fills the chip with 256x256 workgroups at the engine's chunk size.
-int choose_ct(int rows, int64_t pixels_hint) {
+int choose_ct(int rows, int64_t pixels_hint, bool halo_ok) {
+    if (halo_ok && env_int("CV_HALO", 1)) return rows % 128 == 0 ? 128 : 64;   // the halo kernel has 64- and 128-row tiles
     if (rows % 256 == 0 && env_int("CV_CT256", 1) && blocks_for(rows, pixels_hint, 256, 256) >= env_int("CV_CT256_MIN_BLOCKS", 256))
         return 256;
     return rows % 128 == 0 ? 128 : 64;
@@ -295,7 +297,7 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
     }
     p.y = reinterpret_cast<char*>(y.base);
     p.M = x.N * Ho * Wo; p.Ho = Ho; p.Wo = Wo;
-    p.xHp = x.H + 2; p.xWp = x.W + 2; p.stride = L.stride; p.xCs = x.Cs;
+    p.xHp = x.H + 2; p.xWp = x.W + 2; p.stride = L.stride; p.xCs = x.Cs; p.xCoffBytes = x.Coff * esz;
     p.yHp = y.H + 2; p.yWp = y.W + 2; p.yCs = y.Cs; p.yCoff = y.Coff;
     p.Cout = L.cout; p.rows = L.rows; p.nStages = L.nStages; p.nCt = L.nCt; p.relu = relu ? 1 : 0; p.shuffle = L.shuffle ? 1 : 0;
     if (head) {
@@ -305,8 +307,11 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
     const int cfg = choose_cfg(L.ct, L.rows, p.M, L.nStages);
     const int ns = choose_ns(cfg, dt, L.rows, p.M);
     p.nCt = (L.rows + conv_cfg_ct(cfg) - 1) / conv_cfg_ct(cfg);
+    // 3x3 / stride-1 layers whose patch grid divides the image keep the input patch in LDS across the nine taps
+    const bool halo = L.k == 3 && L.stride == 1 && !L.shuffle && kbase != nullptr && L.nStages % 9 == 0 &&
+                      env_int("CV_HALO", 1) && conv_halo_supported(L.ct, Ho, Wo);
     if (profiling) prof_begin(L.name, true, (double)L.macs_per_out_pixel() * (double)p.M, s);
-    hipError_t e = conv_igemm_launch(cfg, ns, dt, p, s);
+    hipError_t e = halo ? conv_halo_launch(L.ct, dt, p, x.N, s) : conv_igemm_launch(cfg, ns, dt, p, s);
     if (profiling) prof_end(s);
     if (e != hipSuccess) return hip_fail(e, ("conv launch " + L.name).c_str());
     return Status();

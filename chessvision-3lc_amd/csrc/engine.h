@@ -76,6 +76,7 @@ struct ConvLayer {
     bool shuffle = false;
     int rows = 0, rowsPad = 0, nStages = 0, nCt = 0;
     int ct = 64;                                    // channel-tile height the weights are packed for (64 | 128)
+    bool halo_ok = false;                           // 3x3 s1 on a 16-divisible square grid: conv_halo.hip tiles (64 | 128 rows)
     int64_t pixels_hint = 0;                        // output pixels per launch at the engine's chunk size (tile choice)
     int kgroup = 8;                                 // input channels per K block (see engine.cpp: K ordering)
     int dt = kF16;
@@ -88,7 +89,8 @@ struct ConvLayer {
 
     // w_oihw: (cout, cin, k, k); scale/shift: (cout)
     Status build_conv(const std::string& name_, int dt_, const float* w_oihw, int cout_, int cin_, int k_,
-                      int stride_, const float* scale_, const float* shift_, int cinPad_, int64_t pixels_hint_ = 0);
+                      int stride_, const float* scale_, const float* shift_, int cinPad_, int64_t pixels_hint_ = 0,
+                      int out_hw_ = 0);
     // w_iohw: (cin, cout, 2, 2); bias: (cout)
     Status build_convT(const std::string& name_, int dt_, const float* w_iohw, int cin_, int cout_,
                        const float* bias, int64_t pixels_hint_ = 0);
@@ -135,7 +137,7 @@ class Engine {
     void prof_clear();
 };
 
-int choose_ct(int rows, int64_t pixels_hint);
+int choose_ct(int rows, int64_t pixels_hint, bool halo_ok);
 int choose_cfg(int ct, int rows, int64_t pixels, int n_stages);
 int choose_ns(int cfg, int dt, int rows, int64_t pixels);
 

@@ -15,7 +15,7 @@ namespace cv {
 
 Status build_conv_bn_public(ConvLayer& L, int dt, const ParamMap& pm, const std::string& conv_key,
                             const std::string& bn_key, int cout, int cin, int k, int stride, int cinPad,
-                            int64_t pixels);
+                            int64_t pixels, int out_hw);
 
 
 static Status need2(const ParamMap& pm, const std::string& key, std::vector<int64_t> shape, const float** out) {
@@ -80,11 +80,11 @@ Status resnet_load(Engine& e, const ParamMap& pm) {
             const int w = widths[l];
             const int stride = (bi == 0 && l > 0) ? 2 : 1;
             const int64_t px = (int64_t)S * res[l] * res[l];
-            CV_TRY(build_conv_bn_public(B.conv1, dt, pm, p + ".conv1", p + ".bn1", w, cin, 3, stride, cin, px));
-            CV_TRY(build_conv_bn_public(B.conv2, dt, pm, p + ".conv2", p + ".bn2", w, w, 3, 1, w, px));
+            CV_TRY(build_conv_bn_public(B.conv1, dt, pm, p + ".conv1", p + ".bn1", w, cin, 3, stride, cin, px, res[l]));
+            CV_TRY(build_conv_bn_public(B.conv2, dt, pm, p + ".conv2", p + ".bn2", w, w, 3, 1, w, px, res[l]));
             B.has_down = (stride != 1 || cin != w);
             if (B.has_down) {
-                CV_TRY(build_conv_bn_public(B.down, dt, pm, p + ".downsample.0", p + ".downsample.1", w, cin, 1, stride, cin, px));
+                CV_TRY(build_conv_bn_public(B.down, dt, pm, p + ".downsample.0", p + ".downsample.1", w, cin, 1, stride, cin, px, res[l]));
                 CV_TRY(B.sc.create(S, res[l], res[l], w, dt));
                 macs += (int64_t)cin * w * res[l] * res[l];
             }

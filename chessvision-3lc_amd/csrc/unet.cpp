@@ -49,17 +49,17 @@ static Status bn_fold(const ParamMap& pm, const std::string& prefix, int c, std:
 
 static Status build_conv_bn(ConvLayer& L, int dt, const ParamMap& pm, const std::string& conv_key,
                             const std::string& bn_key, int cout, int cin, int k, int stride, int cinPad,
-                            int64_t pixels) {
+                            int64_t pixels, int out_hw = 0) {
     const float* w;
     CV_TRY(need(pm, conv_key + ".weight", {cout, cin, k, k}, &w));
     std::vector<float> sc, sh;
     CV_TRY(bn_fold(pm, bn_key, cout, sc, sh));
-    return L.build_conv(conv_key, dt, w, cout, cin, k, stride, sc.data(), sh.data(), cinPad, pixels);
+    return L.build_conv(conv_key, dt, w, cout, cin, k, stride, sc.data(), sh.data(), cinPad, pixels, out_hw);
 }
 Status build_conv_bn_public(ConvLayer& L, int dt, const ParamMap& pm, const std::string& conv_key,
                             const std::string& bn_key, int cout, int cin, int k, int stride, int cinPad,
-                            int64_t pixels) {
-    return build_conv_bn(L, dt, pm, conv_key, bn_key, cout, cin, k, stride, cinPad, pixels);
+                            int64_t pixels, int out_hw) {
+    return build_conv_bn(L, dt, pm, conv_key, bn_key, cout, cin, k, stride, cinPad, pixels, out_hw);
 }
 
 Status unet_load(Engine& e, const ParamMap& pm) {
@@ -80,12 +80,12 @@ Status unet_load(Engine& e, const ParamMap& pm) {
     auto px = [&](int level) { return (int64_t)S * res[level] * res[level]; };
 
     // encoder
-    CV_TRY(build_conv_bn(U.inc0, dt, pm, "inc.double_conv.0", "inc.double_conv.1", 64, 3, 3, 1, 8, px(0)));
-    CV_TRY(build_conv_bn(U.inc1, dt, pm, "inc.double_conv.3", "inc.double_conv.4", 64, 64, 3, 1, 64, px(0)));
+    CV_TRY(build_conv_bn(U.inc0, dt, pm, "inc.double_conv.0", "inc.double_conv.1", 64, 3, 3, 1, 8, px(0), 256));
+    CV_TRY(build_conv_bn(U.inc1, dt, pm, "inc.double_conv.3", "inc.double_conv.4", 64, 64, 3, 1, 64, px(0), 256));
     for (int i = 0; i < 4; ++i) {
         const std::string p = "down" + std::to_string(i + 1) + ".maxpool_conv.1.double_conv.";
-        CV_TRY(build_conv_bn(U.d[i][0], dt, pm, p + "0", p + "1", enc_c[i + 1], enc_c[i], 3, 1, enc_c[i], px(i + 1)));
-        CV_TRY(build_conv_bn(U.d[i][1], dt, pm, p + "3", p + "4", enc_c[i + 1], enc_c[i + 1], 3, 1, enc_c[i + 1], px(i + 1)));
+        CV_TRY(build_conv_bn(U.d[i][0], dt, pm, p + "0", p + "1", enc_c[i + 1], enc_c[i], 3, 1, enc_c[i], px(i + 1), res[i + 1]));
+        CV_TRY(build_conv_bn(U.d[i][1], dt, pm, p + "3", p + "4", enc_c[i + 1], enc_c[i + 1], 3, 1, enc_c[i + 1], px(i + 1), res[i + 1]));
     }
     // decoder: up_i consumes the deeper tensor (channels deep_c) and skip level (3 - i)
     //   transposed: up: deep_c -> deep_c/2 ; conv: cat(skip, up) = deep_c -> out_c -> out_c
@@ -110,8 +110,8 @@ Status unet_load(Engine& e, const ParamMap& pm) {
             out_c = (i == 3) ? 64 : skip_c / 2;
         }
         const std::string c = p + ".conv.double_conv.";
-        CV_TRY(build_conv_bn(U.u[i][0], dt, pm, c + "0", c + "1", mid_c, cat_c, 3, 1, cat_c, px(lvl)));
-        CV_TRY(build_conv_bn(U.u[i][1], dt, pm, c + "3", c + "4", out_c, mid_c, 3, 1, mid_c, px(lvl)));
+        CV_TRY(build_conv_bn(U.u[i][0], dt, pm, c + "0", c + "1", mid_c, cat_c, 3, 1, cat_c, px(lvl), res[lvl]));
+        CV_TRY(build_conv_bn(U.u[i][1], dt, pm, c + "3", c + "4", out_c, mid_c, 3, 1, mid_c, px(lvl), res[lvl]));
         deep_c = out_c;
     }
     {
