@@ -24,19 +24,22 @@
 
 namespace cv {
 
-template <typename T, int CT, int TH, int WGC, int NW>
+// TPS = taps per stage (1, or 3 = one filter row: fewer, fatter stages for the 64-row tile); NSW = weight ring depth.
+template <typename T, int CT, int TH, int WGC, int NW, int TPS, int NSW>
 __global__ __launch_bounds__(64 * NW) void conv3x3_halo_kernel(const ConvParams p) {
-    constexpr int NSW = 3;
+    static_assert((TPS == 1 || TPS == 3) && (NSW == 2 || NSW == 3), "stage shape");
+    constexpr int SPC = 9 / TPS;                        // stages per channel block
     constexpr int WGP = NW / WGC;                       // wave groups along the patch rows
     static_assert(CT / WGC == 64, "every wave owns a 64-channel slab");
     constexpr int FC = 4;
     constexpr int FP = TH / WGP;                        // patch rows (= 16-pixel fragments) per wave
     static_assert(FP >= 1 && FP <= 4 && TH % WGP == 0, "wave tile");
-    constexpr int WSTAGE = CT * 128;
+    constexpr int WTAP = CT * 128;                      // weight bytes of one tap
+    constexpr int WSTAGE = TPS * WTAP;
     constexpr int HR = 18 * (TH + 2);                   // halo rows (one pixel = one 128-byte LDS row)
     constexpr int H = ((HR + 7) / 8 + NW - 1) / NW;     // halo DMA wave-instructions per wave (8 rows each)
     constexpr int HBYTES = H * NW * 1024;
-    constexpr int LW = CT / (8 * NW);
+    constexpr int LW = TPS * CT / (8 * NW);
     static_assert(LW >= 1 && LW + H <= 63, "vmcnt range");
     constexpr bool kSplit16 = sizeof(T) == 4 && !__is_same(T, float);
     typedef typename FragT<T>::V V;
@@ -56,7 +59,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_halo_kernel(const ConvParams 
     const int tx = pt % tilesX; pt /= tilesX;
     const int ty = pt % tilesY;
     const int n = pt / tilesY;
-    const int nS = p.nStages, nCb = nS / 9;
+    const int nCb = p.nStages / 9, nS = nCb * SPC;       // p.nStages counts (channel block, tap) pairs
 
     // DMA sources of this lane's halo rows: row r of the halo <-> padded input pixel (ty*TH + r/18, tx*16 + r%18)
     unsigned hoff[H];
@@ -69,12 +72,12 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_halo_kernel(const ConvParams 
                   (unsigned)(((lane & 7) ^ (lane >> 3)) * 16);
     }
     const char* const xsrc = p.x + p.xCoffBytes;
-    const char* const wsrc = p.w + (size_t)ctTile * nS * WSTAGE + wave * 1024 + lane * 16;
+    const char* const wsrc = p.w + (size_t)ctTile * p.nStages * WTAP + wave * 1024 + lane * 16;
 
     auto issue_w = [&](int s, int slot) {
         char* sW = smem + slot * WSTAGE;
 #pragma unroll
-        for (int i = 0; i < LW; ++i) glds16(wsrc + (size_t)s * WSTAGE + i * (NW * 1024), sW + (i * NW + wave) * 1024);
+        for (int i = 0; i < LW; ++i) glds16(wsrc + (size_t)s * WSTAGE + i * (NW * 1024), sW + (i * NW + wave) * 1024);   // stage s = TPS consecutive taps
     };
     auto issue_halo = [&](int cb, int hb) {
         char* sH = halo + hb * HBYTES;
@@ -97,11 +100,15 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_halo_kernel(const ConvParams 
 #pragma unroll
         for (int g = 0; g < FP; ++g) acc[f][g] = f4{0.f, 0.f, 0.f, 0.f};
 
-    auto compute = [&](auto tap_tag, int wslot, int hb) {
+    auto compute_tap = [&](auto tap_tag, const char* sW, const char* sH) {
         constexpr int TAP = decltype(tap_tag)::value;
         constexpr int TOFF = (TAP / 3) * 18 + (TAP % 3);
-        const char* sW = smem + wslot * WSTAGE;
-        const char* sH = halo + hb * HBYTES;
+        // The halo addresses of all 9 taps x FP rows x {hi, lo} are loop invariant; left alone, LICM keeps ~70 of them
+        // live across the channel-block loop and the 128-row split-f16 tile spills.  Re-deriving them per tap costs a
+        // handful of VALU ops, so make the row base opaque here.
+        int hrb[FP];
+#pragma unroll
+        for (int g = 0; g < FP; ++g) { hrb[g] = hr0[g]; asm volatile("" : "+v"(hrb[g])); }
         if constexpr (kSplit16) {
             const int chi = 2 * q + (q & 1), clo = 2 * q + 1 - (q & 1);
             V ah[FC], al[FC], bh[FP], bl[FP];
@@ -109,14 +116,14 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_halo_kernel(const ConvParams 
             for (int f = 0; f < FC; ++f) ah[f] = *reinterpret_cast<const V*>(sW + rowW + f * 2048 + ((chi ^ l7) << 4));
 #pragma unroll
             for (int g = 0; g < FP; ++g) {
-                const int hr = hr0[g] + TOFF;
+                const int hr = hrb[g] + TOFF;
                 bh[g] = *reinterpret_cast<const V*>(sH + hr * 128 + ((chi ^ (hr & 7)) << 4));
             }
 #pragma unroll
             for (int f = 0; f < FC; ++f) al[f] = *reinterpret_cast<const V*>(sW + rowW + f * 2048 + ((clo ^ l7) << 4));
 #pragma unroll
             for (int g = 0; g < FP; ++g) {
-                const int hr = hr0[g] + TOFF;
+                const int hr = hrb[g] + TOFF;
                 bl[g] = *reinterpret_cast<const V*>(sH + hr * 128 + ((clo ^ (hr & 7)) << 4));
             }
             if (kSetPrio) __builtin_amdgcn_s_setprio(1);
@@ -141,7 +148,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_halo_kernel(const ConvParams 
                 for (int f = 0; f < FC; ++f) a[f] = *reinterpret_cast<const V*>(sW + rowW + f * 2048 + ((c ^ l7) << 4));
 #pragma unroll
                 for (int g = 0; g < FP; ++g) {
-                    const int hr = hr0[g] + TOFF;
+                    const int hr = hrb[g] + TOFF;
                     b[g] = *reinterpret_cast<const V*>(sH + hr * 128 + ((c ^ (hr & 7)) << 4));
                 }
 #pragma unroll
@@ -151,35 +158,49 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_halo_kernel(const ConvParams 
             }
         }
     };
+    // stage J of a channel block covers taps J*TPS .. J*TPS + TPS - 1
+    auto compute = [&](auto j_tag, int wslot, int hb) {
+        constexpr int J = decltype(j_tag)::value;
+        const char* sW = smem + wslot * WSTAGE;
+        const char* sH = halo + hb * HBYTES;
+        compute_tap(std::integral_constant<int, J * TPS>{}, sW, sH);
+        if constexpr (TPS == 3) {
+            compute_tap(std::integral_constant<int, J * TPS + 1>{}, sW + WTAP, sH);
+            compute_tap(std::integral_constant<int, J * TPS + 2>{}, sW + 2 * WTAP, sH);
+        }
+    };
 
-    // ---- main loop: channel blocks x 9 taps -------------------------------------------------------------
+    // ---- main loop: channel blocks x stages ----------------------------------------------------------------
     issue_halo(0, 0);
     issue_w(0, 0);
-    if (nS > 1) issue_w(1, 1);
-    int slotC = 0, slotI = 2, s = 0;
+    if (NSW == 3 && nS > 1) issue_w(1, 1);
+    int slotC = 0, slotI = NSW - 1, s = 0;
     for (int cb = 0; cb < nCb; ++cb) {
         const int hb = cb & 1;
         const bool more_cb = cb + 1 < nCb;
-        auto stage = [&](auto tap_tag) {
-            constexpr int TAP = decltype(tap_tag)::value;
-            const bool w_next = s + 1 < nS;
-            const bool halo_young = (TAP == 1 || TAP == 2) && more_cb;     // next halo was issued after W(s)
+        auto stage = [&](auto j_tag) {
+            constexpr int J = decltype(j_tag)::value;
+            // in flight after W(s): W(s+1) (ring 3 only) and the next halo if it was issued one (or two) stages ago
+            const bool w_next = NSW == 3 && s + 1 < nS;
+            const bool halo_young = (J == 1 || (NSW == 3 && J == 2)) && more_cb;
             if (w_next && halo_young) wait_vm_barrier<LW + H>();
             else if (w_next) wait_vm_barrier<LW>();
             else if (halo_young) wait_vm_barrier<H>();
             else wait_vm_barrier<0>();
-            if (s + 2 < nS) issue_w(s + 2, slotI);
-            if (TAP == 0 && more_cb) issue_halo(cb + 1, hb ^ 1);
-            compute(tap_tag, slotC, hb);
-            slotC = slotC == 2 ? 0 : slotC + 1;
-            slotI = slotI == 2 ? 0 : slotI + 1;
+            if (s + NSW - 1 < nS) issue_w(s + NSW - 1, slotI);
+            if (J == 0 && more_cb) issue_halo(cb + 1, hb ^ 1);
+            compute(j_tag, slotC, hb);
+            slotC = slotC == NSW - 1 ? 0 : slotC + 1;
+            slotI = slotI == NSW - 1 ? 0 : slotI + 1;
             ++s;
         };
         stage(std::integral_constant<int, 0>{}); stage(std::integral_constant<int, 1>{});
-        stage(std::integral_constant<int, 2>{}); stage(std::integral_constant<int, 3>{});
-        stage(std::integral_constant<int, 4>{}); stage(std::integral_constant<int, 5>{});
-        stage(std::integral_constant<int, 6>{}); stage(std::integral_constant<int, 7>{});
-        stage(std::integral_constant<int, 8>{});
+        stage(std::integral_constant<int, 2>{});
+        if constexpr (SPC == 9) {
+            stage(std::integral_constant<int, 3>{}); stage(std::integral_constant<int, 4>{});
+            stage(std::integral_constant<int, 5>{}); stage(std::integral_constant<int, 6>{});
+            stage(std::integral_constant<int, 7>{}); stage(std::integral_constant<int, 8>{});
+        }
     }
 
     // ---- epilogue (see conv_igemm.hip for the rationale of the staged store) ------------------------------
@@ -269,38 +290,39 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_halo_kernel(const ConvParams 
 }
 
 // ---- host-side launch -------------------------------------------------------------------------------------
-template <typename T, int CT, int TH, int WGC, int NW>
-static size_t halo_lds() {
+template <int CT, int TH, int NW, int TPS, int NSW>
+static constexpr size_t halo_lds() {
     constexpr int HR = 18 * (TH + 2);
     constexpr int H = ((HR + 7) / 8 + NW - 1) / NW;
-    return (size_t)3 * CT * 128 + (size_t)2 * H * NW * 1024;
+    return (size_t)NSW * TPS * CT * 128 + (size_t)2 * H * NW * 1024;
 }
 
-template <typename T, int CT, int TH, int WGC, int NW>
+template <typename T, int CT, int TH, int WGC, int NW, int TPS, int NSW>
 static hipError_t launch_halo(const ConvParams& p, int n_images, hipStream_t stream) {
     const int tiles = n_images * (p.Ho / TH) * (p.Wo / 16);
-    auto kern = conv3x3_halo_kernel<T, CT, TH, WGC, NW>;
-    const size_t lds = halo_lds<T, CT, TH, WGC, NW>();
+    auto kern = conv3x3_halo_kernel<T, CT, TH, WGC, NW, TPS, NSW>;
+    const size_t lds = halo_lds<CT, TH, NW, TPS, NSW>();
+    static_assert(halo_lds<CT, TH, NW, TPS, NSW>() <= 160 * 1024, "LDS budget");
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * p.nCt)), dim3(64 * NW), lds, stream, p);
     return hipGetLastError();
 }
 
-template <typename T, int CT, int TH, int WGC, int NW>
+template <typename T, int CT, int TH, int WGC, int NW, int TPS, int NSW>
 static hipError_t prepare_halo() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<T, CT, TH, WGC, NW>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<T, CT, TH, WGC, NW, TPS, NSW>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
-// configurations: 64 channels x 16x16 patch (8 waves as 1 x 8, two patch rows each);
-//                 128 channels x 16x16 patch (8 waves as 2 x 4, four patch rows each)
-#define CV_FOR_EACH_HALO(X, T) \
-    X(T, 64, 16, 1, 8)         \
-    X(T, 128, 16, 2, 8)
+// configurations: 64 channels x 16x16 patch (8 waves as 1 x 8, two patch rows each), one filter ROW per stage, ring 2;
+//                 128 channels x 16x16 patch (8 waves as 2 x 4, four patch rows each), one tap per stage, ring 3
+#define CV_FOR_EACH_HALO(X, T)   \
+    X(T, 64, 16, 1, 8, 3, 2)     \
+    X(T, 128, 16, 2, 8, 1, 3)
 
 hipError_t conv_halo_prepare() {
     hipError_t e;
-#define X(T, CT, TH, WGC, NW) \
-    if ((e = prepare_halo<T, CT, TH, WGC, NW>()) != hipSuccess) return e;
+#define X(T, CT, TH, WGC, NW, TPS, NSW) \
+    if ((e = prepare_halo<T, CT, TH, WGC, NW, TPS, NSW>()) != hipSuccess) return e;
     CV_FOR_EACH_HALO(X, half_t)
     CV_FOR_EACH_HALO(X, float)
     CV_FOR_EACH_HALO(X, split_t)
@@ -316,8 +338,8 @@ bool conv_halo_supported(int ct, int Ho, int Wo) {
 }
 
 hipError_t conv_halo_launch(int ct, int dt, const ConvParams& p, int n_images, hipStream_t stream) {
-#define X(T, CT, TH, WGC, NW) \
-    if (ct == CT) return launch_halo<T, CT, TH, WGC, NW>(p, n_images, stream);
+#define X(T, CT, TH, WGC, NW, TPS, NSW) \
+    if (ct == CT) return launch_halo<T, CT, TH, WGC, NW, TPS, NSW>(p, n_images, stream);
     if (dt == kF16) { CV_FOR_EACH_HALO(X, half_t) } else if (dt == kSplit) { CV_FOR_EACH_HALO(X, split_t) } else { CV_FOR_EACH_HALO(X, float) }
 #undef X
     return hipErrorInvalidValue;
