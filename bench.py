@@ -49,6 +49,30 @@ def pmc_traffic(dtype, unet_chunk, resnet_chunk, unet_launches, resnet_launches)
     return total / max(1, unet_launches + resnet_launches)
 
 
+def conv_algorithmic_bytes(dtype, unet_chunk, resnet_chunk):
+    """Compulsory HBM bytes of the conv launches of one UNet chunk and one ResNet-18 chunk: every layer's input
+    (+ residual), output and weights moved once at the engine's storage width (f32 4 B, f16 2 B, f16x3 4 B = hi+lo)."""
+    esz = {"f32": 4, "f16": 2, "f16x3": 4}[dtype]
+    def conv(n, hw_out, cin, cout, k=3, stride=1, res=False, out_ch=None):
+        px = n * hw_out * hw_out
+        inp = px * (stride * stride if k == 3 else 1) * cin                  # a strided 1x1 reads every other pixel only
+        return (inp + px * (cout if out_ch is None else out_ch) * (2 if res else 1) + k * k * cin * cout) * esz
+    u, n = [], unet_chunk
+    u += [conv(n, 256, 8, 64), conv(n, 256, 64, 64)]                                   # 3 input channels stored as 8
+    for hw, c in ((128, 64), (64, 128), (32, 256), (16, 512)):
+        u += [conv(n, hw, c, 2 * c), conv(n, hw, 2 * c, 2 * c)]
+    for hw, c in ((32, 1024), (64, 512), (128, 256), (256, 128)):                      # hw = output of the transposed conv
+        u.append((n * (hw // 2) ** 2 * c + n * hw * hw * (c // 2) + 4 * c * (c // 2)) * esz)
+        last = hw == 256
+        u += [conv(n, hw, c, c // 2), conv(n, hw, c // 2, c // 2, out_ch=1 if last else None)]   # fused 1x1 head: 1 channel out
+    r, n = [], resnet_chunk
+    r += [conv(n, 16, 64, 64), conv(n, 16, 64, 64, res=True)] * 2
+    for hw, c in ((8, 64), (4, 128), (2, 256)):
+        r += [conv(n, hw, c, 2 * c, stride=2), conv(n, hw, c, 2 * c, k=1, stride=2), conv(n, hw, 2 * c, 2 * c, res=True),
+              conv(n, hw, 2 * c, 2 * c), conv(n, hw, 2 * c, 2 * c, res=True)]
+    return u, r
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
@@ -204,6 +228,10 @@ def main():
     macs_board = eng.model_macs("unet") + 64 * eng.model_macs("resnet18")
     log(f"  step: {ms_per_step:.2f} ms; event-timed kernels {all_ms:.2f} ms; conv family {conv_ms:.2f} ms over {conv_n} launches")
 
+    ub, rb = conv_algorithmic_bytes(args.dtype, args.unet_chunk, args.resnet_chunk)
+    assert len(ub) * -(-B // args.unet_chunk) + len(rb) * -(-(B * 64) // args.resnet_chunk) == conv_n, (len(ub), len(rb), conv_n)
+    alg_bytes = (sum(ub) * launches["unet"] / len(ub) + sum(rb) * launches["resnet18"] / len(rb)) / conv_n   # per launch, as traffic
+
     result = {
         "metric": "boards/sec (UNet 256x256 seg + 64-sq classify)",
         "value": round(value, 2), "unit": "boards/sec",
@@ -219,12 +247,13 @@ def main():
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                      "frac": round(achieved / peak, 4),
                      "traffic": pmc_traffic(args.dtype, args.unet_chunk, args.resnet_chunk, launches["unet"], launches["resnet18"]),
-                     "kernel": "cv::conv_igemm_kernel (all instantiations)", "launches_per_step": conv_n,
+                     "algorithmic_bytes": alg_bytes,
+                     "kernel": "cv::conv_igemm_kernel + cv::conv3x3_halo_kernel (the conv family, all instantiations)", "launches_per_step": conv_n,
                      "avg_launch_ms": round(conv_ms / max(conv_n, 1), 4), "algorithmic_gflop_per_step": round(conv_flop / 1e9, 2),
                      "mfma_products_per_mac": MFMA_PER_MAC[args.dtype],
                      "mfma_issued_tflops": round(achieved * MFMA_PER_MAC[args.dtype], 2),
                      "frac_of_raw_mfma_peak": round(achieved * MFMA_PER_MAC[args.dtype] / (157.3 if args.dtype == "f32" else 2500.0), 4),
-                     "traffic_unit": "HBM bytes per conv launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)"},
+                     "traffic_unit": "HBM bytes per conv launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json); algorithmic_bytes = compulsory bytes per launch"},
     }
     if world == 1 and not args.no_cpu_baseline:
         nchk = min(B, 64)

@@ -100,6 +100,12 @@ static Status finish_layer(ConvLayer& L, const std::vector<float>& Wk, int K, co
     std::vector<char> packed;
     pack_rows(L.dt, packed, CT, L.nCt, L.nStages, L.rows, K, Wk);
     CV_TRY(L.w.upload(packed.data(), packed.size()));
+    if (CT == 256) {
+        // small launches (single boards, tail chunks) cannot fill the chip with 256x256 workgroups: keep a second copy
+        // packed for 128-row tiles and pick per launch
+        pack_rows(L.dt, packed, 128, L.rows / 128, L.nStages, L.rows, K, Wk);
+        CV_TRY(L.w_small.upload(packed.data(), packed.size()));
+    }
     std::vector<float> sc(L.rowsPad, 0.f), sh(L.rowsPad, 0.f);
     std::memcpy(sc.data(), scale.data(), sizeof(float) * L.rows);
     std::memcpy(sh.data(), shift.data(), sizeof(float) * L.rows);
@@ -304,14 +310,20 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
         if (L.rows != 64 || L.shuffle) return fail(1, L.name + ": the fused 1x1 head needs a 64-channel layer");
         p.head_w = head->w; p.head_b = head->b; p.head_logits = head->logits; p.head_mask = head->mask; p.head_thr = head->thr;
     }
-    const int cfg = choose_cfg(L.ct, L.rows, p.M, L.nStages);
+    int ct = L.ct;
+    if (ct == 256 && blocks_for(L.rows, p.M, 256, 256) < 192) {     // under ~3/4 of a wave of 256x256 workgroups
+        ct = 128;
+        p.w = reinterpret_cast<const char*>(L.w_small.ptr);
+    }
+    const int cfg = choose_cfg(ct, L.rows, p.M, L.nStages);
     const int ns = choose_ns(cfg, dt, L.rows, p.M);
     p.nCt = (L.rows + conv_cfg_ct(cfg) - 1) / conv_cfg_ct(cfg);
     // 3x3 / stride-1 layers whose patch grid divides the image keep the input patch in LDS across the nine taps
     const bool halo = L.k == 3 && L.stride == 1 && !L.shuffle && kbase != nullptr && L.nStages % 9 == 0 &&
-                      env_int("CV_HALO", 1) && conv_halo_supported(L.ct, Ho, Wo);
+                      env_int("CV_HALO", 1) && conv_halo_supported(ct, Ho, Wo) &&
+                      blocks_for(L.rows, p.M, ct, 256) >= 128;        // single boards: 128x128 tiles give more workgroups
     if (profiling) prof_begin(L.name, true, (double)L.macs_per_out_pixel() * (double)p.M, s);
-    hipError_t e = halo ? conv_halo_launch(L.ct, dt, p, x.N, s) : conv_igemm_launch(cfg, ns, dt, p, s);
+    hipError_t e = halo ? conv_halo_launch(ct, dt, p, x.N, s) : conv_igemm_launch(cfg, ns, dt, p, s);
     if (profiling) prof_end(s);
     if (e != hipSuccess) return hip_fail(e, ("conv launch " + L.name).c_str());
     return Status();

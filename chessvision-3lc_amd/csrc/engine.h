@@ -81,6 +81,7 @@ struct ConvLayer {
     int kgroup = 8;                                 // input channels per K block (see engine.cpp: K ordering)
     int dt = kF16;
     DeviceBuffer w, scale, shift;
+    DeviceBuffer w_small;                           // ct == 256 layers only: the same weights packed for 128-row tiles
     // koff tables are geometry dependent: keyed by (xWp, xCs, xCoff)
     struct KoffKey { int xWp, xCs, xCoff; bool operator<(const KoffKey& o) const {
         if (xWp != o.xWp) return xWp < o.xWp; if (xCs != o.xCs) return xCs < o.xCs; return xCoff < o.xCoff; } };

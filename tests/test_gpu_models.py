@@ -137,6 +137,37 @@ def test_resnet18_forward_matches_oracle(prec):
         assert agree >= 0.99
 
 
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_full_chunks_and_small_tail_launches(prec):
+    """Default chunk sizes (32 boards / 8192 squares): the full chunk runs the 256-row tiles and the halo kernel, the
+    one-board / 64-square tail runs the same layers from the 128-row weight packing.  Both must match the oracle."""
+    from chessvision.hip_backend import HipEngine
+
+    unet, resnet = synth.make_unet(seed=1), synth.make_resnet(seed=2)
+    x = synth.unet_input(seed=11, batch=33)
+    sq = synth.squares_input(seed=12, n=8192 + 64)
+    eng = HipEngine(precision=prec)
+    eng.load_unet(unet.state_dict())
+    eng.load_resnet18(resnet.state_dict())
+    out_u = eng.unet_forward(x).cpu()
+    out_r = eng.resnet18_forward(sq).cpu()
+    one = eng.unet_forward(x[5:6]).cpu()                       # the same board alone: small-launch path end to end
+    few = eng.resnet18_forward(sq[100:164]).cpu()
+    eng.close()
+    pick_u = [0, 5, 31, 32]
+    pick_r = list(range(0, 64)) + list(range(8100, 8256))
+    with torch.no_grad():
+        ref_u = unet(x[pick_u])
+        ref_r = resnet(sq[pick_r])
+    err_u = float((out_u[pick_u] - ref_u).abs().max())
+    err_r = float((out_r[pick_r] - ref_r).abs().max())
+    err_one = float((one - ref_u[1:2]).abs().max())
+    with torch.no_grad():
+        err_few = float((few - resnet(sq[100:164])).abs().max())
+    _record("chunks_and_tails", {"prec": prec, "unet": err_u, "resnet18": err_r, "unet_single": err_one, "resnet_64": err_few})
+    assert max(err_u, err_r, err_one, err_few) <= 1e-3, (err_u, err_r, err_one, err_few)
+
+
 def test_u8_entry_points_match_float_path():
     """cv_unet_forward_u8 / cv_resnet18_forward_u8 == float path fed with u8/255 (core.py:215,237)."""
     from chessvision.hip_backend import HipEngine

@@ -22,8 +22,9 @@ def per_dispatch(path, counter):
 def main():
     fetch, write, out, label = sys.argv[1:5]
     f, w = per_dispatch(fetch, "FETCH_SIZE"), per_dispatch(write, "WRITE_SIZE")
-    fc = [v for k, (n, v) in f.items() if "conv_igemm" in n]
-    wc = [v for k, (n, v) in w.items() if "conv_igemm" in n]
+    conv = lambda n: "conv_igemm" in n or "conv3x3_halo" in n      # the two kernels of the conv family
+    fc = [v for k, (n, v) in f.items() if conv(n)]
+    wc = [v for k, (n, v) in w.items() if conv(n)]
     assert len(fc) == len(wc) and fc, (len(fc), len(wc))
     n = len(fc)
     read_b = 2.0 * sum(fc) * 1024 / n          # FETCH_SIZE is in KiB; x2 = gfx950 wide-read correction
