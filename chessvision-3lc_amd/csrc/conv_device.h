@@ -9,6 +9,12 @@ namespace cv {
 #ifndef CV_ABLATE
 #define CV_ABLATE 0       // timing experiments only (wrong results): 1 = no steady-state DMA, 2 = no MFMA
 #endif
+#ifndef CV_STAMP
+#define CV_STAMP 0        // diagnostic build: wave 0 of every workgroup stamps s_memtime / s_memrealtime around the K loop
+#endif
+#ifndef CV_SCHED_HINTS
+#define CV_SCHED_HINTS 1  // conv_halo.hip: interleave the next stage's DMA issue / LDS reads with the tail MFMAs
+#endif
 #ifndef CV_SETPRIO
 #define CV_SETPRIO 1
 #endif

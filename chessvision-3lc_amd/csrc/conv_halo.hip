@@ -26,7 +26,7 @@ namespace cv {
 
 // TPS = taps per stage (1, or 3 = one filter row: fewer, fatter stages for the 64-row tile); NSW = weight ring depth.
 template <typename T, int CT, int TH, int WGC, int NW, int TPS, int NSW>
-__global__ __launch_bounds__(64 * NW) void conv3x3_halo_kernel(const ConvParams p) {
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_halo_kernel(const ConvParams p) {
     static_assert((TPS == 1 || TPS == 3) && (NSW == 2 || NSW == 3), "stage shape");
     constexpr int SPC = 9 / TPS;                        // stages per channel block
     constexpr int WGP = NW / WGC;                       // wave groups along the patch rows
@@ -61,16 +61,11 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_halo_kernel(const ConvParams 
     const int n = pt / tilesY;
     const int nCb = p.nStages / 9, nS = nCb * SPC;       // p.nStages counts (channel block, tap) pairs
 
-    // DMA sources of this lane's halo rows: row r of the halo <-> padded input pixel (ty*TH + r/18, tx*16 + r%18)
-    unsigned hoff[H];
-#pragma unroll
-    for (int i = 0; i < H; ++i) {
-        const int r = (i * NW + wave) * 8 + (lane >> 3);
-        const int rr = r < HR ? r : HR - 1;             // rows of the padded tail re-read the last real one
-        const int hy = rr / 18, hx = rr - hy * 18;
-        hoff[i] = (unsigned)((n * p.xHp + ty * TH + hy) * p.xWp + tx * 16 + hx) * (unsigned)p.xCs * (unsigned)sizeof(T) +
-                  (unsigned)(((lane & 7) ^ (lane >> 3)) * 16);
-    }
+    // DMA sources of this lane's halo rows: row r of the halo <-> padded input pixel (ty*TH + r/18, tx*16 + r%18).
+    // Needed once per channel block only, so they are re-derived at each use (the lane id is made opaque to keep LICM
+    // from parking H more VGPRs across the whole K loop).
+    const unsigned hbase = (unsigned)((n * p.xHp + ty * TH) * p.xWp + tx * 16);
+    const unsigned xpix = (unsigned)p.xCs * (unsigned)sizeof(T);
     const char* const xsrc = p.x + p.xCoffBytes;
     const char* const wsrc = p.w + (size_t)ctTile * p.nStages * WTAP + wave * 1024 + lane * 16;
 
@@ -81,8 +76,16 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_halo_kernel(const ConvParams 
     };
     auto issue_halo = [&](int cb, int hb) {
         char* sH = halo + hb * HBYTES;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
 #pragma unroll
-        for (int i = 0; i < H; ++i) glds16(xsrc + hoff[i] + cb * 128, sH + (i * NW + wave) * 1024);
+        for (int i = 0; i < H; ++i) {
+            const int r = (i * NW + wave) * 8 + (ln >> 3);
+            const int rr = r < HR ? r : HR - 1;         // rows of the padded tail re-read the last real one
+            const int hy = rr / 18, hx = rr - hy * 18;
+            const unsigned off = (hbase + (unsigned)(hy * p.xWp + hx)) * xpix + (unsigned)(((ln & 7) ^ (ln >> 3)) * 16);
+            glds16(xsrc + off + cb * 128, sH + (i * NW + wave) * 1024);
+        }
     };
 
     const int wci = wave / WGP, wpi = wave % WGP;
@@ -100,109 +103,180 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_halo_kernel(const ConvParams 
 #pragma unroll
         for (int g = 0; g < FP; ++g) acc[f][g] = f4{0.f, 0.f, 0.f, 0.f};
 
-    auto compute_tap = [&](auto tap_tag, const char* sW, const char* sH) {
+    // Fragment sets of one stage.  Every precision reads two 16-byte chunks per lane and operand: split-f16 the hi and
+    // the lo chunk of its channel group (products hi.hi, lo.hi, hi.lo), f16 / f32 the two k-halves of the 128-byte line
+    // (products set0.set0, set1.set1).
+    struct Frags { V a[2][FC]; V b[2][FP]; };
+    const int c0 = kSplit16 ? 2 * q + (q & 1) : q;
+    const int c1 = kSplit16 ? 2 * q + 1 - (q & 1) : 4 + q;
+
+    auto load_a = [&](Frags& F, const char* sW) {       // weights: published by the barrier of the previous stage
+#pragma unroll
+        for (int f = 0; f < FC; ++f) F.a[0][f] = *reinterpret_cast<const V*>(sW + rowW + f * 2048 + ((c0 ^ l7) << 4));
+#pragma unroll
+        for (int f = 0; f < FC; ++f) F.a[1][f] = *reinterpret_cast<const V*>(sW + rowW + f * 2048 + ((c1 ^ l7) << 4));
+    };
+    auto load_b = [&](Frags& F, auto tap_tag, const char* sH) {   // pixels: nine shifted views of the resident halo
         constexpr int TAP = decltype(tap_tag)::value;
         constexpr int TOFF = (TAP / 3) * 18 + (TAP % 3);
-        // The halo addresses of all 9 taps x FP rows x {hi, lo} are loop invariant; left alone, LICM keeps ~70 of them
-        // live across the channel-block loop and the 128-row split-f16 tile spills.  Re-deriving them per tap costs a
-        // handful of VALU ops, so make the row base opaque here.
+        // The halo addresses of all 9 taps x FP rows x 2 chunks are loop invariant; left alone, LICM keeps ~70 of them
+        // live across the channel-block loop and the 128-row tile spills.  Re-deriving them per tap costs a handful of
+        // VALU ops, so make the row base opaque here.
         int hrb[FP];
 #pragma unroll
         for (int g = 0; g < FP; ++g) { hrb[g] = hr0[g]; asm volatile("" : "+v"(hrb[g])); }
+#pragma unroll
+        for (int g = 0; g < FP; ++g) {
+            const int hr = hrb[g] + TOFF;
+            F.b[0][g] = *reinterpret_cast<const V*>(sH + hr * 128 + ((c0 ^ (hr & 7)) << 4));
+        }
+#pragma unroll
+        for (int g = 0; g < FP; ++g) {
+            const int hr = hrb[g] + TOFF;
+            F.b[1][g] = *reinterpret_cast<const V*>(sH + hr * 128 + ((c1 ^ (hr & 7)) << 4));
+        }
+    };
+    // first third (split) / half of the stage's MFMAs: needs set 0 only
+    auto mma_head = [&](const Frags& F) {
+#pragma unroll
+        for (int f = 0; f < FC; ++f)
+#pragma unroll
+            for (int g = 0; g < FP; ++g) mma16(acc[f][g], F.a[0][f], F.b[0][g]);
+    };
+    auto mma_tail = [&](const Frags& F) {               // passes over all accumulators: dependent MFMAs stay FC*FP apart
         if constexpr (kSplit16) {
-            const int chi = 2 * q + (q & 1), clo = 2 * q + 1 - (q & 1);
-            V ah[FC], al[FC], bh[FP], bl[FP];
-#pragma unroll
-            for (int f = 0; f < FC; ++f) ah[f] = *reinterpret_cast<const V*>(sW + rowW + f * 2048 + ((chi ^ l7) << 4));
-#pragma unroll
-            for (int g = 0; g < FP; ++g) {
-                const int hr = hrb[g] + TOFF;
-                bh[g] = *reinterpret_cast<const V*>(sH + hr * 128 + ((chi ^ (hr & 7)) << 4));
-            }
-#pragma unroll
-            for (int f = 0; f < FC; ++f) al[f] = *reinterpret_cast<const V*>(sW + rowW + f * 2048 + ((clo ^ l7) << 4));
-#pragma unroll
-            for (int g = 0; g < FP; ++g) {
-                const int hr = hrb[g] + TOFF;
-                bl[g] = *reinterpret_cast<const V*>(sH + hr * 128 + ((clo ^ (hr & 7)) << 4));
-            }
-            if (kSetPrio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int f = 0; f < FC; ++f)
 #pragma unroll
-                for (int g = 0; g < FP; ++g) mma16(acc[f][g], ah[f], bh[g]);
+                for (int g = 0; g < FP; ++g) mma16(acc[f][g], F.a[1][f], F.b[0][g]);
 #pragma unroll
             for (int f = 0; f < FC; ++f)
 #pragma unroll
-                for (int g = 0; g < FP; ++g) {
-                    mma16(acc[f][g], al[f], bh[g]);
-                    mma16(acc[f][g], ah[f], bl[g]);
-                }
-            if (kSetPrio) __builtin_amdgcn_s_setprio(0);
+                for (int g = 0; g < FP; ++g) mma16(acc[f][g], F.a[0][f], F.b[1][g]);
         } else {
 #pragma unroll
-            for (int sub = 0; sub < 2; ++sub) {
-                const int c = sub * 4 + q;
-                V a[FC], b[FP];
+            for (int f = 0; f < FC; ++f)
 #pragma unroll
-                for (int f = 0; f < FC; ++f) a[f] = *reinterpret_cast<const V*>(sW + rowW + f * 2048 + ((c ^ l7) << 4));
-#pragma unroll
-                for (int g = 0; g < FP; ++g) {
-                    const int hr = hrb[g] + TOFF;
-                    b[g] = *reinterpret_cast<const V*>(sH + hr * 128 + ((c ^ (hr & 7)) << 4));
-                }
-#pragma unroll
-                for (int f = 0; f < FC; ++f)
-#pragma unroll
-                    for (int g = 0; g < FP; ++g) mma16(acc[f][g], a[f], b[g]);
-            }
+                for (int g = 0; g < FP; ++g) mma16(acc[f][g], F.a[1][f], F.b[1][g]);
         }
     };
-    // stage J of a channel block covers taps J*TPS .. J*TPS + TPS - 1
-    auto compute = [&](auto j_tag, int wslot, int hb) {
-        constexpr int J = decltype(j_tag)::value;
-        const char* sW = smem + wslot * WSTAGE;
-        const char* sH = halo + hb * HBYTES;
-        compute_tap(std::integral_constant<int, J * TPS>{}, sW, sH);
-        if constexpr (TPS == 3) {
-            compute_tap(std::integral_constant<int, J * TPS + 1>{}, sW + WTAP, sH);
-            compute_tap(std::integral_constant<int, J * TPS + 2>{}, sW + 2 * WTAP, sH);
-        }
-    };
+    constexpr int kMfmaPerMma = __is_same(T, float) ? 4 : 1;
+    constexpr int NTAIL = FC * FP * (kSplit16 ? 2 : 1) * kMfmaPerMma;         // MFMA instructions of the tail
+    constexpr int MPL = (NTAIL - LW) / (2 * FC) > 2 ? 2 : ((NTAIL - LW) / (2 * FC) > 0 ? (NTAIL - LW) / (2 * FC) : 1);
 
-    // ---- main loop: channel blocks x stages ----------------------------------------------------------------
+    // ---- main loop: channel blocks x taps, register double-buffered ----------------------------------------
+    // Stage s = (channel block, tap).  Its fragments were read from LDS during stage s-1, so the MFMA pipe never waits
+    // for the barrier-then-read sequence:
+    //     MFMA head(s)  |  wait W(s+1) landed + barrier  |  DMA W(s+3) (+ next halo at tap 0)  |  ds_read frags(s+1)
+    //     |  MFMA tail(s)                      <- covers the LDS latency of the reads just issued
+    // The barrier of stage s publishes W(s+1) and frees the slot of W(s) (every wave's reads of it completed before
+    // its own lgkmcnt(0) at that barrier).  DMA completes in issue order, so the counted wait may leave in flight
+    // what was issued after W(s+1): W(s+2), and the next halo when it was issued one or two stages ago.
+#if CV_STAMP
+    unsigned long long st_wait = 0, st_head = 0, st_issue = 0, st_tail = 0;
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    static_assert(NSW == 3 && TPS == 1, "the pipelined loop is written for one tap per stage and a 3-deep weight ring");
+    Frags F0, F1;
     issue_halo(0, 0);
     issue_w(0, 0);
-    if (NSW == 3 && nS > 1) issue_w(1, 1);
-    int slotC = 0, slotI = NSW - 1, s = 0;
-    for (int cb = 0; cb < nCb; ++cb) {
-        const int hb = cb & 1;
+    issue_w(1, 1);
+    issue_w(2, 2);
+    wait_vm_barrier<2 * LW>();
+    load_a(F0, smem);
+    load_b(F0, std::integral_constant<int, 0>{}, halo);
+    int s = 0, slot = 0;                                // slot = s % 3
+    auto stage = [&](Frags& cur, Frags& nxt, auto j_tag, auto hb_tag, int cb) {
+        constexpr int J = decltype(j_tag)::value;
+        constexpr int HB = decltype(hb_tag)::value;
         const bool more_cb = cb + 1 < nCb;
-        auto stage = [&](auto j_tag) {
-            constexpr int J = decltype(j_tag)::value;
-            // in flight after W(s): W(s+1) (ring 3 only) and the next halo if it was issued one (or two) stages ago
-            const bool w_next = NSW == 3 && s + 1 < nS;
-            const bool halo_young = (J == 1 || (NSW == 3 && J == 2)) && more_cb;
-            if (w_next && halo_young) wait_vm_barrier<LW + H>();
-            else if (w_next) wait_vm_barrier<LW>();
-            else if (halo_young) wait_vm_barrier<H>();
-            else wait_vm_barrier<0>();
-            if (s + NSW - 1 < nS) issue_w(s + NSW - 1, slotI);
-            if (J == 0 && more_cb) issue_halo(cb + 1, hb ^ 1);
-            compute(j_tag, slotC, hb);
-            slotC = slotC == NSW - 1 ? 0 : slotC + 1;
-            slotI = slotI == NSW - 1 ? 0 : slotI + 1;
-            ++s;
-        };
-        stage(std::integral_constant<int, 0>{}); stage(std::integral_constant<int, 1>{});
-        stage(std::integral_constant<int, 2>{});
-        if constexpr (SPC == 9) {
-            stage(std::integral_constant<int, 3>{}); stage(std::integral_constant<int, 4>{});
-            stage(std::integral_constant<int, 5>{}); stage(std::integral_constant<int, 6>{});
-            stage(std::integral_constant<int, 7>{}); stage(std::integral_constant<int, 8>{});
+#if CV_STAMP
+        const unsigned long long st_0 = __builtin_amdgcn_s_memtime();
+#endif
+        __builtin_amdgcn_sched_barrier(0);              // head MFMAs (they wait for this stage's reads) stay behind the previous tail
+        // the next tap's pixel fragments come from the resident halo: no need to wait for the barrier to read them
+        load_b(nxt, std::integral_constant<int, (J + 1) % 9>{}, halo + (J == 8 ? HB ^ 1 : HB) * HBYTES);
+        mma_head(cur);
+#if CV_SCHED_HINTS
+        // an MFMA first: its wait for the weight fragments (read during the previous tail) is emitted as lgkmcnt(0),
+        // which must not find a fresh read in the queue
+        __builtin_amdgcn_sched_group_barrier(0x008, kMfmaPerMma, 0);
+#pragma unroll
+        for (int i = 0; i < 2 * FP; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);               // one ds_read
+            __builtin_amdgcn_sched_group_barrier(0x008, kMfmaPerMma, 0);
         }
+#endif
+        constexpr bool w_young = true;                  // a weight stage is issued at every barrier (clamped at the end)
+        const bool halo_young = (J == 1 || J == 2) && more_cb;
+#if CV_STAMP
+        const unsigned long long st_a = __builtin_amdgcn_s_memtime();
+#endif
+        __builtin_amdgcn_sched_barrier(0);              // the head MFMAs stay in front of the rendezvous, the tail behind it
+        if (w_young && halo_young) wait_vm_barrier<LW + H>();
+        else if (w_young) wait_vm_barrier<LW>();
+        else if (halo_young) wait_vm_barrier<H>();
+        else wait_vm_barrier<0>();
+        __builtin_amdgcn_sched_barrier(0);
+#if CV_STAMP
+        const unsigned long long st_b = __builtin_amdgcn_s_memtime();
+#endif
+        // One scheduling region from here to the next barrier: no branches around the DMA / LDS reads (the clamped
+        // weight stage and the reads past the last stage are harmless repeats), and the hints below deal the DMA
+        // issues and LDS reads out between the tail MFMAs instead of leaving the matrix pipe idle while both waves
+        // of a SIMD issue them back to back (measured r01: that phase alone was 29 % of the stage).
+        issue_w(s + 3 < nS ? s + 3 : nS - 1, slot);
+        if (J == 0 && more_cb) issue_halo(cb + 1, HB ^ 1);
+        const int nslot = slot == 2 ? 0 : slot + 1;
+        load_a(nxt, smem + nslot * WSTAGE);
+#if CV_STAMP
+        const unsigned long long st_c = __builtin_amdgcn_s_memtime();
+#endif
+        mma_tail(cur);
+#if CV_SCHED_HINTS
+#pragma unroll
+        for (int i = 0; i < LW; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);               // one LDS-DMA (VMEM read)
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);               // one MFMA
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * FC; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);               // one ds_read
+            __builtin_amdgcn_sched_group_barrier(0x008, MPL, 0);
+        }
+#endif
+#if CV_STAMP
+        const unsigned long long st_d = __builtin_amdgcn_s_memtime();
+        st_head += st_a - st_0; st_wait += st_b - st_a; st_issue += st_c - st_b; st_tail += st_d - st_c;
+#endif
+        slot = nslot;
+        ++s;
+    };
+    auto run_cb = [&](auto pb_tag, int cb) {             // PB = parity of the channel block = halo buffer = parity of its tap 0
+        constexpr int PB = decltype(pb_tag)::value;
+        typedef std::integral_constant<int, PB> HBt;
+        Frags& E = PB ? F1 : F0;                         // fragments of even taps
+        Frags& O = PB ? F0 : F1;
+        stage(E, O, std::integral_constant<int, 0>{}, HBt{}, cb); stage(O, E, std::integral_constant<int, 1>{}, HBt{}, cb);
+        stage(E, O, std::integral_constant<int, 2>{}, HBt{}, cb); stage(O, E, std::integral_constant<int, 3>{}, HBt{}, cb);
+        stage(E, O, std::integral_constant<int, 4>{}, HBt{}, cb); stage(O, E, std::integral_constant<int, 5>{}, HBt{}, cb);
+        stage(E, O, std::integral_constant<int, 6>{}, HBt{}, cb); stage(O, E, std::integral_constant<int, 7>{}, HBt{}, cb);
+        stage(E, O, std::integral_constant<int, 8>{}, HBt{}, cb);
+    };
+    for (int cb = 0; cb < nCb; cb += 2) {
+        run_cb(std::integral_constant<int, 0>{}, cb);
+        if (cb + 1 < nCb) run_cb(std::integral_constant<int, 1>{}, cb + 1);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the clamped repeats of the last weight stage are still landing
 
+#if CV_STAMP
+    const unsigned long long st_t1 = __builtin_amdgcn_s_memtime(), st_r1 = __builtin_amdgcn_s_memrealtime();
+    if (p.stamp && lane == 0) {
+        unsigned long long* o = p.stamp + ((size_t)bid * NW + wave) * 8;
+        o[0] = st_t1 - st_t0; o[1] = st_r1 - st_r0; o[2] = st_wait; o[3] = (unsigned long long)nS;
+        o[4] = st_head; o[5] = st_issue; o[6] = st_tail;
+    }
+#endif
     // ---- epilogue (see conv_igemm.hip for the rationale of the staged store) ------------------------------
     constexpr int NV = 4 * FC;
     const int row0 = ctTile * CT + wci * 64 + q * NV;
@@ -313,10 +387,11 @@ static hipError_t prepare_halo() {
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
-// configurations: 64 channels x 16x16 patch (8 waves as 1 x 8, two patch rows each), one filter ROW per stage, ring 2;
+// configurations: 64 channels x 8x16 patch (4 waves, two patch rows each), one tap per stage, ring 3: 72 KB, so two
+//                 workgroups share a CU and fill each other's barrier stalls;
 //                 128 channels x 16x16 patch (8 waves as 2 x 4, four patch rows each), one tap per stage, ring 3
 #define CV_FOR_EACH_HALO(X, T)   \
-    X(T, 64, 16, 1, 8, 3, 2)     \
+    X(T, 64, 8, 1, 4, 1, 3)      \
     X(T, 128, 16, 2, 8, 1, 3)
 
 hipError_t conv_halo_prepare() {
@@ -330,10 +405,10 @@ hipError_t conv_halo_prepare() {
     return hipSuccess;
 }
 
-// The 64-row tile is instantiated and tested (CV_HALO64=1) but measured slower than conv_igemm's 64x256 tile with
-// two workgroups per CU (r01_tuning.md step 14): its 24-MFMA stages are barrier-bound.  Default: 128-row tile only.
+// The 64-row tile (4 waves, 72 KB: two workgroups per CU) beats conv_igemm's 64x256 tile by 5-10 % on the 64-channel
+// layers (r01_tuning.md step 16); CV_HALO64=0 switches it off for A/B runs.
 bool conv_halo_supported(int ct, int Ho, int Wo) {
-    static const bool allow64 = [] { const char* v = std::getenv("CV_HALO64"); return v && v[0] == '1'; }();
+    static const bool allow64 = [] { const char* v = std::getenv("CV_HALO64"); return !(v && v[0] == '0'); }();
     return (ct == 128 || (ct == 64 && allow64)) && Ho % 16 == 0 && Wo % 16 == 0;
 }
 

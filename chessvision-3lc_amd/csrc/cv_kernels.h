@@ -73,6 +73,7 @@ struct ConvParams {
     float* head_logits;
     uint8_t* head_mask;
     float head_thr;
+    unsigned long long* stamp;   // diagnostic builds (-DCV_STAMP=1) only: per-workgroup cycle stamps, else null
 };
 
 }  // namespace cv

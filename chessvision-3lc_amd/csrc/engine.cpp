@@ -1,5 +1,6 @@
 // engine.cpp -- weight packing, device buffers, conv launch plumbing and profiling hooks.
 #include "engine.h"
+#include <algorithm>
 #include "models.h"
 
 #include <cmath>
@@ -322,9 +323,39 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
     const bool halo = L.k == 3 && L.stride == 1 && !L.shuffle && kbase != nullptr && L.nStages % 9 == 0 &&
                       env_int("CV_HALO", 1) && conv_halo_supported(ct, Ho, Wo) &&
                       blocks_for(L.rows, p.M, ct, 256) >= 128;        // single boards: 128x128 tiles give more workgroups
+    // diagnostic (library built with -DCV_STAMP=1, CV_STAMP_LAYER=<layer name>|all): in-kernel cycle stamps of the K loop
+    static const char* const stamp_layer = std::getenv("CV_STAMP_LAYER");
+    unsigned long long* stamp_dev = nullptr;
+    size_t stamp_n = 0;
+    if (halo && stamp_layer && (L.name == stamp_layer || std::string(stamp_layer) == "all")) {
+        stamp_n = ((size_t)p.M / 128 + 1) * (size_t)p.nCt * 8 * 8;
+        if (hipMalloc(&stamp_dev, stamp_n * 8) == hipSuccess) { (void)hipMemsetAsync(stamp_dev, 0, stamp_n * 8, s); p.stamp = stamp_dev; }
+    }
     if (profiling) prof_begin(L.name, true, (double)L.macs_per_out_pixel() * (double)p.M, s);
     hipError_t e = halo ? conv_halo_launch(ct, dt, p, x.N, s) : conv_igemm_launch(cfg, ns, dt, p, s);
     if (profiling) prof_end(s);
+    if (stamp_dev) {
+        std::vector<unsigned long long> h(stamp_n);
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h.data(), stamp_dev, stamp_n * 8, hipMemcpyDeviceToHost);
+        (void)hipFree(stamp_dev);
+        std::vector<double> cyc, clk, wfrac, hd, is, tl;
+        double stages = 0;
+        for (size_t i = 0; i + 7 < stamp_n; i += 8) {
+            if (!h[i + 3] || !h[i + 1]) continue;
+            cyc.push_back((double)h[i]); clk.push_back((double)h[i] / (double)h[i + 1] * 0.1);
+            wfrac.push_back((double)h[i + 2] / (double)h[i]); stages = (double)h[i + 3];
+            hd.push_back((double)h[i + 4] / (double)h[i]); is.push_back((double)h[i + 5] / (double)h[i]);
+            tl.push_back((double)h[i + 6] / (double)h[i]);
+        }
+        if (!cyc.empty()) {
+            auto med = [](std::vector<double>& v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+            auto mean = [](const std::vector<double>& v) { double t = 0; for (double x : v) t += x; return t / (double)v.size(); };
+            const double c = med(cyc), k = med(clk);
+            std::fprintf(stderr, "[stamp] %-40s ct=%d waves=%zu stages=%.0f loop=%.0f cyc (%.1f cyc/stage) clock=%.3f GHz head=%.1f %% wait+barrier=%.1f %% issue=%.1f %% tail=%.1f %%\n",
+                         L.name.c_str(), ct, cyc.size(), stages, c, c / stages, k, 100.0 * mean(hd), 100.0 * mean(wfrac), 100.0 * mean(is), 100.0 * mean(tl));
+        }
+    }
     if (e != hipSuccess) return hip_fail(e, ("conv launch " + L.name).c_str());
     return Status();
 }

@@ -64,6 +64,8 @@ CONV_CASES = [
     ("many_pixels_128x256cfg", 8, 64, 64, 64, 128, 3, 1, True, False),
     ("tile_256x256cfg", 8, 64, 64, 64, 512, 3, 1, True, False),
     ("tile_256x256_residual_tail", 9, 128, 60, 60, 256, 3, 1, True, True),
+    ("resnet_layer1_residual_halo", 128, 64, 16, 16, 64, 3, 1, True, True),
+    ("cin128_c64_halo_4blocks", 8, 128, 64, 64, 64, 3, 1, True, False),
 ]
 
 
