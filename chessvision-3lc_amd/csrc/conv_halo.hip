@@ -37,10 +37,17 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     constexpr int WTAP = CT * 128;                      // weight bytes of one tap
     constexpr int WSTAGE = TPS * WTAP;
     constexpr int HR = 18 * (TH + 2);                   // halo rows (one pixel = one 128-byte LDS row)
-    constexpr int H = ((HR + 7) / 8 + NW - 1) / NW;     // halo DMA wave-instructions per wave (8 rows each)
-    constexpr int HBYTES = H * NW * 1024;
-    constexpr int LW = TPS * CT / (8 * NW);
-    static_assert(LW >= 1 && LW + H <= 63, "vmcnt range");
+    // DMA roles.  With 8 waves, waves w and w + 4 share a SIMD: if both issued their DMA pieces right after the barrier
+    // (each piece costs its wave ~60-100 issue cycles) the matrix pipe of that SIMD would sit idle meanwhile.  So waves
+    // 0..3 move the weight stages and waves 4..7 the halo (two pieces per stage over taps 0..5): on every SIMD one wave
+    // issues DMA while the other already feeds MFMAs.  4-wave workgroups (one wave per SIMD) keep symmetric duties.
+    constexpr bool kRoles = NW == 8;
+    constexpr int NWI = kRoles ? NW / 2 : NW;           // waves sharing one kind of DMA
+    constexpr int H = ((HR + 7) / 8 + NWI - 1) / NWI;   // halo DMA wave-instructions per issuing wave (8 rows each)
+    constexpr int HPS = kRoles ? 2 : H;                 // ... of which per stage (roles: spread over taps 0..5)
+    constexpr int HBYTES = H * NWI * 1024;
+    constexpr int LW = TPS * CT / (8 * NWI);
+    static_assert(LW >= 1 && LW + H <= 63 && (!kRoles || 6 * HPS >= H), "vmcnt range / halo spread");
     constexpr bool kSplit16 = sizeof(T) == 4 && !__is_same(T, float);
     typedef typename FragT<T>::V V;
 
@@ -67,24 +74,28 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const unsigned hbase = (unsigned)((n * p.xHp + ty * TH) * p.xWp + tx * 16);
     const unsigned xpix = (unsigned)p.xCs * (unsigned)sizeof(T);
     const char* const xsrc = p.x + p.xCoffBytes;
-    const char* const wsrc = p.w + (size_t)ctTile * p.nStages * WTAP + wave * 1024 + lane * 16;
+    const bool is_w = !kRoles || wave < NWI;            // this wave moves weight stages / halo pieces
+    const bool is_h = !kRoles || wave >= NWI;
+    const int wi = kRoles && wave >= NWI ? wave - NWI : wave;     // index among the waves of its role
+    const char* const wsrc = p.w + (size_t)ctTile * p.nStages * WTAP + wi * 1024 + lane * 16;
 
     auto issue_w = [&](int s, int slot) {
         char* sW = smem + slot * WSTAGE;
 #pragma unroll
-        for (int i = 0; i < LW; ++i) glds16(wsrc + (size_t)s * WSTAGE + i * (NW * 1024), sW + (i * NW + wave) * 1024);   // stage s = TPS consecutive taps
+        for (int i = 0; i < LW; ++i) glds16(wsrc + (size_t)s * WSTAGE + i * (NWI * 1024), sW + (i * NWI + wi) * 1024);   // stage s = TPS consecutive taps
     };
-    auto issue_halo = [&](int cb, int hb) {
+    auto issue_halo = [&](int cb, int hb, auto i0_tag, auto n_tag) {          // pieces [I0, I0 + N) of this wave's H
+        constexpr int I0 = decltype(i0_tag)::value, N = decltype(n_tag)::value;
         char* sH = halo + hb * HBYTES;
         int ln = lane;
         asm volatile("" : "+v"(ln));
 #pragma unroll
-        for (int i = 0; i < H; ++i) {
-            const int r = (i * NW + wave) * 8 + (ln >> 3);
+        for (int i = I0; i < I0 + N && i < H; ++i) {
+            const int r = (i * NWI + wi) * 8 + (ln >> 3);
             const int rr = r < HR ? r : HR - 1;         // rows of the padded tail re-read the last real one
             const int hy = rr / 18, hx = rr - hy * 18;
-            const unsigned off = (hbase + (unsigned)(hy * p.xWp + hx)) * xpix + (unsigned)(((ln & 7) ^ (ln >> 3)) * 16);
-            glds16(xsrc + off + cb * 128, sH + (i * NW + wave) * 1024);
+            const unsigned off = (hbase + (unsigned)(hy * p.xWp + hx)) * xpix + (unsigned)(((ln & 7) ^ (hx & 7)) * 16);
+            glds16(xsrc + off + cb * 128, sH + (i * NWI + wi) * 1024);
         }
     };
 
@@ -92,9 +103,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const int q = lane >> 4, l15 = lane & 15;
     const int rowW = (wci * 64 + l15) * 128;
     const int wrow0 = wpi * FP;                          // first patch row of this wave
-    int hr0[FP];                                         // halo row of (patch row, pixel l15) for tap (0,0)
-#pragma unroll
-    for (int g = 0; g < FP; ++g) hr0[g] = (wrow0 + g) * 18 + l15;
     const int l7 = lane & 7;
 
     f4 acc[FC][FP];
@@ -110,31 +118,37 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const int c0 = kSplit16 ? 2 * q + (q & 1) : q;
     const int c1 = kSplit16 ? 2 * q + 1 - (q & 1) : 4 + q;
 
-    auto load_a = [&](Frags& F, const char* sW) {       // weights: published by the barrier of the previous stage
+    // LDS read addresses = one VGPR per (chunk set[, filter column]) + an immediate: the weight row of this lane, and
+    // the halo pixel (patch row 0 of this wave, column l15 + kx).  The halo image is XOR-swizzled by the pixel's COLUMN
+    // (hx & 7; all 16 lanes of a fragment read share the halo line, so this is as conflict-free as a row key), which
+    // makes the swizzle independent of the filter row and of the patch row: both are immediates.  The ring slot of
+    // stage s is s % 3 = tap % 3 (nine taps per channel block), an immediate as well.  (r01: the address arithmetic of
+    // the previous layout cost ~35 VALU issues per stage and wave -- the SIMD's vector issue port is shared with the
+    // MFMAs of both resident waves.)
+    int aoff[2], boff[2][3];
+    aoff[0] = rowW + ((c0 ^ l7) << 4);
+    aoff[1] = rowW + ((c1 ^ l7) << 4);
 #pragma unroll
-        for (int f = 0; f < FC; ++f) F.a[0][f] = *reinterpret_cast<const V*>(sW + rowW + f * 2048 + ((c0 ^ l7) << 4));
+    for (int kx = 0; kx < 3; ++kx) {
+        const int col = l15 + kx;
+        boff[0][kx] = NSW * WSTAGE + (wrow0 * 18 + col) * 128 + ((c0 ^ (col & 7)) << 4);
+        boff[1][kx] = NSW * WSTAGE + (wrow0 * 18 + col) * 128 + ((c1 ^ (col & 7)) << 4);
+    }
+    auto load_a = [&](Frags& F, auto slot_tag) {        // weights: published by the barrier of the previous stage
+        constexpr int SLOT = decltype(slot_tag)::value;
 #pragma unroll
-        for (int f = 0; f < FC; ++f) F.a[1][f] = *reinterpret_cast<const V*>(sW + rowW + f * 2048 + ((c1 ^ l7) << 4));
+        for (int f = 0; f < FC; ++f) F.a[0][f] = *reinterpret_cast<const V*>(smem + aoff[0] + (SLOT * WSTAGE + f * 2048));
+#pragma unroll
+        for (int f = 0; f < FC; ++f) F.a[1][f] = *reinterpret_cast<const V*>(smem + aoff[1] + (SLOT * WSTAGE + f * 2048));
     };
-    auto load_b = [&](Frags& F, auto tap_tag, const char* sH) {   // pixels: nine shifted views of the resident halo
+    auto load_b = [&](Frags& F, auto tap_tag, auto hb_tag) {      // pixels: nine shifted views of the resident halo
         constexpr int TAP = decltype(tap_tag)::value;
-        constexpr int TOFF = (TAP / 3) * 18 + (TAP % 3);
-        // The halo addresses of all 9 taps x FP rows x 2 chunks are loop invariant; left alone, LICM keeps ~70 of them
-        // live across the channel-block loop and the 128-row tile spills.  Re-deriving them per tap costs a handful of
-        // VALU ops, so make the row base opaque here.
-        int hrb[FP];
+        constexpr int KY = TAP / 3, KX = TAP % 3;
+        constexpr int BUF = decltype(hb_tag)::value * HBYTES;
 #pragma unroll
-        for (int g = 0; g < FP; ++g) { hrb[g] = hr0[g]; asm volatile("" : "+v"(hrb[g])); }
+        for (int g = 0; g < FP; ++g) F.b[0][g] = *reinterpret_cast<const V*>(smem + boff[0][KX] + (BUF + (g + KY) * (18 * 128)));
 #pragma unroll
-        for (int g = 0; g < FP; ++g) {
-            const int hr = hrb[g] + TOFF;
-            F.b[0][g] = *reinterpret_cast<const V*>(sH + hr * 128 + ((c0 ^ (hr & 7)) << 4));
-        }
-#pragma unroll
-        for (int g = 0; g < FP; ++g) {
-            const int hr = hrb[g] + TOFF;
-            F.b[1][g] = *reinterpret_cast<const V*>(sH + hr * 128 + ((c1 ^ (hr & 7)) << 4));
-        }
+        for (int g = 0; g < FP; ++g) F.b[1][g] = *reinterpret_cast<const V*>(smem + boff[1][KX] + (BUF + (g + KY) * (18 * 128)));
     };
     // first third (split) / half of the stage's MFMAs: needs set 0 only
     auto mma_head = [&](const Frags& F) {
@@ -178,14 +192,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #endif
     static_assert(NSW == 3 && TPS == 1, "the pipelined loop is written for one tap per stage and a 3-deep weight ring");
     Frags F0, F1;
-    issue_halo(0, 0);
-    issue_w(0, 0);
-    issue_w(1, 1);
-    issue_w(2, 2);
-    wait_vm_barrier<2 * LW>();
-    load_a(F0, smem);
-    load_b(F0, std::integral_constant<int, 0>{}, halo);
-    int s = 0, slot = 0;                                // slot = s % 3
+    if (is_h) issue_halo(0, 0, std::integral_constant<int, 0>{}, std::integral_constant<int, H>{});
+    if (is_w) { issue_w(0, 0); issue_w(1, 1); issue_w(2, 2); }
+    if (is_w) wait_vm_barrier<2 * LW>();                // halo(0) and W(0) landed; W(1), W(2) may still fly
+    else wait_vm_barrier<0>();
+    load_a(F0, std::integral_constant<int, 0>{});
+    load_b(F0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    int s = 0;
     auto stage = [&](Frags& cur, Frags& nxt, auto j_tag, auto hb_tag, int cb) {
         constexpr int J = decltype(j_tag)::value;
         constexpr int HB = decltype(hb_tag)::value;
@@ -195,7 +208,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #endif
         __builtin_amdgcn_sched_barrier(0);              // head MFMAs (they wait for this stage's reads) stay behind the previous tail
         // the next tap's pixel fragments come from the resident halo: no need to wait for the barrier to read them
-        load_b(nxt, std::integral_constant<int, (J + 1) % 9>{}, halo + (J == 8 ? HB ^ 1 : HB) * HBYTES);
+#if CV_ABLATE != 3
+        load_b(nxt, std::integral_constant<int, (J + 1) % 9>{}, std::integral_constant<int, (J == 8 ? HB ^ 1 : HB)>{});
+#endif
         mma_head(cur);
 #if CV_SCHED_HINTS
         // an MFMA first: its wait for the weight fragments (read during the previous tail) is emitted as lgkmcnt(0),
@@ -207,16 +222,20 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             __builtin_amdgcn_sched_group_barrier(0x008, kMfmaPerMma, 0);
         }
 #endif
-        constexpr bool w_young = true;                  // a weight stage is issued at every barrier (clamped at the end)
-        const bool halo_young = (J == 1 || J == 2) && more_cb;
+        // vmcnt at the barrier of stage s: W(s+1) must have landed, W(s+2) (issued one stage ago; a weight stage is
+        // issued at every barrier, clamped at the end) may fly.  Symmetric duties: plus the next halo when it was issued
+        // one or two stages ago.  Roles: the halo waves drain theirs at tap 7 (its last pieces leave at tap 5; the
+        // next block's pixel reads start in the head of tap 8).
+        const bool halo_young = !kRoles && (J == 1 || J == 2) && more_cb;
 #if CV_STAMP
         const unsigned long long st_a = __builtin_amdgcn_s_memtime();
 #endif
         __builtin_amdgcn_sched_barrier(0);              // the head MFMAs stay in front of the rendezvous, the tail behind it
-        if (w_young && halo_young) wait_vm_barrier<LW + H>();
-        else if (w_young) wait_vm_barrier<LW>();
-        else if (halo_young) wait_vm_barrier<H>();
-        else wait_vm_barrier<0>();
+        if (kRoles && !is_w) {
+            if (J == 7) wait_vm_barrier<0>();
+            else wait_vm_barrier<63>();
+        } else if (halo_young) wait_vm_barrier<LW + H>();
+        else wait_vm_barrier<LW>();
         __builtin_amdgcn_sched_barrier(0);
 #if CV_STAMP
         const unsigned long long st_b = __builtin_amdgcn_s_memtime();
@@ -225,19 +244,30 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         // weight stage and the reads past the last stage are harmless repeats), and the hints below deal the DMA
         // issues and LDS reads out between the tail MFMAs instead of leaving the matrix pipe idle while both waves
         // of a SIMD issue them back to back (measured r01: that phase alone was 29 % of the stage).
-        issue_w(s + 3 < nS ? s + 3 : nS - 1, slot);
-        if (J == 0 && more_cb) issue_halo(cb + 1, HB ^ 1);
-        const int nslot = slot == 2 ? 0 : slot + 1;
-        load_a(nxt, smem + nslot * WSTAGE);
+#if CV_ABLATE != 1 && CV_ABLATE != 3
+        if constexpr (kRoles) {
+            // un-interleaved on purpose: the other wave of this SIMD covers the matrix pipe meanwhile
+            if (is_w) issue_w(s + 3 < nS ? s + 3 : nS - 1, J % 3);
+            else if (J < 6 && more_cb) issue_halo(cb + 1, HB ^ 1, std::integral_constant<int, J * HPS>{}, std::integral_constant<int, HPS>{});
+        } else {
+            issue_w(s + 3 < nS ? s + 3 : nS - 1, J % 3);
+            if (J == 0 && more_cb) issue_halo(cb + 1, HB ^ 1, std::integral_constant<int, 0>{}, std::integral_constant<int, H>{});
+        }
+#endif
+#if CV_ABLATE != 3
+        load_a(nxt, std::integral_constant<int, (J + 1) % 3>{});
+#endif
 #if CV_STAMP
         const unsigned long long st_c = __builtin_amdgcn_s_memtime();
 #endif
         mma_tail(cur);
 #if CV_SCHED_HINTS
+        if constexpr (!kRoles) {
 #pragma unroll
-        for (int i = 0; i < LW; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);               // one LDS-DMA (VMEM read)
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);               // one MFMA
+            for (int i = 0; i < LW; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);           // one LDS-DMA (VMEM read)
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           // one MFMA
+            }
         }
 #pragma unroll
         for (int i = 0; i < 2 * FC; ++i) {
@@ -249,7 +279,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const unsigned long long st_d = __builtin_amdgcn_s_memtime();
         st_head += st_a - st_0; st_wait += st_b - st_a; st_issue += st_c - st_b; st_tail += st_d - st_c;
 #endif
-        slot = nslot;
         ++s;
     };
     auto run_cb = [&](auto pb_tag, int cb) {             // PB = parity of the channel block = halo buffer = parity of its tap 0
@@ -367,8 +396,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 template <int CT, int TH, int NW, int TPS, int NSW>
 static constexpr size_t halo_lds() {
     constexpr int HR = 18 * (TH + 2);
-    constexpr int H = ((HR + 7) / 8 + NW - 1) / NW;
-    return (size_t)NSW * TPS * CT * 128 + (size_t)2 * H * NW * 1024;
+    constexpr int NWI = NW == 8 ? NW / 2 : NW;          // as in the kernel: waves per DMA role
+    constexpr int H = ((HR + 7) / 8 + NWI - 1) / NWI;
+    return (size_t)NSW * TPS * CT * 128 + (size_t)2 * H * NWI * 1024;
 }
 
 template <typename T, int CT, int TH, int WGC, int NW, int TPS, int NSW>
