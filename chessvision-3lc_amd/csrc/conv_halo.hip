@@ -53,6 +53,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const halo = smem + NSW * WSTAGE;
+#if CV_STAMP
+    const unsigned long long st_k0 = __builtin_amdgcn_s_memtime();
+#endif
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     // its own lgkmcnt(0) at that barrier).  DMA completes in issue order, so the counted wait may leave in flight
     // what was issued after W(s+1): W(s+2), and the next halo when it was issued one or two stages ago.
 #if CV_STAMP
-    unsigned long long st_wait = 0, st_head = 0, st_issue = 0, st_tail = 0;
+    unsigned long long st_wait = 0, st_head = 0, st_tail = 0;
     const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
     static_assert(NSW == 3 && TPS == 1, "the pipelined loop is written for one tap per stage and a 3-deep weight ring");
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #endif
 #if CV_STAMP
         const unsigned long long st_d = __builtin_amdgcn_s_memtime();
-        st_head += st_a - st_0; st_wait += st_b - st_a; st_issue += st_c - st_b; st_tail += st_d - st_c;
+        st_head += st_a - st_0; st_wait += st_b - st_a; st_tail += st_d - st_b; (void)st_c;
 #endif
         ++s;
     };
@@ -303,7 +306,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     if (p.stamp && lane == 0) {
         unsigned long long* o = p.stamp + ((size_t)bid * NW + wave) * 8;
         o[0] = st_t1 - st_t0; o[1] = st_r1 - st_r0; o[2] = st_wait; o[3] = (unsigned long long)nS;
-        o[4] = st_head; o[5] = st_issue; o[6] = st_tail;
+        o[4] = st_head; o[5] = st_t0 - st_k0; o[6] = st_tail;
     }
 #endif
     // ---- epilogue (see conv_igemm.hip for the rationale of the staged store) ------------------------------
@@ -345,6 +348,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 if (p.head_mask) p.head_mask[pix] = (1.f / (1.f + __expf(-l))) > p.head_thr ? 255 : 0;
             }
         }
+#if CV_STAMP
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (p.stamp && lane == 0) p.stamp[((size_t)bid * NW + wave) * 8 + 7] = __builtin_amdgcn_s_memtime() - st_t1;
+#endif
         return;
     }
 
@@ -390,6 +397,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
         asm volatile("" ::: "memory");
     }
+#if CV_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (p.stamp && lane == 0) p.stamp[((size_t)bid * NW + wave) * 8 + 7] = __builtin_amdgcn_s_memtime() - st_t1;
+#endif
 }
 
 // ---- host-side launch -------------------------------------------------------------------------------------
@@ -419,7 +430,8 @@ static hipError_t prepare_halo() {
 
 // configurations: 64 channels x 8x16 patch (4 waves, two patch rows each), one tap per stage, ring 3: 72 KB, so two
 //                 workgroups share a CU and fill each other's barrier stalls;
-//                 128 channels x 16x16 patch (8 waves as 2 x 4, four patch rows each), one tap per stage, ring 3
+//                 128 channels x 16x16 patch (8 waves as 2 x 4, four patch rows each), one tap per stage, ring 3.
+// (An 8-wave 64 x 16x16 variant of the pipelined loop measured 10 % slower than the 4-wave tile, r01_tuning.md step 17.)
 #define CV_FOR_EACH_HALO(X, T)   \
     X(T, 64, 8, 1, 4, 1, 3)      \
     X(T, 128, 16, 2, 8, 1, 3)

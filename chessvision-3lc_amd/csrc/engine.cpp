@@ -339,21 +339,21 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(h.data(), stamp_dev, stamp_n * 8, hipMemcpyDeviceToHost);
         (void)hipFree(stamp_dev);
-        std::vector<double> cyc, clk, wfrac, hd, is, tl;
+        std::vector<double> cyc, clk, wfrac, hd, is, tl, ep;
         double stages = 0;
         for (size_t i = 0; i + 7 < stamp_n; i += 8) {
             if (!h[i + 3] || !h[i + 1]) continue;
             cyc.push_back((double)h[i]); clk.push_back((double)h[i] / (double)h[i + 1] * 0.1);
             wfrac.push_back((double)h[i + 2] / (double)h[i]); stages = (double)h[i + 3];
             hd.push_back((double)h[i + 4] / (double)h[i]); is.push_back((double)h[i + 5] / (double)h[i]);
-            tl.push_back((double)h[i + 6] / (double)h[i]);
+            tl.push_back((double)h[i + 6] / (double)h[i]); ep.push_back((double)h[i + 7]);
         }
         if (!cyc.empty()) {
             auto med = [](std::vector<double>& v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
             auto mean = [](const std::vector<double>& v) { double t = 0; for (double x : v) t += x; return t / (double)v.size(); };
             const double c = med(cyc), k = med(clk);
-            std::fprintf(stderr, "[stamp] %-40s ct=%d waves=%zu stages=%.0f loop=%.0f cyc (%.1f cyc/stage) clock=%.3f GHz head=%.1f %% wait+barrier=%.1f %% issue=%.1f %% tail=%.1f %%\n",
-                         L.name.c_str(), ct, cyc.size(), stages, c, c / stages, k, 100.0 * mean(hd), 100.0 * mean(wfrac), 100.0 * mean(is), 100.0 * mean(tl));
+            std::fprintf(stderr, "[stamp] %-40s ct=%d waves=%zu stages=%.0f loop=%.0f cyc (%.1f cyc/stage) clock=%.3f GHz head=%.1f %% wait+barrier=%.1f %% tail=%.1f %% pre-loop=%.0f cyc epilogue=%.0f cyc\n",
+                         L.name.c_str(), ct, cyc.size(), stages, c, c / stages, k, 100.0 * mean(hd), 100.0 * mean(wfrac), 100.0 * mean(tl), mean(is) * c, mean(ep));
         }
     }
     if (e != hipSuccess) return hip_fail(e, ("conv launch " + L.name).c_str());
