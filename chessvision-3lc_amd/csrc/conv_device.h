@@ -12,6 +12,9 @@ namespace cv {
 #ifndef CV_STAMP
 #define CV_STAMP 0        // diagnostic build: wave 0 of every workgroup stamps s_memtime / s_memrealtime around the K loop
 #endif
+#ifndef CV_IGEMM_PIPE
+#define CV_IGEMM_PIPE 1   // conv_igemm.hip: register-rotating software pipeline (0 = the barrier -> DMA -> reads -> MFMA loop)
+#endif
 #ifndef CV_SCHED_HINTS
 #define CV_SCHED_HINTS 1  // conv_halo.hip: interleave the next stage's DMA issue / LDS reads with the tail MFMAs
 #endif

@@ -131,6 +131,110 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvParams p)
         for (int g = 0; g < FP; ++g) acc[f][g] = f4{0.f, 0.f, 0.f, 0.f};
 
     constexpr bool kSplit16 = sizeof(T) == 4 && !__is_same(T, float);
+    // Two K loops, chosen per launch (wave-uniform): the register-rotating pipeline for the long loops of the f16-MFMA
+    // dtypes, the plain barrier -> DMA -> reads -> MFMA loop for short K (1-tap GEMMs, the 3-channel first layer:
+    // the pipeline's longer prologue costs 4-9 % there) and for f32 (32-cycle MFMAs already cover the bubble; the
+    // per-fragment refill order serialises dependent f32 MFMAs: -15 % on layer2, r01_tuning.md step 18).
+    constexpr bool kPipeType = CV_IGEMM_PIPE != 0 && !__is_same(T, float);
+    if (kPipeType && nS >= 8) {
+    // ---- main loop: register-rotating software pipeline -----------------------------------------------------
+    // The fragments of stage s are in registers when the stage starts (read from LDS during stage s-1), and the MFMAs
+    // run channel-fragment-major: block f = all products of weight fragment f.  A fragment's registers are refilled
+    // with stage s+1 as soon as its last MFMA has been issued -- weight fragment f right after block f, pixel fragment
+    // g inside the last block -- so nothing is double buffered (the 256x256 tile has no registers for that) and
+    // every LDS read has at least a block of MFMAs between issue and use.  The one barrier of the stage sits behind
+    // block 0: it publishes stage s+1 (needed from block 0's refill on) and frees the ring slot of stage s, which
+    // nobody reads during stage s, for the DMA of stage s+NS.  The matrix pipe therefore always has queued work on
+    // both sides of the rendezvous.  (Before r01 step 18 every wave did barrier -> DMA issue -> reads -> MFMAs.)
+    // Per stage and operand two 16-byte chunks per lane: split-f16 the hi and lo chunk of its channel group (products
+    // hi.hi, lo.hi, hi.lo), f16 / f32 the two k-halves of the line (products set0.set0, set1.set1).
+    constexpr int FPH = FP > 4 ? 4 : FP;               // pixel fragments per pass (FP = 8: two passes, bounds VGPR use)
+    constexpr int NP = FP / FPH;
+    struct Frags { V a[2][FC]; V b[2][FPH]; } F;
+    const int c0 = kSplit16 ? 2 * q + (q & 1) : q;
+    const int c1 = kSplit16 ? 2 * q + 1 - (q & 1) : 4 + q;
+    const int swz0 = (c0 ^ (lane & 7)) << 4, swz1 = (c1 ^ (lane & 7)) << 4;
+    auto load_a = [&](int f, int so) {
+        F.a[0][f] = *reinterpret_cast<const V*>(smem + (so + rowW + swz0) + f * 2048);
+        F.a[1][f] = *reinterpret_cast<const V*>(smem + (so + rowW + swz1) + f * 2048);
+    };
+    auto load_b = [&](int g, int gsrc, int so) {        // register slot g <- pixel fragment gsrc of the stage in ring offset so
+        F.b[0][g] = *reinterpret_cast<const V*>(smem + (so + rowX + swz0) + gsrc * 2048);
+        F.b[1][g] = *reinterpret_cast<const V*>(smem + (so + rowX + swz1) + gsrc * 2048);
+    };
+    auto mma_fg = [&](int f, int g, int gacc) {
+        mma16(acc[f][gacc], F.a[0][f], F.b[0][g]);
+        if constexpr (kSplit16) {
+            mma16(acc[f][gacc], F.a[1][f], F.b[0][g]);
+            mma16(acc[f][gacc], F.a[0][f], F.b[1][g]);
+        } else {
+            mma16(acc[f][gacc], F.a[1][f], F.b[1][g]);
+        }
+    };
+    auto block = [&](int f, int ps) {
+#pragma unroll
+        for (int g = 0; g < FPH; ++g) mma_fg(f, g, ps * FPH + g);
+    };
+    static_assert(NS == 2 || NS == 3, "ring depth 2 or 3");
+    issue(0, 0);
+    if (nS > 1) issue(1, 1);
+    if (NS == 3 && nS > 2) issue(2, 2);
+    if (NS == 3 && nS > 2) wait_vm_barrier<2 * L>();
+    else if (nS > 1) wait_vm_barrier<L>();
+    else wait_vm_barrier<0>();
+#pragma unroll
+    for (int f = 0; f < FC; ++f) load_a(f, 0);
+#pragma unroll
+    for (int g = 0; g < FPH; ++g) load_b(g, g, 0);
+    int slotS = 0, slotN = nS > 1 ? 1 : 0;             // ring slots of stage s and stage s+1
+    // one stage; MORE = a next stage exists (its data is published by this stage's barrier and refills the fragments)
+    auto stage = [&](auto more_tag, int s) {
+        constexpr bool MORE = decltype(more_tag)::value;
+        const int soS = slotS * STAGE, soN = slotN * STAGE;
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+            const bool lastp = ps == NP - 1;
+            block(0, ps);
+            if (lastp && MORE) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (NS == 3 && s + 2 < nS) wait_vm_barrier<L>(); else wait_vm_barrier<0>();
+                __builtin_amdgcn_sched_barrier(0);
+                if (s + NS < nS) issue(s + NS, slotS);
+                load_a(0, soN);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int f = 1; f < FC - 1; ++f) {
+                block(f, ps);
+                if (lastp && MORE) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_a(f, soN);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < FPH; ++g) {
+                mma_fg(FC - 1, g, ps * FPH + g);
+                if (!lastp) {                            // next pass of this stage: its pixel fragments, same ring slot
+                    __builtin_amdgcn_sched_barrier(0);  // refill in place: no hoisting over the fragment's last use
+                    load_b(g, (ps + 1) * FPH + g, soS);
+                } else if (MORE) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_b(g, g, soN);
+                }
+            }
+            if (lastp && MORE) {
+                load_a(FC - 1, soN);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    for (int s = 0; s + 1 < nS; ++s) {
+        stage(std::true_type{}, s);
+        slotS = slotN;
+        slotN = slotN == NS - 1 ? 0 : slotN + 1;
+    }
+    stage(std::false_type{}, nS - 1);
+    } else {
     // Stagger (8-wave split-f16 tiles): the two waves sharing a SIMD would otherwise run in lockstep -- both reading
     // LDS, then both queueing on the matrix pipe.  Waves 4-7 ("late") defer the 32 cross-term MFMAs of every stage
     // to the start of the next one (operands stay in registers across the barrier), so they occupy the matrix pipe
@@ -259,6 +363,8 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvParams p)
         else      main_loop(std::integral_constant<int, 1>{});
     } else {
         main_loop(std::integral_constant<int, 1>{});
+    }
+
     }
 
     // ---- epilogue: BN affine (+ residual) (+ ReLU), convert, 16-B NHWC stores -------------------------
