@@ -363,9 +363,15 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     char* const stg = smem + wave * (16 * SROW);
     const int slab0 = ctTile * CT + wci * 64;
+    // fused 2x2 max-pool (UNet encoder): the horizontal partner pixel sits UPP lanes away in the read-back layout, the
+    // vertical one in the next patch row of the same wave (patch rows per wave and their origin are even)
+    static_assert(FP % 2 == 0, "pooling pairs patch rows inside a wave");
+    T* const pbase = reinterpret_cast<T*>(p.pool_y);
+    float hold[UPL][UN];
 #pragma unroll
     for (int g = 0; g < FP; ++g) {
         const unsigned obase = (unsigned)((n * p.yHp + oy0 + g + 1) * p.yWp + ox + 1);
+        const unsigned qbase = (unsigned)((n * p.pHp + ((oy0 + g) >> 1) + 1) * p.pWp + (ox >> 1) + 1);
 #pragma unroll
         for (int f = 0; f < FC; ++f) {
             f4 t;
@@ -393,6 +399,23 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     for (int j = 0; j < UN; ++j) w[j] = w[j] > 0.f ? w[j] : 0.f;
                 }
                 OutVec<T, UN>::store(ybase + (size_t)ob * p.yCs + p.yCoff + co, p.yCoff + co, w);
+            }
+            if (pbase) {                                 // wave-uniform
+                const unsigned qb = __shfl(qbase, px);
+#pragma unroll
+                for (int j = 0; j < UN; ++j) {
+                    const float o = __shfl_xor(w[j], UPP);
+                    w[j] = w[j] > o ? w[j] : o;
+                }
+                if ((g & 1) == 0) {
+#pragma unroll
+                    for (int j = 0; j < UN; ++j) hold[i][j] = w[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < UN; ++j) w[j] = w[j] > hold[i][j] ? w[j] : hold[i][j];
+                    if ((px & 1) == 0 && co < p.rows)
+                        OutVec<T, UN>::store(pbase + (size_t)qb * p.pCs + p.pCoff + co, p.pCoff + co, w);
+                }
             }
         }
         asm volatile("" ::: "memory");

@@ -73,6 +73,10 @@ struct ConvParams {
     float* head_logits;
     uint8_t* head_mask;
     float head_thr;
+    // optional fused 2x2/s2 max-pool of the (post-ReLU) output (conv_halo.hip): a second, pooled PHWC tensor
+    char* pool_y;             // null = no pooled output
+    int pHp, pWp;             // its padded dims (Ho/2 + 2, Wo/2 + 2)
+    int pCs, pCoff;           // its channel stride / first channel
     unsigned long long* stamp;   // diagnostic builds (-DCV_STAMP=1) only: per-workgroup cycle stamps, else null
 };
 

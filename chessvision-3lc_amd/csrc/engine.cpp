@@ -2,6 +2,7 @@
 #include "engine.h"
 #include <algorithm>
 #include "models.h"
+#include "pointwise.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -271,7 +272,7 @@ Engine::Engine() {}
 Engine::~Engine() { prof_clear(); }
 
 Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, const TensorRef* res, bool relu,
-                        hipStream_t s, const Head* head) {
+                        hipStream_t s, const Head* head, const TensorRef* pool_out) {
     if (x.C != L.cinPad) return fail(1, L.name + ": input slice has " + std::to_string(x.C) + " channels, layer packs " + std::to_string(L.cinPad));
     const int esz = dtype_size(dt);
     if (dt == kSplit && (x.Coff % 8 || y.Coff % 8 || (res && res->Coff % 8)))
@@ -323,6 +324,15 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
     const bool halo = L.k == 3 && L.stride == 1 && !L.shuffle && kbase != nullptr && L.nStages % 9 == 0 &&
                       env_int("CV_HALO", 1) && conv_halo_supported(ct, Ho, Wo) &&
                       blocks_for(L.rows, p.M, ct, 256) >= 128;        // single boards: 128x128 tiles give more workgroups
+    const bool fuse_pool = pool_out && halo && !head && env_int("CV_FUSE_POOL", 1);
+    if (pool_out) {
+        if (pool_out->H * 2 != y.H || pool_out->W * 2 != y.W || pool_out->C != y.C || pool_out->N != y.N)
+            return fail(1, L.name + ": pooled output shape mismatch");
+        if (fuse_pool) {
+            p.pool_y = reinterpret_cast<char*>(pool_out->base);
+            p.pHp = pool_out->H + 2; p.pWp = pool_out->W + 2; p.pCs = pool_out->Cs; p.pCoff = pool_out->Coff;
+        }
+    }
     // diagnostic (library built with -DCV_STAMP=1, CV_STAMP_LAYER=<layer name>|all): in-kernel cycle stamps of the K loop
     static const char* const stamp_layer = std::getenv("CV_STAMP_LAYER");
     unsigned long long* stamp_dev = nullptr;
@@ -357,6 +367,12 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
         }
     }
     if (e != hipSuccess) return hip_fail(e, ("conv launch " + L.name).c_str());
+    if (pool_out && !fuse_pool) {
+        if (profiling) prof_begin("maxpool2x2", false, 0, s);
+        e = maxpool2x2(dt, y, *pool_out, s);
+        if (profiling) prof_end(s);
+        if (e != hipSuccess) return hip_fail(e, "maxpool2x2");
+    }
     return Status();
 }
 

@@ -130,8 +130,10 @@ class Engine {
     ~Engine();
 
     struct Head { const float* w; const float* b; float* logits; uint8_t* mask; float thr; };
+    // pool_out: also produce max_pool2d(y, 2) -- fused into the conv epilogue when the halo kernel runs the layer,
+    // otherwise by the stand-alone pooling kernel right after it
     Status run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, const TensorRef* res, bool relu,
-                    hipStream_t s, const Head* head = nullptr);
+                    hipStream_t s, const Head* head = nullptr, const TensorRef* pool_out = nullptr);
     void prof_begin(const std::string& name, bool is_conv, double macs, hipStream_t s);
     void prof_end(hipStream_t s);
     Status prof_collect();

@@ -210,13 +210,14 @@ static Status unet_chunk(Engine& e, const void* x, bool x_u8, int n, float* logi
     else      CV_TRY(timed("pack_nchw_f32", pack_nchw_f32(dt, (const float*)x, 3, U.in8.ref(n, 0, 8), s)));
 
     CV_TRY(e.run_conv(U.inc0, U.in8.ref(n, 0, 8), U.a_inc0.ref(n), nullptr, true, s));
-    CV_TRY(e.run_conv(U.inc1, U.a_inc0.ref(n), U.cat[0].ref(n, 0, 64), nullptr, true, s));
+    // every encoder level's second conv also emits its 2x2 max-pool (fused into the epilogue where the halo kernel runs)
+    const TensorRef pool0 = U.pool[0].ref(n);
+    CV_TRY(e.run_conv(U.inc1, U.a_inc0.ref(n), U.cat[0].ref(n, 0, 64), nullptr, true, s, nullptr, &pool0));
     for (int i = 0; i < 4; ++i) {
-        begin("maxpool2x2");
-        CV_TRY(timed("maxpool2x2", maxpool2x2(dt, U.cat[i].ref(n, 0, enc_c[i]), U.pool[i].ref(n), s)));
         CV_TRY(e.run_conv(U.d[i][0], U.pool[i].ref(n), U.dmid[i].ref(n), nullptr, true, s));
         TensorRef out = (i < 3) ? U.cat[i + 1].ref(n, 0, enc_c[i + 1]) : U.bott.ref(n);
-        CV_TRY(e.run_conv(U.d[i][1], U.dmid[i].ref(n), out, nullptr, true, s));
+        const TensorRef pool_next = (i < 3) ? U.pool[i + 1].ref(n) : TensorRef();
+        CV_TRY(e.run_conv(U.d[i][1], U.dmid[i].ref(n), out, nullptr, true, s, nullptr, i < 3 ? &pool_next : nullptr));
     }
     TensorRef deep = U.bott.ref(n);
     for (int i = 0; i < 4; ++i) {
