@@ -6,9 +6,6 @@
 
 namespace cv {
 
-#ifndef CV_ABLATE
-#define CV_ABLATE 0       // timing experiments only (wrong results): 1 = no steady-state DMA, 2 = no MFMA
-#endif
 #ifndef CV_STAMP
 #define CV_STAMP 0        // diagnostic build: wave 0 of every workgroup stamps s_memtime / s_memrealtime around the K loop
 #endif
@@ -22,17 +19,9 @@ namespace cv {
 #define CV_SETPRIO 1
 #endif
 constexpr bool kSetPrio = CV_SETPRIO != 0;
-#ifndef CV_STAGGER
-#define CV_STAGGER 0      // measured r01: -3 % with the late-wave schedule on (same-box A/B), kept as a build option
-#endif
-constexpr bool kStagger = CV_STAGGER != 0;
 #ifndef CV_ABLATE
 #define CV_ABLATE 0       // timing experiments only (wrong results): 1 = no steady-state DMA, 2 = no MFMA
 #endif
-#ifndef CV_INTERLEAVE
-#define CV_INTERLEAVE 0   // measured r01: -2.5 % (same-box A/B): issuing the prefetch right after the barrier wins
-#endif
-constexpr bool kInterleave = CV_INTERLEAVE != 0;   // deal the next stage's DMA issue out between MFMA clusters
 
 template <typename T> struct FragT;
 template <> struct FragT<half_t> { typedef half8 V; };

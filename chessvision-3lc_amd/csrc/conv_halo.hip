@@ -12,10 +12,10 @@
 // precisions as conv_igemm.hip.  Requirements checked by the host: k = 3, stride 1, one channel block = one 128-byte
 // line (separable offsets), output width a multiple of 16, output height a multiple of TH.
 //
-// Synchronisation: one s_barrier per stage (= channel block x tap).  The weight ring is NSW = 3 deep; the halo is
-// double buffered and the next block's halo is issued at tap 0.  DMA completes in issue order, so the counted
-// s_waitcnt before stage s = (cb, tap) may leave in flight exactly what was issued after W(s): W(s+1), plus the next
-// halo when tap is 1 or 2.
+// K loop: one stage = (channel block, tap), one s_barrier per stage, software pipelined through registers: the
+// fragments of stage s+1 are read while stage s computes (see the comment at the main loop).  The weight ring is 3
+// deep, the halo double buffered; DMA completes in issue order, so the counted s_waitcnt at the barrier of stage s
+// may leave in flight exactly what was issued after W(s+1).
 #include "cv_kernels.h"
 #include "conv_igemm.h"
 #include "conv_device.h"

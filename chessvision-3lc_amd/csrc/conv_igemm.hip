@@ -27,7 +27,8 @@ namespace cv {
 
 // CT x PT = channel x pixel tile of the workgroup (NW waves as WGC x NW/WGC); every wave owns a 64-channel
 // slab (FC = 4 fragments: the row permutation the host packs for) and PT*WGC/NW pixels.  NW = 8 puts two waves
-// of one workgroup on every SIMD: while one is parked on the stage barrier / its LDS reads, the other issues MFMAs.
+// of one workgroup on every SIMD.  Two K loops (see the main-loop comment): a register-rotating software pipeline for
+// long K on the f16-MFMA dtypes, a plain barrier -> prefetch -> reads -> MFMAs loop otherwise.
 // SEP: every stage's 8 K chunks are one contiguous 128-byte line of a pixel (all layers with Cin a multiple of the
 // line), so the gather offset is kbase[stage] + 16 * chunk: the per-stage base comes through the scalar cache and no
 // LDS is spent on the offset table (lets two 80 KB workgroups share a CU).
@@ -80,25 +81,6 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvParams p)
     const char* wsrc = p.w + (size_t)ctTile * nS * (CT * 128) + wave * 1024 + lane * 16;
     __syncthreads();                                    // koffs visible
 
-    // gather offset of this lane's K chunk in stage s
-    auto stage_koff = [&](int s) -> int {
-        if constexpr (SEP) {
-            typedef const __attribute__((address_space(4))) int* cptr_t;     // scalar-cache load, see `issue`
-            return reinterpret_cast<cptr_t>(reinterpret_cast<uintptr_t>(p.kbase))[s] + myChunk * 16;
-        } else {
-            return koffs[s * 8 + myChunk];
-        }
-    };
-    // DMA instruction j (0 .. L-1) of stage s: the first LW fetch weights, the rest activations.  Issued one by one
-    // from inside the MFMA clusters (kInterleave) so that their issue cost (~60-180 cycles each) is not serialised
-    // behind the stage barrier in every wave at once.
-    auto issue_one = [&](int s, int buf, int ko, int j) {
-        char* sW = smem + buf * STAGE;
-        char* sX = sW + CT * 128;
-        if (j < LW) glds16(wsrc + (size_t)s * (CT * 128) + j * (NW * 1024), sW + (j * NW + wave) * 1024);
-        else        glds16(p.x + xoff[j - LW] + ko, sX + ((j - LW) * NW + wave) * 1024);
-    };
-
     auto issue = [&](int s, int buf) {
         char* sW = smem + buf * STAGE;
         char* sX = sW + CT * 128;
@@ -122,7 +104,6 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvParams p)
     const int q = lane >> 4, l15 = lane & 15;
     const int rowW = (wci * WCT + l15) * 128;
     const int rowX = CT * 128 + (wpi * WPT + l15) * 128;
-    const int sw0 = (q ^ (lane & 7)) * 16;              // chunk (0*4+q) of a row with (row&7)==(lane&7)
 
     f4 acc[FC][FP];
 #pragma unroll
@@ -131,12 +112,11 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvParams p)
         for (int g = 0; g < FP; ++g) acc[f][g] = f4{0.f, 0.f, 0.f, 0.f};
 
     constexpr bool kSplit16 = sizeof(T) == 4 && !__is_same(T, float);
+    static_assert(NS == 2 || NS == 3, "ring depth 2 or 3");
     // Two K loops, chosen per launch (wave-uniform): the register-rotating pipeline for the long loops of the f16-MFMA
     // dtypes, the plain barrier -> DMA -> reads -> MFMA loop for short K (1-tap GEMMs, the 3-channel first layer:
     // the pipeline's longer prologue costs 4-9 % there) and for f32 (32-cycle MFMAs already cover the bubble; the
     // per-fragment refill order serialises dependent f32 MFMAs: -15 % on layer2, r01_tuning.md step 18).
-    constexpr bool kPipeType = CV_IGEMM_PIPE != 0 && !__is_same(T, float);
-    if (kPipeType && nS >= 8) {
     // ---- main loop: register-rotating software pipeline -----------------------------------------------------
     // The fragments of stage s are in registers when the stage starts (read from LDS during stage s-1), and the MFMAs
     // run channel-fragment-major: block f = all products of weight fragment f.  A fragment's registers are refilled
@@ -175,7 +155,8 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvParams p)
 #pragma unroll
         for (int g = 0; g < FPH; ++g) mma_fg(f, g, ps * FPH + g);
     };
-    static_assert(NS == 2 || NS == 3, "ring depth 2 or 3");
+    constexpr bool kPipeType = CV_IGEMM_PIPE != 0 && !__is_same(T, float);
+    if (kPipeType && nS >= 8) {
     issue(0, 0);
     if (nS > 1) issue(1, 1);
     if (NS == 3 && nS > 2) issue(2, 2);
@@ -235,103 +216,31 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvParams p)
     }
     stage(std::false_type{}, nS - 1);
     } else {
-    // Stagger (8-wave split-f16 tiles): the two waves sharing a SIMD would otherwise run in lockstep -- both reading
-    // LDS, then both queueing on the matrix pipe.  Waves 4-7 ("late") defer the 32 cross-term MFMAs of every stage
-    // to the start of the next one (operands stay in registers across the barrier), so they occupy the matrix pipe
-    // exactly while waves 0-3 issue their DMA and fragment reads, and read their own fragments while waves 0-3
-    // compute.  Same products, same accumulation targets; only the order of additions into an accumulator differs.
-    const bool late = kSplit16 && NW == 8 && kStagger && wave >= 4;
-
-    // split-f16 fragment state (persists across iterations for the late waves)
-    constexpr int FPH = FP > 4 ? 4 : FP;               // pixel fragments processed per pass (bounds VGPR use at FP = 8)
-    V ah[FC], al[FC], bh[FPH], bl[FPH];
-    const int chi = 2 * q + (q & 1), clo = 2 * q + 1 - (q & 1);   // lane group q: hi chunk / lo chunk of K-group q
-    const int swh = (chi ^ (lane & 7)) * 16, swl = (clo ^ (lane & 7)) * 16;
-    int g0 = 0;                                          // first pixel fragment of the current pass
-    auto load_split_a = [&](int buf) {
-        const char* s = smem + buf * STAGE;
+        // plain loop: barrier -> prefetch of a later stage -> fragment reads -> MFMAs
+        auto compute = [&](int so) {
 #pragma unroll
-        for (int f = 0; f < FC; ++f) ah[f] = *reinterpret_cast<const V*>(s + rowW + f * 2048 + swh);
+            for (int f = 0; f < FC; ++f) load_a(f, so);
 #pragma unroll
-        for (int f = 0; f < FC; ++f) al[f] = *reinterpret_cast<const V*>(s + rowW + f * 2048 + swl);
-    };
-    auto load_split_b = [&](int buf, int gbase) {
-        const char* s = smem + buf * STAGE;
+            for (int ps = 0; ps < NP; ++ps) {
 #pragma unroll
-        for (int g = 0; g < FPH; ++g) bh[g] = *reinterpret_cast<const V*>(s + rowX + (gbase + g) * 2048 + swh);
+                for (int g = 0; g < FPH; ++g) load_b(g, ps * FPH + g, so);
+                if (kSetPrio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int g = 0; g < FPH; ++g) bl[g] = *reinterpret_cast<const V*>(s + rowX + (gbase + g) * 2048 + swl);
-    };
-    auto load_split = [&](int buf) { load_split_a(buf); load_split_b(buf, 0); };
-    auto lead = [&]() {                                  // hi*hi: needs only the hi fragments
-        if (kSetPrio) __builtin_amdgcn_s_setprio(1);
+                for (int f = 0; f < FC; ++f)             // first the products that need only the first chunk of each row
 #pragma unroll
-        for (int f = 0; f < FC; ++f)
+                    for (int g = 0; g < FPH; ++g) mma16(acc[f][ps * FPH + g], F.a[0][f], F.b[0][g]);
 #pragma unroll
-            for (int g = 0; g < FPH; ++g) mma16(acc[f][g0 + g], ah[f], bh[g]);
-        if (kSetPrio) __builtin_amdgcn_s_setprio(0);
-    };
-    // lo*hi + hi*lo; with a pending stage (sn >= 0) its L DMA instructions are dealt out between the FC row groups
-    auto cross = [&](int sn, int bufn) {
-        const int ko = sn >= 0 ? stage_koff(sn) : 0;
+                for (int f = 0; f < FC; ++f)
 #pragma unroll
-        for (int f = 0; f < FC; ++f) {
-            if (sn >= 0) {
-#pragma unroll
-                for (int j = f * L / FC; j < (f + 1) * L / FC; ++j) issue_one(sn, bufn, ko, j);
-            }
-            if (kSetPrio) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int g = 0; g < FPH; ++g) {
-                mma16(acc[f][g0 + g], al[f], bh[g]);
-                mma16(acc[f][g0 + g], ah[f], bl[g]);
-            }
-            if (kSetPrio) __builtin_amdgcn_s_setprio(0);
-        }
-    };
-
-    auto compute_plain = [&](int buf) {                  // f16 / f32: two k-steps per stage
-        const char* s = smem + buf * STAGE;
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            const int sw = sw0 ^ (sub * 64);
-            V a[FC], b[FP];
-#pragma unroll
-            for (int f = 0; f < FC; ++f) a[f] = *reinterpret_cast<const V*>(s + rowW + f * 2048 + sw);
-#pragma unroll
-            for (int g = 0; g < FP; ++g) b[g] = *reinterpret_cast<const V*>(s + rowX + g * 2048 + sw);
-#pragma unroll
-            for (int f = 0; f < FC; ++f)
-#pragma unroll
-                for (int g = 0; g < FP; ++g) mma16(acc[f][g], a[f], b[g]);
-        }
-    };
-
-    // The main loop exists twice (wave-uniform branch) so that each copy is straight-line code for the register
-    // allocator: MODE 0 = plain dtypes, 1 = split-f16 in stage order, 2 = split-f16 late waves (cross terms deferred).
-    auto main_loop = [&](auto mode_tag) {
-        constexpr int MODE = decltype(mode_tag)::value;
-        // body(buf, t, sn, bufn): compute stage t from ring slot buf; sn/bufn = stage to prefetch now (or -1)
-        auto body = [&](int buf, int t, int sn, int bufn) {
-            if constexpr (MODE == 0) {
-                if (sn >= 0) issue(sn, bufn);
-                compute_plain(buf);
-            } else if constexpr (MODE == 1) {
-                if constexpr (FP > 4) {                  // two passes over the pixel fragments (64ch x 128px wave tile)
-                    if (sn >= 0) issue(sn, bufn);
-                    load_split_a(buf);
-                    load_split_b(buf, 0);
-                    g0 = 0; lead(); cross(-1, 0);
-                    load_split_b(buf, 4);
-                    g0 = 4; lead(); cross(-1, 0);
-                    g0 = 0;
-                } else if constexpr (kInterleave) { load_split(buf); lead(); cross(sn, bufn); }
-                else { if (sn >= 0) issue(sn, bufn); load_split(buf); lead(); cross(-1, 0); }
-            } else {
-                if (sn >= 0) issue(sn, bufn);
-                if (t > 0) cross(-1, 0);
-                load_split(buf);
-                lead();
+                    for (int g = 0; g < FPH; ++g) {
+                        if constexpr (kSplit16) {
+                            mma16(acc[f][ps * FPH + g], F.a[1][f], F.b[0][g]);
+                            mma16(acc[f][ps * FPH + g], F.a[0][f], F.b[1][g]);
+                        } else {
+                            mma16(acc[f][ps * FPH + g], F.a[1][f], F.b[1][g]);
+                        }
+                    }
+                if (kSetPrio) __builtin_amdgcn_s_setprio(0);
             }
         };
         if constexpr (NS == 2) {
@@ -339,32 +248,22 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvParams p)
             int buf = 0;
             for (int t = 0; t < nS; ++t) {
                 wait_vm_barrier<0>();
-                body(buf, t, (CV_ABLATE != 1 && t + 1 < nS) ? t + 1 : -1, buf ^ 1);
+                if (CV_ABLATE != 1 && t + 1 < nS) issue(t + 1, buf ^ 1);
+                compute(buf * STAGE);
                 buf ^= 1;
             }
         } else {
-            static_assert(NS == 3, "ring depth 2 or 3");
             issue(0, 0);
             if (nS > 1) issue(1, 1);
             int bufC = 0, bufI = 2;
             for (int t = 0; t < nS; ++t) {
                 if (t + 1 < nS) wait_vm_barrier<L>(); else wait_vm_barrier<0>();
-                body(bufC, t, (CV_ABLATE != 1 && t + 2 < nS) ? t + 2 : -1, bufI);
+                if (CV_ABLATE != 1 && t + 2 < nS) issue(t + 2, bufI);
+                compute(bufC * STAGE);
                 bufC = bufC == 2 ? 0 : bufC + 1;
                 bufI = bufI == 2 ? 0 : bufI + 1;
             }
         }
-        if constexpr (MODE == 2) cross(-1, 0);           // the last stage's deferred cross terms
-    };
-    if constexpr (!kSplit16) {
-        main_loop(std::integral_constant<int, 0>{});
-    } else if constexpr (NW == 8 && kStagger) {
-        if (late) main_loop(std::integral_constant<int, 2>{});
-        else      main_loop(std::integral_constant<int, 1>{});
-    } else {
-        main_loop(std::integral_constant<int, 1>{});
-    }
-
     }
 
     // ---- epilogue: BN affine (+ residual) (+ ReLU), convert, 16-B NHWC stores -------------------------
