@@ -25,7 +25,10 @@
 namespace cv {
 
 // TPS = taps per stage (1, or 3 = one filter row: fewer, fatter stages for the 64-row tile); NSW = weight ring depth.
-template <typename T, int CT, int TH, int WGC, int NW, int TPS, int NSW>
+// IMG = 0: one TH x 16 patch of one (large) image per workgroup.  IMG = 8: feature maps of 8 x 8 (ResNet layer2): the
+// 16 x 16 pixel tile is four whole images (2 x 2), whose zero-bordered 10 x 10 PHWC planes are contiguous in memory, so
+// the "halo" is simply 400 consecutive pixels and a fragment's 16 lanes read row y of two neighbouring images.
+template <typename T, int CT, int TH, int WGC, int NW, int TPS, int NSW, int IMG>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_halo_kernel(const ConvParams p) {
     static_assert((TPS == 1 || TPS == 3) && (NSW == 2 || NSW == 3), "stage shape");
     constexpr int SPC = 9 / TPS;                        // stages per channel block
@@ -36,7 +39,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     static_assert(FP >= 1 && FP <= 4 && TH % WGP == 0, "wave tile");
     constexpr int WTAP = CT * 128;                      // weight bytes of one tap
     constexpr int WSTAGE = TPS * WTAP;
-    constexpr int HR = 18 * (TH + 2);                   // halo rows (one pixel = one 128-byte LDS row)
+    static_assert(IMG == 0 || (IMG == 8 && TH == 16), "packed-image mode: 2 x 2 images of 8 x 8");
+    constexpr int HLW = IMG ? IMG + 2 : 18;             // pixels per halo line
+    constexpr int HR = IMG ? 4 * HLW * HLW : 18 * (TH + 2);   // halo rows (one pixel = one 128-byte LDS row)
     // DMA roles.  With 8 waves, waves w and w + 4 share a SIMD: if both issued their DMA pieces right after the barrier
     // (each piece costs its wave ~60-100 issue cycles) the matrix pipe of that SIMD would sit idle meanwhile.  So waves
     // 0..3 move the weight stages and waves 4..7 the halo (two pieces per stage over taps 0..5): on every SIMD one wave
@@ -44,7 +49,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     constexpr bool kRoles = NW == 8;
     constexpr int NWI = kRoles ? NW / 2 : NW;           // waves sharing one kind of DMA
     constexpr int H = ((HR + 7) / 8 + NWI - 1) / NWI;   // halo DMA wave-instructions per issuing wave (8 rows each)
-    constexpr int HPS = kRoles ? 2 : H;                 // ... of which per stage (roles: spread over taps 0..5)
+    constexpr int HPS = kRoles ? (H + 5) / 6 : H;       // ... of which per stage (roles: spread over taps 0..5)
     constexpr int HBYTES = H * NWI * 1024;
     constexpr int LW = TPS * CT / (8 * NWI);
     static_assert(LW >= 1 && LW + H <= 63 && (!kRoles || 6 * HPS >= H), "vmcnt range / halo spread");
@@ -65,10 +70,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const unsigned lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
     const int ctTile = lid % p.nCt;
     int pt = lid / p.nCt;
-    const int tilesX = p.Wo / 16, tilesY = p.Ho / TH;
+    const int tilesX = IMG ? 1 : p.Wo / 16, tilesY = IMG ? 1 : p.Ho / TH;
     const int tx = pt % tilesX; pt /= tilesX;
     const int ty = pt % tilesY;
-    const int n = pt / tilesY;
+    const int n = IMG ? 4 * (pt / tilesY) : pt / tilesY;            // (first) image of this workgroup
+    const int nImg = p.M / (p.Ho * p.Wo);
     const int nCb = p.nStages / 9, nS = nCb * SPC;       // p.nStages counts (channel block, tap) pairs
 
     // DMA sources of this lane's halo rows: row r of the halo <-> padded input pixel (ty*TH + r/18, tx*16 + r%18).
@@ -96,8 +102,16 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         for (int i = I0; i < I0 + N && i < H; ++i) {
             const int r = (i * NWI + wi) * 8 + (ln >> 3);
             const int rr = r < HR ? r : HR - 1;         // rows of the padded tail re-read the last real one
-            const int hy = rr / 18, hx = rr - hy * 18;
-            const unsigned off = (hbase + (unsigned)(hy * p.xWp + hx)) * xpix + (unsigned)(((ln & 7) ^ (hx & 7)) * 16);
+            unsigned off;
+            if constexpr (IMG == 0) {
+                const int hy = rr / 18, hx = rr - hy * 18;
+                off = (hbase + (unsigned)(hy * p.xWp + hx)) * xpix + (unsigned)(((ln & 7) ^ (hx & 7)) * 16);
+            } else {                                     // 400 consecutive pixels; images past the batch re-read the last one
+                const int lim = (nImg - n) * (HLW * HLW) - 1;
+                const int rc = rr < lim ? rr : lim;
+                const int hx = (rr % (HLW * HLW)) % HLW;
+                off = (unsigned)(n * (HLW * HLW) + rc) * xpix + (unsigned)(((ln & 7) ^ (hx & 7)) * 16);
+            }
             glds16(xsrc + off + cb * 128, sH + (i * NWI + wi) * 1024);
         }
     };
@@ -133,9 +147,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     aoff[1] = rowW + ((c1 ^ l7) << 4);
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
-        const int col = l15 + kx;
-        boff[0][kx] = NSW * WSTAGE + (wrow0 * 18 + col) * 128 + ((c0 ^ (col & 7)) << 4);
-        boff[1][kx] = NSW * WSTAGE + (wrow0 * 18 + col) * 128 + ((c1 ^ (col & 7)) << 4);
+        // halo row of (first patch row of this wave, pixel l15) for filter column kx, and its swizzle key (the column)
+        const int col = IMG ? (l15 & 7) + kx : l15 + kx;
+        const int row = IMG ? ((wrow0 >> 3) * 2 + (l15 >> 3)) * (HLW * HLW) + (wrow0 & 7) * HLW + col : wrow0 * 18 + col;
+        boff[0][kx] = NSW * WSTAGE + row * 128 + ((c0 ^ (col & 7)) << 4);
+        boff[1][kx] = NSW * WSTAGE + row * 128 + ((c1 ^ (col & 7)) << 4);
     }
     auto load_a = [&](Frags& F, auto slot_tag) {        // weights: published by the barrier of the previous stage
         constexpr int SLOT = decltype(slot_tag)::value;
@@ -149,9 +165,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         constexpr int KY = TAP / 3, KX = TAP % 3;
         constexpr int BUF = decltype(hb_tag)::value * HBYTES;
 #pragma unroll
-        for (int g = 0; g < FP; ++g) F.b[0][g] = *reinterpret_cast<const V*>(smem + boff[0][KX] + (BUF + (g + KY) * (18 * 128)));
+        for (int g = 0; g < FP; ++g) F.b[0][g] = *reinterpret_cast<const V*>(smem + boff[0][KX] + (BUF + (g + KY) * (HLW * 128)));
 #pragma unroll
-        for (int g = 0; g < FP; ++g) F.b[1][g] = *reinterpret_cast<const V*>(smem + boff[1][KX] + (BUF + (g + KY) * (18 * 128)));
+        for (int g = 0; g < FP; ++g) F.b[1][g] = *reinterpret_cast<const V*>(smem + boff[1][KX] + (BUF + (g + KY) * (HLW * 128)));
     };
     // first third (split) / half of the stage's MFMAs: needs set 0 only
     auto mma_head = [&](const Frags& F) {
@@ -322,7 +338,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
     T* const ybase = reinterpret_cast<T*>(p.y);
     const T* const rbase = reinterpret_cast<const T*>(p.res);
-    const int oy0 = ty * TH + wrow0, ox = tx * 16 + l15;
+    // output pixel of (patch row wrow0 + g, lane l15): image, row origin, column
+    const int oimg = IMG ? n + (wrow0 >> 3) * 2 + (l15 >> 3) : n;
+    const int oy0 = IMG ? (wrow0 & 7) : ty * TH + wrow0, ox = IMG ? (l15 & 7) : tx * 16 + l15;
+    const bool olive = oimg < nImg;
 
     if (p.head_w) {                                      // fused OutConv, as in conv_igemm.hip
         float hw[NV];
@@ -342,7 +361,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             part += __shfl_xor(part, 16);
             part += __shfl_xor(part, 32);
             if (q == 0) {
-                const size_t pix = ((size_t)n * p.Ho + oy0 + g) * p.Wo + ox;
+                const size_t pix = ((size_t)oimg * p.Ho + oy0 + g) * p.Wo + ox;
                 const float l = part + p.head_b[0];
                 p.head_logits[pix] = l;
                 if (p.head_mask) p.head_mask[pix] = (1.f / (1.f + __expf(-l))) > p.head_thr ? 255 : 0;
@@ -370,8 +389,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     float hold[UPL][UN];
 #pragma unroll
     for (int g = 0; g < FP; ++g) {
-        const unsigned obase = (unsigned)((n * p.yHp + oy0 + g + 1) * p.yWp + ox + 1);
-        const unsigned qbase = (unsigned)((n * p.pHp + ((oy0 + g) >> 1) + 1) * p.pWp + (ox >> 1) + 1);
+        const unsigned obase = (unsigned)((oimg * p.yHp + oy0 + g + 1) * p.yWp + ox + 1);
+        const unsigned qbase = (unsigned)((oimg * p.pHp + ((oy0 + g) >> 1) + 1) * p.pWp + (ox >> 1) + 1);
+        const int plive = olive ? 1 : 0;
 #pragma unroll
         for (int f = 0; f < FC; ++f) {
             f4 t;
@@ -392,7 +412,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             }
             const unsigned ob = __shfl(obase, px);
             const int co = slab0 + cu * UN;
-            if (co < p.rows) {
+            if (co < p.rows && (IMG == 0 || __shfl(plive, px))) {
                 if (rbase) OutVec<T, UN>::add(rbase + (size_t)ob * p.rCs + p.rCoff + co, p.rCoff + co, w);
                 if (p.relu) {
 #pragma unroll
@@ -427,42 +447,44 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 }
 
 // ---- host-side launch -------------------------------------------------------------------------------------
-template <int CT, int TH, int NW, int TPS, int NSW>
+template <int CT, int TH, int NW, int TPS, int NSW, int IMG>
 static constexpr size_t halo_lds() {
-    constexpr int HR = 18 * (TH + 2);
+    constexpr int HR = IMG ? 4 * (IMG + 2) * (IMG + 2) : 18 * (TH + 2);
     constexpr int NWI = NW == 8 ? NW / 2 : NW;          // as in the kernel: waves per DMA role
     constexpr int H = ((HR + 7) / 8 + NWI - 1) / NWI;
     return (size_t)NSW * TPS * CT * 128 + (size_t)2 * H * NWI * 1024;
 }
 
-template <typename T, int CT, int TH, int WGC, int NW, int TPS, int NSW>
+template <typename T, int CT, int TH, int WGC, int NW, int TPS, int NSW, int IMG>
 static hipError_t launch_halo(const ConvParams& p, int n_images, hipStream_t stream) {
-    const int tiles = n_images * (p.Ho / TH) * (p.Wo / 16);
-    auto kern = conv3x3_halo_kernel<T, CT, TH, WGC, NW, TPS, NSW>;
-    const size_t lds = halo_lds<CT, TH, NW, TPS, NSW>();
-    static_assert(halo_lds<CT, TH, NW, TPS, NSW>() <= 160 * 1024, "LDS budget");
+    const int tiles = IMG ? (n_images + 3) / 4 : n_images * (p.Ho / TH) * (p.Wo / 16);
+    auto kern = conv3x3_halo_kernel<T, CT, TH, WGC, NW, TPS, NSW, IMG>;
+    const size_t lds = halo_lds<CT, TH, NW, TPS, NSW, IMG>();
+    static_assert(halo_lds<CT, TH, NW, TPS, NSW, IMG>() <= 160 * 1024, "LDS budget");
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * p.nCt)), dim3(64 * NW), lds, stream, p);
     return hipGetLastError();
 }
 
-template <typename T, int CT, int TH, int WGC, int NW, int TPS, int NSW>
+template <typename T, int CT, int TH, int WGC, int NW, int TPS, int NSW, int IMG>
 static hipError_t prepare_halo() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<T, CT, TH, WGC, NW, TPS, NSW>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<T, CT, TH, WGC, NW, TPS, NSW, IMG>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 // configurations: 64 channels x 8x16 patch (4 waves, two patch rows each), one tap per stage, ring 3: 72 KB, so two
 //                 workgroups share a CU and fill each other's barrier stalls;
-//                 128 channels x 16x16 patch (8 waves as 2 x 4, four patch rows each), one tap per stage, ring 3.
+//                 128 channels x 16x16 patch (8 waves as 2 x 4, four patch rows each), one tap per stage, ring 3;
+//                 the same 128-channel tile over four packed 8x8 images (ResNet-18 layer2).
 // (An 8-wave 64 x 16x16 variant of the pipelined loop measured 10 % slower than the 4-wave tile, r01_tuning.md step 17.)
 #define CV_FOR_EACH_HALO(X, T)   \
-    X(T, 64, 8, 1, 4, 1, 3)      \
-    X(T, 128, 16, 2, 8, 1, 3)
+    X(T, 64, 8, 1, 4, 1, 3, 0)   \
+    X(T, 128, 16, 2, 8, 1, 3, 0) \
+    X(T, 128, 16, 2, 8, 1, 3, 8)
 
 hipError_t conv_halo_prepare() {
     hipError_t e;
-#define X(T, CT, TH, WGC, NW, TPS, NSW) \
-    if ((e = prepare_halo<T, CT, TH, WGC, NW, TPS, NSW>()) != hipSuccess) return e;
+#define X(T, CT, TH, WGC, NW, TPS, NSW, IMG) \
+    if ((e = prepare_halo<T, CT, TH, WGC, NW, TPS, NSW, IMG>()) != hipSuccess) return e;
     CV_FOR_EACH_HALO(X, half_t)
     CV_FOR_EACH_HALO(X, float)
     CV_FOR_EACH_HALO(X, split_t)
@@ -471,15 +493,18 @@ hipError_t conv_halo_prepare() {
 }
 
 // The 64-row tile (4 waves, 72 KB: two workgroups per CU) beats conv_igemm's 64x256 tile by 5-10 % on the 64-channel
-// layers (r01_tuning.md step 16); CV_HALO64=0 switches it off for A/B runs.
+// layers (r01_tuning.md step 16); CV_HALO64=0 switches it off for A/B runs, CV_HALO_IMG8=0 the packed-image mode.
 bool conv_halo_supported(int ct, int Ho, int Wo) {
     static const bool allow64 = [] { const char* v = std::getenv("CV_HALO64"); return !(v && v[0] == '0'); }();
+    static const bool allow_img8 = [] { const char* v = std::getenv("CV_HALO_IMG8"); return !(v && v[0] == '0'); }();
+    if (ct == 128 && Ho == 8 && Wo == 8) return allow_img8;
     return (ct == 128 || (ct == 64 && allow64)) && Ho % 16 == 0 && Wo % 16 == 0;
 }
 
 hipError_t conv_halo_launch(int ct, int dt, const ConvParams& p, int n_images, hipStream_t stream) {
-#define X(T, CT, TH, WGC, NW, TPS, NSW) \
-    if (ct == CT) return launch_halo<T, CT, TH, WGC, NW, TPS, NSW>(p, n_images, stream);
+    const int img = (p.Ho == 8 && p.Wo == 8) ? 8 : 0;
+#define X(T, CT, TH, WGC, NW, TPS, NSW, IMG) \
+    if (ct == CT && img == IMG) return launch_halo<T, CT, TH, WGC, NW, TPS, NSW, IMG>(p, n_images, stream);
     if (dt == kF16) { CV_FOR_EACH_HALO(X, half_t) } else if (dt == kSplit) { CV_FOR_EACH_HALO(X, split_t) } else { CV_FOR_EACH_HALO(X, float) }
 #undef X
     return hipErrorInvalidValue;

@@ -138,7 +138,8 @@ Status ConvLayer::build_conv(const std::string& name_, int dt_, const float* w_o
                              int stride_, const float* scale_, const float* shift_, int cinPad_, int64_t pixels_hint_, int out_hw_) {
     name = name_; dt = dt_; cin = cin_; cinPad = cinPad_; cout = cout_; k = k_; stride = stride_;
     shuffle = false; rows = cout_; pixels_hint = pixels_hint_;
-    halo_ok = k_ == 3 && stride_ == 1 && out_hw_ > 0 && out_hw_ % 16 == 0 && cinPad_ % (128 / dtype_size(dt_)) == 0;
+    halo_ok = k_ == 3 && stride_ == 1 && out_hw_ > 0 && (out_hw_ % 16 == 0 || (out_hw_ == 8 && cout_ % 128 == 0)) &&
+              cinPad_ % (128 / dtype_size(dt_)) == 0;
     if (cinPad % 8 || cinPad < cin) return fail(1, name + ": input channel padding must be a multiple of 8");
     if (k != 1 && k != 3) return fail(1, name + ": implicit-GEMM path supports 1x1 and 3x3 kernels");
     if (cout % 16) return fail(1, name + ": output channels must be a multiple of 16");

@@ -168,6 +168,22 @@ def test_full_chunks_and_small_tail_launches(prec):
     assert max(err_u, err_r, err_one, err_few) <= 1e-3, (err_u, err_r, err_one, err_few)
 
 
+def test_empty_batches_are_no_ops():
+    """B = 0 is legal at the seam (an image without a detected board yields no squares): shapes only, no launches."""
+    from chessvision.hip_backend import HipEngine
+
+    eng = HipEngine(precision="f16x3")
+    eng.load_unet(synth.make_unet(seed=1).state_dict())
+    eng.load_resnet18(synth.make_resnet(seed=2).state_dict())
+    assert tuple(eng.unet_forward(torch.empty(0, 3, 256, 256)).shape) == (0, 1, 256, 256)
+    assert tuple(eng.resnet18_forward(torch.empty(0, 1, 64, 64)).shape) == (0, 13)
+    logits, mask = eng.unet_forward_u8(torch.empty(0, 256, 256, 3, dtype=torch.uint8))
+    assert tuple(logits.shape) == (0, 1, 256, 256) and tuple(mask.shape) == (0, 256, 256)
+    assert tuple(eng.resnet18_forward_u8(torch.empty(0, 64, 64, dtype=torch.uint8)).shape) == (0, 13)
+    assert tuple(eng.softmax13(torch.empty(0, 13)).shape) == (0, 13)
+    eng.close()
+
+
 def test_u8_entry_points_match_float_path():
     """cv_unet_forward_u8 / cv_resnet18_forward_u8 == float path fed with u8/255 (core.py:215,237)."""
     from chessvision.hip_backend import HipEngine

@@ -66,6 +66,8 @@ CONV_CASES = [
     ("tile_256x256_residual_tail", 9, 128, 60, 60, 256, 3, 1, True, True),
     ("resnet_layer1_residual_halo", 128, 64, 16, 16, 64, 3, 1, True, True),
     ("cin128_c64_halo_4blocks", 8, 128, 64, 64, 64, 3, 1, True, False),
+    ("layer2_like_8x8_packed_images_tail", 514, 128, 8, 8, 128, 3, 1, True, True),
+    ("layer2_like_8x8_packed_c256", 516, 128, 8, 8, 256, 3, 1, False, False),
 ]
 
 
