@@ -16,7 +16,7 @@ sys.path.insert(0, str(ROOT / "chessvision-3lc_amd"))
 import torch  # noqa: E402
 
 from chessvision.hip_backend import HipEngine  # noqa: E402
-from oracle import synth  # noqa: E402
+from chessvision import synthetic  # noqa: E402
 
 
 def main():
@@ -29,10 +29,11 @@ def main():
     ap.add_argument("--iters", type=int, default=3)
     args = ap.parse_args()
     eng = HipEngine(precision=args.prec, unet_chunk=args.chunk, resnet_chunk=args.sq_chunk)
-    eng.load_unet(synth.make_unet(1).state_dict())
-    eng.load_resnet18(synth.make_resnet(2).state_dict())
-    x = synth.unet_input(3, 4).repeat(args.unet_batch // 4 + 1, 1, 1, 1)[: args.unet_batch].cuda()
-    sq = synth.squares_input(4, 256).repeat(args.squares // 256 + 1, 1, 1, 1)[: args.squares].cuda()
+    eng.load_unet(synthetic.unet_state_dict(1))
+    eng.load_resnet18(synthetic.resnet18_state_dict(2))
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    x = torch.randint(0, 256, (max(args.unet_batch, 1), 3, 256, 256), dtype=torch.uint8, device="cuda", generator=g).float().div_(255)[: args.unet_batch]
+    sq = torch.randint(0, 256, (max(args.squares, 1), 1, 64, 64), dtype=torch.uint8, device="cuda", generator=g).float().div_(255)[: args.squares]
     for model, inp, units in (("unet", x, args.unet_batch), ("resnet18", sq, args.squares)):
         fwd = eng.unet_forward if model == "unet" else eng.resnet18_forward
         for _ in range(2):
