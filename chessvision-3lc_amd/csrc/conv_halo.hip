@@ -341,7 +341,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     // output pixel of (patch row wrow0 + g, lane l15): image, row origin, column
     const int oimg = IMG ? n + (wrow0 >> 3) * 2 + (l15 >> 3) : n;
     const int oy0 = IMG ? (wrow0 & 7) : ty * TH + wrow0, ox = IMG ? (l15 & 7) : tx * 16 + l15;
-    const bool olive = oimg < nImg;
 
     if (p.head_w) {                                      // fused OutConv, as in conv_igemm.hip
         float hw[NV];
@@ -378,71 +377,91 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     constexpr int UPP = 64 / UN;
     constexpr int UPL = 16 * UPP / 64;
     constexpr int SROW = 272;
-    static_assert(NW * 16 * SROW <= NSW * WSTAGE + 2 * HBYTES, "staging must fit in LDS");
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    char* const stg = smem + wave * (16 * SROW);
+#if CV_STAMP
+    const unsigned long long st_e0 = __builtin_amdgcn_s_memtime();
+#endif
+    // Two patch rows are staged together (the LDS write -> read-back round trip is the latency chain of this epilogue:
+    // 7 of its 11.5 k cycles remained with the stores ablated, r01_tuning.md step 21), and output addresses are derived
+    // from the pixel index instead of being shuffled in from the lane that owns the pixel.
+    constexpr int RG = 2;
+    static_assert(FP % RG == 0 && NW * RG * 16 * SROW <= NSW * WSTAGE + 2 * HBYTES, "row-pair staging must fit in LDS");
+    char* const stg = smem + wave * (RG * 16 * SROW);
     const int slab0 = ctTile * CT + wci * 64;
-    // fused 2x2 max-pool (UNet encoder): the horizontal partner pixel sits UPP lanes away in the read-back layout, the
-    // vertical one in the next patch row of the same wave (patch rows per wave and their origin are even)
-    static_assert(FP % 2 == 0, "pooling pairs patch rows inside a wave");
     T* const pbase = reinterpret_cast<T*>(p.pool_y);
-    float hold[UPL][UN];
-#pragma unroll
-    for (int g = 0; g < FP; ++g) {
-        const unsigned obase = (unsigned)((oimg * p.yHp + oy0 + g + 1) * p.yWp + ox + 1);
-        const unsigned qbase = (unsigned)((oimg * p.pHp + ((oy0 + g) >> 1) + 1) * p.pWp + (ox >> 1) + 1);
-        const int plive = olive ? 1 : 0;
-#pragma unroll
-        for (int f = 0; f < FC; ++f) {
-            f4 t;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) t[r] = acc[f][g][r] * sc[f * 4 + r] + sh[f * 4 + r];
-            *reinterpret_cast<f4*>(stg + l15 * SROW + (q * NV + f * 4) * 4) = t;
+    // output pixel index (in padded-plane pixels) of (patch row oy0 + g, pixel px of the 16-lane row)
+    auto out_pixel = [&](int g, int px, bool* live) -> unsigned {
+        if constexpr (IMG == 0) {
+            *live = true;
+            return (unsigned)((n * p.yHp + oy0 + g + 1) * p.yWp + tx * 16 + px + 1);
+        } else {
+            const int img = n + (wrow0 >> 3) * 2 + (px >> 3);
+            *live = img < nImg;
+            return (unsigned)((img * p.yHp + oy0 + g + 1) * p.yWp + (px & 7) + 1);
         }
+    };
+#pragma unroll
+    for (int g0 = 0; g0 < FP; g0 += RG) {
+#pragma unroll
+        for (int r = 0; r < RG; ++r)
+#pragma unroll
+            for (int f = 0; f < FC; ++f) {
+                f4 t;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) t[k] = acc[f][g0 + r][k] * sc[f * 4 + k] + sh[f * 4 + k];
+                *reinterpret_cast<f4*>(stg + r * (16 * SROW) + l15 * SROW + (q * NV + f * 4) * 4) = t;
+            }
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int i = 0; i < UPL; ++i) {
             const int unit = lane + 64 * i;
             const int px = unit / UPP, cu = unit % UPP;
-            float w[UN];
-#pragma unroll
-            for (int j = 0; j < UN; j += 4) {
-                const f4 t = *reinterpret_cast<const f4*>(stg + px * SROW + (cu * UN + j) * 4);
-                w[j] = t[0]; w[j + 1] = t[1]; w[j + 2] = t[2]; w[j + 3] = t[3];
-            }
-            const unsigned ob = __shfl(obase, px);
             const int co = slab0 + cu * UN;
-            if (co < p.rows && (IMG == 0 || __shfl(plive, px))) {
-                if (rbase) OutVec<T, UN>::add(rbase + (size_t)ob * p.rCs + p.rCoff + co, p.rCoff + co, w);
-                if (p.relu) {
+            float w[RG][UN];
 #pragma unroll
-                    for (int j = 0; j < UN; ++j) w[j] = w[j] > 0.f ? w[j] : 0.f;
+            for (int r = 0; r < RG; ++r)
+#pragma unroll
+                for (int j = 0; j < UN; j += 4) {
+                    const f4 t = *reinterpret_cast<const f4*>(stg + r * (16 * SROW) + px * SROW + (cu * UN + j) * 4);
+                    w[r][j] = t[0]; w[r][j + 1] = t[1]; w[r][j + 2] = t[2]; w[r][j + 3] = t[3];
                 }
-                OutVec<T, UN>::store(ybase + (size_t)ob * p.yCs + p.yCoff + co, p.yCoff + co, w);
+#pragma unroll
+            for (int r = 0; r < RG; ++r) {
+                bool live;
+                const unsigned ob = out_pixel(g0 + r, px, &live);
+                if (co < p.rows && live) {
+                    if (rbase) OutVec<T, UN>::add(rbase + (size_t)ob * p.rCs + p.rCoff + co, p.rCoff + co, w[r]);
+                    if (p.relu) {
+#pragma unroll
+                        for (int j = 0; j < UN; ++j) w[r][j] = w[r][j] > 0.f ? w[r][j] : 0.f;
+                    }
+                    OutVec<T, UN>::store(ybase + (size_t)ob * p.yCs + p.yCoff + co, p.yCoff + co, w[r]);
+                }
             }
-            if (pbase) {                                 // wave-uniform
-                const unsigned qb = __shfl(qbase, px);
+            if (IMG == 0 && pbase) {                     // wave-uniform: fused 2x2 max-pool of the (post-ReLU) row pair
+                float m[UN];
 #pragma unroll
                 for (int j = 0; j < UN; ++j) {
-                    const float o = __shfl_xor(w[j], UPP);
-                    w[j] = w[j] > o ? w[j] : o;
+                    const float v = w[0][j] > w[1][j] ? w[0][j] : w[1][j];
+                    const float o = __shfl_xor(v, UPP);  // the horizontal partner pixel sits UPP lanes away
+                    m[j] = v > o ? v : o;
                 }
-                if ((g & 1) == 0) {
-#pragma unroll
-                    for (int j = 0; j < UN; ++j) hold[i][j] = w[j];
-                } else {
-#pragma unroll
-                    for (int j = 0; j < UN; ++j) w[j] = w[j] > hold[i][j] ? w[j] : hold[i][j];
-                    if ((px & 1) == 0 && co < p.rows)
-                        OutVec<T, UN>::store(pbase + (size_t)qb * p.pCs + p.pCoff + co, p.pCoff + co, w);
-                }
+                const unsigned qb = (unsigned)((n * p.pHp + ((oy0 + g0) >> 1) + 1) * p.pWp + ((tx * 16 + px) >> 1) + 1);
+                if ((px & 1) == 0 && co < p.rows)
+                    OutVec<T, UN>::store(pbase + (size_t)qb * p.pCs + p.pCoff + co, p.pCoff + co, m);
             }
         }
         asm volatile("" ::: "memory");
     }
 #if CV_STAMP
+    const unsigned long long st_e1 = __builtin_amdgcn_s_memtime();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (p.stamp && lane == 0) p.stamp[((size_t)bid * NW + wave) * 8 + 7] = __builtin_amdgcn_s_memtime() - st_t1;
+    if (p.stamp && lane == 0) {
+        unsigned long long* o = p.stamp + ((size_t)bid * NW + wave) * 8;
+        o[7] = __builtin_amdgcn_s_memtime() - st_t1;     // epilogue until the stores have drained
+        o[4] = st_e0 - st_t1;                            // ... until every wave has left the K loop
+        o[6] = st_e1 - st_t1;                            // ... until the last store is issued
+    }
 #endif
 }
 

@@ -363,8 +363,8 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
             auto med = [](std::vector<double>& v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
             auto mean = [](const std::vector<double>& v) { double t = 0; for (double x : v) t += x; return t / (double)v.size(); };
             const double c = med(cyc), k = med(clk);
-            std::fprintf(stderr, "[stamp] %-40s ct=%d waves=%zu stages=%.0f loop=%.0f cyc (%.1f cyc/stage) clock=%.3f GHz head=%.1f %% wait+barrier=%.1f %% tail=%.1f %% pre-loop=%.0f cyc epilogue=%.0f cyc\n",
-                         L.name.c_str(), ct, cyc.size(), stages, c, c / stages, k, 100.0 * mean(hd), 100.0 * mean(wfrac), 100.0 * mean(tl), mean(is) * c, mean(ep));
+            std::fprintf(stderr, "[stamp] %-40s ct=%d waves=%zu stages=%.0f loop=%.0f cyc (%.1f cyc/stage) clock=%.3f GHz wait+barrier=%.1f %% pre-loop=%.0f cyc | epilogue: rendezvous %.0f, stores issued %.0f, drained %.0f cyc\n",
+                         L.name.c_str(), ct, cyc.size(), stages, c, c / stages, k, 100.0 * mean(wfrac), mean(is) * c, mean(hd) * c, mean(tl) * c, mean(ep));
         }
     }
     if (e != hipSuccess) return hip_fail(e, ("conv launch " + L.name).c_str());
