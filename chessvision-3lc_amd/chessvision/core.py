@@ -169,12 +169,15 @@ class ChessVision:
                                                    square_crops=squares)
 
     def process_images(self, images: Sequence[NDArray[np.uint8]], threshold: float = 0.5, flip: bool = False,
-                       fallback_quad: bool = False) -> list[ChessVisionResult]:
+                       fallback_quad: bool = False, pipeline_chunk: int = 64) -> list[ChessVisionResult]:
         """Batched pipeline (new; the reference processes one image per call).  Images stay on the device between
-        the two CNNs: INTER_AREA resize -> UNet (u8 in, logits + thresholded mask out) run per group of equally
-        sized images; only the 64 KB masks come back for the C++ contour stage; the quadrangles go back as 3x3 maps
-        and ONE fused warp+gray+flip+split kernel writes the classifier input; ONE classifier pass with softmax on
-        device covers every found board.  Results are identical in layout to ``process_image``'s."""
+        the two CNNs: INTER_AREA resize -> UNet (u8 in, logits + thresholded mask out); only the 64 KB masks come
+        back for the C++ contour stage; the quadrangles go back as 3x3 maps and ONE fused warp+gray+flip+split kernel
+        writes the classifier input; the classifier runs with softmax on device.  Work is cut into jobs of up to
+        ``pipeline_chunk`` equally sized images and software-pipelined on the host: while the GPU runs the UNet of job
+        k+1 the host finds the quadrangles of job k, and while it classifies job k the host writes the FENs of job k-1
+        (device->host copies land in pinned buffers behind events, so nothing blocks the stream).  Results are
+        identical in layout to ``process_image``'s."""
         started = time.time()
         for image in images:
             assert isinstance(image, np.ndarray) and image.dtype == np.uint8 and image.ndim == 3
@@ -185,48 +188,95 @@ class ChessVision:
 
         eng = self._get_engine()
         n = len(images)
-        logits = np.empty((n, 256, 256), dtype=np.float32)
-        masks = np.empty((n, 256, 256), dtype=np.uint8)
-        device_images: dict[int, torch.Tensor] = {}
-        groups: dict[tuple, list[int]] = {}
-        for i, im in enumerate(images):
-            groups.setdefault(im.shape, []).append(i)
-        for shape, ids in groups.items():
-            batch = torch.from_numpy(np.stack([images[i] for i in ids])).to(self.device)
-            small = eng.resize_area_u8(batch, (constants.INPUT_SIZE[1], constants.INPUT_SIZE[0]))
-            lg, mk = eng.unet_forward_u8(small, threshold=threshold, want_mask=True)
-            logits[ids] = lg[:, 0].cpu().numpy()
-            masks[ids] = mk.cpu().numpy()
-            for k, i in enumerate(ids):
-                device_images[i] = batch[k]
-        quads: list[NDArray[np.float32] | None] = []
-        for i, q in enumerate(find_quadrangles(masks)):
-            if q is None and fallback_quad:
-                q = np.array([[[255, 0]], [[0, 0]], [[0, 255]], [[255, 255]]], dtype=np.int32)   # TR, TL, BL, BR
-            quads.append(None if q is None else self._scale_quadrangle(q, (images[i].shape[0], images[i].shape[1])))
-        found = [i for i in range(n) if quads[i] is not None]
-        boards: dict[int, NDArray[np.uint8]] = {}
-        positions: dict[int, PositionResult] = {}
         names = constants.SQUARE_NAMES_FLIPPED if flip else constants.SQUARE_NAMES_NORMAL
         w, h = constants.BOARD_SIZE
         dest = np.array(((0, 0), (w, 0), (w, h), (0, h)), np.float32)
-        by_shape: dict[tuple, list[int]] = {}
-        for i in found:
-            by_shape.setdefault(images[i].shape, []).append(i)
-        for shape, ids in by_shape.items():
-            inv = np.stack([np.linalg.inv(classical.get_perspective_transform(quads[i].reshape(4, 2), dest)) for i in ids])
-            squares_dev, boards_dev = eng.extract_squares_u8(torch.stack([device_images[i] for i in ids]), inv)
-            probs = eng.resnet18_forward_u8(squares_dev).cpu().numpy().reshape(len(ids), 64, constants.NUM_CLASSES)
-            squares_host = squares_dev.cpu().numpy().reshape(len(ids), 64, 64, 64, 1)
-            boards_host = boards_dev.cpu().numpy()
+        groups: dict[tuple, list[int]] = {}
+        for i, im in enumerate(images):
+            groups.setdefault(im.shape, []).append(i)
+        step = max(1, int(pipeline_chunk))
+        jobs = [ids[k:k + step] for ids in groups.values() for k in range(0, len(ids), step)]
+
+        def pinned(shape, dtype):
+            return torch.empty(shape, dtype=dtype, pin_memory=True)
+
+        def segment(ids):                                   # host -> device, resize, UNet; masks start their way back
+            batch = torch.from_numpy(np.stack([images[i] for i in ids])).to(self.device, non_blocking=True)
+            small = eng.resize_area_u8(batch, (constants.INPUT_SIZE[1], constants.INPUT_SIZE[0]))
+            lg, mk = eng.unet_forward_u8(small, threshold=threshold, want_mask=True)
+            st = {"ids": ids, "batch": batch, "logits": pinned((len(ids), 256, 256), torch.float32),
+                  "masks": pinned((len(ids), 256, 256), torch.uint8), "ev": torch.cuda.Event()}
+            st["logits"].copy_(lg[:, 0], non_blocking=True)
+            st["masks"].copy_(mk, non_blocking=True)
+            st["ev"].record()
+            return st
+
+        def classify(st):                                   # masks -> quadrangles (host) -> warp + split + classifier (device)
+            st["ev"].synchronize()
+            ids = st["ids"]
+            masks = st["masks"].numpy()
+            quads = []
+            for k, q in enumerate(find_quadrangles(masks)):
+                if q is None and fallback_quad:
+                    q = np.array([[[255, 0]], [[0, 0]], [[0, 255]], [[255, 255]]], dtype=np.int32)   # TR, TL, BL, BR
+                shape = images[ids[k]].shape
+                quads.append(None if q is None else self._scale_quadrangle(q, (shape[0], shape[1])))
+            st["quads"] = quads
+            found = [k for k in range(len(ids)) if quads[k] is not None]
+            st["found"] = found
+            if found:
+                inv = np.stack([np.linalg.inv(classical.get_perspective_transform(quads[k].reshape(4, 2), dest)) for k in found])
+                src = st["batch"] if len(found) == len(ids) else st["batch"][torch.as_tensor(found, device=self.device)]
+                squares_dev, boards_dev = eng.extract_squares_u8(src, inv)
+                probs_dev = eng.resnet18_forward_u8(squares_dev)
+                st["probs"] = pinned((len(found) * 64, constants.NUM_CLASSES), torch.float32)
+                st["squares"] = pinned((len(found) * 64, 64, 64), torch.uint8)
+                st["boards"] = pinned((len(found), h, w), torch.uint8)
+                st["probs"].copy_(probs_dev, non_blocking=True)
+                st["squares"].copy_(squares_dev, non_blocking=True)
+                st["boards"].copy_(boards_dev, non_blocking=True)
+                st["ev2"] = torch.cuda.Event()
+                st["ev2"].record()
+            st["batch"] = None
+            return st
+
+        logits_of: dict[int, NDArray[np.float32]] = {}
+        masks_of: dict[int, NDArray[np.uint8]] = {}
+        quads_of: dict[int, NDArray[np.float32] | None] = {}
+        boards: dict[int, NDArray[np.uint8]] = {}
+        positions: dict[int, PositionResult] = {}
+
+        def finish(st):                                     # probabilities -> labels, FEN, pawn rule (host)
+            ids = st["ids"]
+            lg, mk = st["logits"].numpy(), st["masks"].numpy()
             for k, i in enumerate(ids):
-                boards[i] = boards_host[k]
-                positions[i] = self.process_position_probabilities(probs[k], names, squares_host[k])
+                logits_of[i], masks_of[i], quads_of[i] = lg[k], mk[k], st["quads"][k]
+            if st["found"]:
+                st["ev2"].synchronize()
+                m = len(st["found"])
+                probs = st["probs"].numpy().reshape(m, 64, constants.NUM_CLASSES)
+                squares = st["squares"].numpy().reshape(m, 64, 64, 64, 1)
+                brd = st["boards"].numpy()
+                for j, k in enumerate(st["found"]):
+                    boards[ids[k]] = brd[j]
+                    positions[ids[k]] = self.process_position_probabilities(probs[j], names, squares[j])
+
+        # software pipeline over the jobs: segment(k+1) is enqueued before the host works on job k
+        seg = segment(jobs[0])
+        cls = None
+        for k in range(len(jobs)):
+            nxt = segment(jobs[k + 1]) if k + 1 < len(jobs) else None
+            cur = classify(seg)
+            if cls is not None:
+                finish(cls)
+            cls, seg = cur, nxt
+        finish(cls)
+
         per_image = (time.time() - started) / n
         results = []
         for i in range(n):
-            extraction = BoardExtractionResult(board_image=boards.get(i), binary_mask=masks[i], quadrangle=quads[i],
-                                               probabilities=logits[i])
+            extraction = BoardExtractionResult(board_image=boards.get(i), binary_mask=masks_of[i], quadrangle=quads_of[i],
+                                               probabilities=logits_of[i])
             results.append(ChessVisionResult(board_extraction=extraction, position=positions.get(i),
                                              processing_time=per_image))
         return results
