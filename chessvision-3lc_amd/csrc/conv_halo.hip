@@ -389,6 +389,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     char* const stg = smem + wave * (RG * 16 * SROW);
     const int slab0 = ctTile * CT + wci * 64;
     T* const pbase = reinterpret_cast<T*>(p.pool_y);
+    const bool relu_early = p.relu && !rbase;
     // output pixel index (in padded-plane pixels) of (patch row oy0 + g, pixel px of the 16-lane row)
     auto out_pixel = [&](int g, int px, bool* live) -> unsigned {
         if constexpr (IMG == 0) {
@@ -408,7 +409,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             for (int f = 0; f < FC; ++f) {
                 f4 t;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) t[k] = acc[f][g0 + r][k] * sc[f * 4 + k] + sh[f * 4 + k];
+                for (int k = 0; k < 4; ++k) {
+                    t[k] = acc[f][g0 + r][k] * sc[f * 4 + k] + sh[f * 4 + k];
+                    // ReLU on the FMA result (known canonical: one v_max); after the read-back the compiler has to
+                    // canonicalise first.  With a residual the ReLU follows the add below.
+                    if (relu_early) t[k] = __builtin_fmaxf(t[k], 0.f);
+                }
                 *reinterpret_cast<f4*>(stg + r * (16 * SROW) + l15 * SROW + (q * NV + f * 4) * 4) = t;
             }
         asm volatile("" ::: "memory");
@@ -430,12 +436,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 bool live;
                 const unsigned ob = out_pixel(g0 + r, px, &live);
                 if (co < p.rows && live) {
-                    if (rbase) OutVec<T, UN>::add(rbase + (size_t)ob * p.rCs + p.rCoff + co, p.rCoff + co, w[r]);
-                    if (p.relu) {
+                    if (rbase) {                         // tensors stay below 4 GiB (checked on the host): 32-bit element offsets
+                        OutVec<T, UN>::add(rbase + (ob * (unsigned)p.rCs + (unsigned)(p.rCoff + co)), p.rCoff + co, w[r]);
+                        if (p.relu) {
 #pragma unroll
-                        for (int j = 0; j < UN; ++j) w[r][j] = w[r][j] > 0.f ? w[r][j] : 0.f;
+                            for (int j = 0; j < UN; ++j) w[r][j] = __builtin_fmaxf(w[r][j], 0.f);
+                        }
                     }
-                    OutVec<T, UN>::store(ybase + (size_t)ob * p.yCs + p.yCoff + co, p.yCoff + co, w[r]);
+                    OutVec<T, UN>::store(ybase + (ob * (unsigned)p.yCs + (unsigned)(p.yCoff + co)), p.yCoff + co, w[r]);
                 }
             }
             if (IMG == 0 && pbase) {                     // wave-uniform: fused 2x2 max-pool of the (post-ReLU) row pair
@@ -448,7 +456,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 }
                 const unsigned qb = (unsigned)((n * p.pHp + ((oy0 + g0) >> 1) + 1) * p.pWp + ((tx * 16 + px) >> 1) + 1);
                 if ((px & 1) == 0 && co < p.rows)
-                    OutVec<T, UN>::store(pbase + (size_t)qb * p.pCs + p.pCoff + co, p.pCoff + co, m);
+                    OutVec<T, UN>::store(pbase + (qb * (unsigned)p.pCs + (unsigned)(p.pCoff + co)), p.pCoff + co, m);
             }
         }
         asm volatile("" ::: "memory");
