@@ -59,8 +59,11 @@ def conv_algorithmic_bytes(dtype, unet_chunk, resnet_chunk):
         return (inp + px * (cout if out_ch is None else out_ch) * (2 if res else 1) + k * k * cin * cout) * esz
     u, n = [], unet_chunk
     u += [conv(n, 256, 8, 64), conv(n, 256, 64, 64)]                                   # 3 input channels stored as 8
+    u[-1] += n * 128 * 128 * 64 * esz                                                  # + the fused 2x2 max-pool's output
     for hw, c in ((128, 64), (64, 128), (32, 256), (16, 512)):
         u += [conv(n, hw, c, 2 * c), conv(n, hw, 2 * c, 2 * c)]
+        if hw > 16:
+            u[-1] += n * (hw // 2) ** 2 * 2 * c * esz
     for hw, c in ((32, 1024), (64, 512), (128, 256), (256, 128)):                      # hw = output of the transposed conv
         u.append((n * (hw // 2) ** 2 * c + n * hw * hw * (c // 2) + 4 * c * (c // 2)) * esz)
         last = hw == 256
