@@ -28,7 +28,10 @@ namespace cv {
 // IMG = 0: one TH x 16 patch of one (large) image per workgroup.  IMG = 8: feature maps of 8 x 8 (ResNet layer2): the
 // 16 x 16 pixel tile is four whole images (2 x 2), whose zero-bordered 10 x 10 PHWC planes are contiguous in memory, so
 // the "halo" is simply 400 consecutive pixels and a fragment's 16 lanes read row y of two neighbouring images.
-template <typename T, int CT, int TH, int WGC, int NW, int TPS, int NSW, int IMG>
+// PERSIST: the grid is one workgroup per CU slot and every workgroup walks tiles lid, lid + grid, ...; the first DMAs of the
+// next tile (its halo and three weight stages) are issued before the current tile's epilogue, so their latency, the
+// store drain and the workgroup relaunch disappear behind it (r01_tuning.md step 22).
+template <typename T, int CT, int TH, int WGC, int NW, int TPS, int NSW, int IMG, bool PERSIST>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_halo_kernel(const ConvParams p) {
     static_assert((TPS == 1 || TPS == 3) && (NSW == 2 || NSW == 3), "stage shape");
     constexpr int SPC = 9 / TPS;                        // stages per channel block
@@ -68,25 +71,32 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const unsigned nwg = gridDim.x, bid = blockIdx.x;   // XCD-aware remap, as in conv_igemm.hip
     const unsigned xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
     const unsigned lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
-    const int ctTile = lid % p.nCt;
-    int pt = lid / p.nCt;
     const int tilesX = IMG ? 1 : p.Wo / 16, tilesY = IMG ? 1 : p.Ho / TH;
-    const int tx = pt % tilesX; pt /= tilesX;
-    const int ty = pt % tilesY;
-    const int n = IMG ? 4 * (pt / tilesY) : pt / tilesY;            // (first) image of this workgroup
     const int nImg = p.M / (p.Ho * p.Wo);
     const int nCb = p.nStages / 9, nS = nCb * SPC;       // p.nStages counts (channel block, tap) pairs
+    const unsigned nTiles = (unsigned)((IMG ? (nImg + 3) / 4 : nImg * tilesX * tilesY) * p.nCt);
+    // the tile the DMA side works on (in a persistent workgroup that is already the NEXT tile during an epilogue)
+    int ctTile, tx, ty, n;
+    unsigned hbase;
+    const char* wsrc;
 
     // DMA sources of this lane's halo rows: row r of the halo <-> padded input pixel (ty*TH + r/18, tx*16 + r%18).
     // Needed once per channel block only, so they are re-derived at each use (the lane id is made opaque to keep LICM
     // from parking H more VGPRs across the whole K loop).
-    const unsigned hbase = (unsigned)((n * p.xHp + ty * TH) * p.xWp + tx * 16);
     const unsigned xpix = (unsigned)p.xCs * (unsigned)sizeof(T);
     const char* const xsrc = p.x + p.xCoffBytes;
     const bool is_w = !kRoles || wave < NWI;            // this wave moves weight stages / halo pieces
     const bool is_h = !kRoles || wave >= NWI;
     const int wi = kRoles && wave >= NWI ? wave - NWI : wave;     // index among the waves of its role
-    const char* const wsrc = p.w + (size_t)ctTile * p.nStages * WTAP + wi * 1024 + lane * 16;
+    auto decode = [&](unsigned tile) {
+        ctTile = tile % p.nCt;
+        int pt = tile / p.nCt;
+        tx = pt % tilesX; pt /= tilesX;
+        ty = pt % tilesY;
+        n = IMG ? 4 * (pt / tilesY) : pt / tilesY;      // (first) image of the tile
+        hbase = (unsigned)((n * p.xHp + ty * TH) * p.xWp + tx * 16);
+        wsrc = p.w + (size_t)ctTile * p.nStages * WTAP + wi * 1024 + lane * 16;
+    };
 
     auto issue_w = [&](int s, int slot) {
         char* sW = smem + slot * WSTAGE;
@@ -123,10 +133,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const int l7 = lane & 7;
 
     f4 acc[FC][FP];
-#pragma unroll
-    for (int f = 0; f < FC; ++f)
-#pragma unroll
-        for (int g = 0; g < FP; ++g) acc[f][g] = f4{0.f, 0.f, 0.f, 0.f};
 
     // Fragment sets of one stage.  Every precision reads two 16-byte chunks per lane and operand: split-f16 the hi and
     // the lo chunk of its channel group (products hi.hi, lo.hi, hi.lo), f16 / f32 the two k-halves of the 128-byte line
@@ -211,13 +217,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #endif
     static_assert(NSW == 3 && TPS == 1, "the pipelined loop is written for one tap per stage and a 3-deep weight ring");
     Frags F0, F1;
-    if (is_h) issue_halo(0, 0, std::integral_constant<int, 0>{}, std::integral_constant<int, H>{});
-    if (is_w) { issue_w(0, 0); issue_w(1, 1); issue_w(2, 2); }
-    if (is_w) wait_vm_barrier<2 * LW>();                // halo(0) and W(0) landed; W(1), W(2) may still fly
-    else wait_vm_barrier<0>();
-    load_a(F0, std::integral_constant<int, 0>{});
-    load_b(F0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
     int s = 0;
+    auto issue_prologue = [&]() {                        // first DMAs of the tile `decode` was last called for
+        if (is_h) issue_halo(0, 0, std::integral_constant<int, 0>{}, std::integral_constant<int, H>{});
+        if (is_w) { issue_w(0, 0); issue_w(1, 1); issue_w(2, 2); }
+    };
     auto stage = [&](Frags& cur, Frags& nxt, auto j_tag, auto hb_tag, int cb) {
         constexpr int J = decltype(j_tag)::value;
         constexpr int HB = decltype(hb_tag)::value;
@@ -311,6 +315,23 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         stage(E, O, std::integral_constant<int, 6>{}, HBt{}, cb); stage(O, E, std::integral_constant<int, 7>{}, HBt{}, cb);
         stage(E, O, std::integral_constant<int, 8>{}, HBt{}, cb);
     };
+    unsigned tile = lid;
+    decode(tile);
+    issue_prologue();
+    for (bool first = true;; first = false) {
+#pragma unroll
+    for (int f = 0; f < FC; ++f)
+#pragma unroll
+        for (int g = 0; g < FP; ++g) acc[f][g] = f4{0.f, 0.f, 0.f, 0.f};
+    if (first) {
+        if (is_w) wait_vm_barrier<2 * LW>();            // halo(0) and W(0) landed; W(1), W(2) may still fly
+        else wait_vm_barrier<0>();
+    } else {
+        wait_vm_barrier<0>();                            // issued a whole epilogue ago; also drains that epilogue's stores
+    }
+    load_a(F0, std::integral_constant<int, 0>{});
+    load_b(F0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    s = 0;
     for (int cb = 0; cb < nCb; cb += 2) {
         run_cb(std::integral_constant<int, 0>{}, cb);
         if (cb + 1 < nCb) run_cb(std::integral_constant<int, 1>{}, cb + 1);
@@ -325,9 +346,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         o[4] = st_head; o[5] = st_t0 - st_k0; o[6] = st_tail;
     }
 #endif
+    // the epilogue works on the tile just finished; the DMA side moves on to the next one
+    const int eCt = ctTile, eTx = tx, eTy = ty, eN = n;
+    const unsigned nxt_tile = tile + nwg;
+    const bool more_tiles = PERSIST && nxt_tile < nTiles;
     // ---- epilogue (see conv_igemm.hip for the rationale of the staged store) ------------------------------
     constexpr int NV = 4 * FC;
-    const int row0 = ctTile * CT + wci * 64 + q * NV;
+    const int row0 = eCt * CT + wci * 64 + q * NV;
     float sc[NV], sh[NV];
 #pragma unroll
     for (int i = 0; i < NV; i += 4) {
@@ -339,10 +364,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     T* const ybase = reinterpret_cast<T*>(p.y);
     const T* const rbase = reinterpret_cast<const T*>(p.res);
     // output pixel of (patch row wrow0 + g, lane l15): image, row origin, column
-    const int oimg = IMG ? n + (wrow0 >> 3) * 2 + (l15 >> 3) : n;
-    const int oy0 = IMG ? (wrow0 & 7) : ty * TH + wrow0, ox = IMG ? (l15 & 7) : tx * 16 + l15;
+    const int oimg = IMG ? eN + (wrow0 >> 3) * 2 + (l15 >> 3) : eN;
+    const int oy0 = IMG ? (wrow0 & 7) : eTy * TH + wrow0, ox = IMG ? (l15 & 7) : eTx * 16 + l15;
 
-    if (p.head_w) {                                      // fused OutConv, as in conv_igemm.hip
+    if (!PERSIST && p.head_w) {                          // fused OutConv, as in conv_igemm.hip (64-channel tile only)
         float hw[NV];
 #pragma unroll
         for (int i = 0; i < NV; ++i) hw[i] = p.head_w[row0 + i];
@@ -377,30 +402,35 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     constexpr int UPP = 64 / UN;
     constexpr int UPL = 16 * UPP / 64;
     constexpr int SROW = 272;
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // every wave is done reading the ring and the halo
 #if CV_STAMP
     const unsigned long long st_e0 = __builtin_amdgcn_s_memtime();
 #endif
-    // Two patch rows are staged together (the LDS write -> read-back round trip is the latency chain of this epilogue:
-    // 7 of its 11.5 k cycles remained with the stores ablated, r01_tuning.md step 21), and output addresses are derived
-    // from the pixel index instead of being shuffled in from the lane that owns the pixel.
-    constexpr int RG = 2;
-    static_assert(FP % RG == 0 && NW * RG * 16 * SROW <= NSW * WSTAGE + 2 * HBYTES, "row-pair staging must fit in LDS");
-    char* const stg = smem + wave * (RG * 16 * SROW);
-    const int slab0 = ctTile * CT + wci * 64;
+    if (more_tiles) {                                    // next tile: halo(0) -> buffer 0, W(0..2) -> ring; lands during this epilogue
+        decode(nxt_tile);
+        issue_prologue();
+    }
+    // Patch rows are staged RG at a time in wave-private LDS and read back so that consecutive lanes hold consecutive
+    // bytes; output addresses are derived from the pixel index.  A persistent workgroup stages in halo buffer 1, the
+    // only region the next tile's first DMAs do not write, which has room for one row per wave.
+    constexpr int RG = PERSIST ? 1 : 2;
+    static_assert(FP % 2 == 0 && NW * RG * 16 * SROW <= (PERSIST ? HBYTES : NSW * WSTAGE + 2 * HBYTES), "staging must fit in LDS");
+    char* const stg = (PERSIST ? halo + HBYTES : smem) + wave * (RG * 16 * SROW);
+    const int slab0 = eCt * CT + wci * 64;
     T* const pbase = reinterpret_cast<T*>(p.pool_y);
     const bool relu_early = p.relu && !rbase;
     // output pixel index (in padded-plane pixels) of (patch row oy0 + g, pixel px of the 16-lane row)
     auto out_pixel = [&](int g, int px, bool* live) -> unsigned {
         if constexpr (IMG == 0) {
             *live = true;
-            return (unsigned)((n * p.yHp + oy0 + g + 1) * p.yWp + tx * 16 + px + 1);
+            return (unsigned)((eN * p.yHp + oy0 + g + 1) * p.yWp + eTx * 16 + px + 1);
         } else {
-            const int img = n + (wrow0 >> 3) * 2 + (px >> 3);
+            const int img = eN + (wrow0 >> 3) * 2 + (px >> 3);
             *live = img < nImg;
             return (unsigned)((img * p.yHp + oy0 + g + 1) * p.yWp + (px & 7) + 1);
         }
     };
+    float hold[UPL][UN];                                 // RG == 1 only
 #pragma unroll
     for (int g0 = 0; g0 < FP; g0 += RG) {
 #pragma unroll
@@ -450,12 +480,23 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 float m[UN];
 #pragma unroll
                 for (int j = 0; j < UN; ++j) {
-                    const float v = w[0][j] > w[1][j] ? w[0][j] : w[1][j];
+                    const float v = RG == 2 ? (w[0][j] > w[RG - 1][j] ? w[0][j] : w[RG - 1][j]) : w[0][j];
                     const float o = __shfl_xor(v, UPP);  // the horizontal partner pixel sits UPP lanes away
                     m[j] = v > o ? v : o;
                 }
-                const unsigned qb = (unsigned)((n * p.pHp + ((oy0 + g0) >> 1) + 1) * p.pWp + ((tx * 16 + px) >> 1) + 1);
-                if ((px & 1) == 0 && co < p.rows)
+                bool emit = true;
+                if constexpr (RG == 1) {                 // one row per pass: the upper row of a pair waits in registers
+                    if ((g0 & 1) == 0) {
+                        emit = false;
+#pragma unroll
+                        for (int j = 0; j < UN; ++j) hold[i][j] = m[j];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < UN; ++j) m[j] = m[j] > hold[i][j] ? m[j] : hold[i][j];
+                    }
+                }
+                const unsigned qb = (unsigned)((eN * p.pHp + ((oy0 + g0) >> 1) + 1) * p.pWp + ((eTx * 16 + px) >> 1) + 1);
+                if (emit && (px & 1) == 0 && co < p.rows)
                     OutVec<T, UN>::store(pbase + (qb * (unsigned)p.pCs + (unsigned)(p.pCoff + co)), p.pCoff + co, m);
             }
         }
@@ -471,6 +512,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         o[6] = st_e1 - st_t1;                            // ... until the last store is issued
     }
 #endif
+    if (!more_tiles) break;
+    tile = nxt_tile;
+    }
 }
 
 // ---- host-side launch -------------------------------------------------------------------------------------
@@ -482,19 +526,38 @@ static constexpr size_t halo_lds() {
     return (size_t)NSW * TPS * CT * 128 + (size_t)2 * H * NWI * 1024;
 }
 
+static int g_halo_cus = 256;                            // CUs of the device (set by conv_halo_prepare)
+
+// 8-wave tiles (one 136-152 KB workgroup per CU) run persistent; CV_HALO_PERSIST=0 launches one workgroup per tile
+template <int NW> static bool halo_persistent() {
+    static const bool on = [] { const char* v = std::getenv("CV_HALO_PERSIST"); return !(v && v[0] == '0'); }();
+    return NW == 8 && on;
+}
+
 template <typename T, int CT, int TH, int WGC, int NW, int TPS, int NSW, int IMG>
 static hipError_t launch_halo(const ConvParams& p, int n_images, hipStream_t stream) {
-    const int tiles = IMG ? (n_images + 3) / 4 : n_images * (p.Ho / TH) * (p.Wo / 16);
-    auto kern = conv3x3_halo_kernel<T, CT, TH, WGC, NW, TPS, NSW, IMG>;
+    const int tiles = (IMG ? (n_images + 3) / 4 : n_images * (p.Ho / TH) * (p.Wo / 16)) * p.nCt;
     const size_t lds = halo_lds<CT, TH, NW, TPS, NSW, IMG>();
     static_assert(halo_lds<CT, TH, NW, TPS, NSW, IMG>() <= 160 * 1024, "LDS budget");
-    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * p.nCt)), dim3(64 * NW), lds, stream, p);
+    // persistent only where it pays (same-box A/B, r01_tuning.md step 22): several tiles per CU and a K loop short enough
+    // for the hidden prologue to matter; long loops lose ~1 % to the single-row staging
+    if (NW == 8 && halo_persistent<NW>() && tiles >= 4 * g_halo_cus && p.nStages <= 72) {
+        auto kern = conv3x3_halo_kernel<T, CT, TH, WGC, NW, TPS, NSW, IMG, NW == 8>;
+        const int grid = tiles < g_halo_cus ? tiles : g_halo_cus;
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * NW), lds, stream, p);
+    } else {
+        auto kern = conv3x3_halo_kernel<T, CT, TH, WGC, NW, TPS, NSW, IMG, false>;
+        hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(64 * NW), lds, stream, p);
+    }
     return hipGetLastError();
 }
 
 template <typename T, int CT, int TH, int WGC, int NW, int TPS, int NSW, int IMG>
 static hipError_t prepare_halo() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<T, CT, TH, WGC, NW, TPS, NSW, IMG>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<T, CT, TH, WGC, NW, TPS, NSW, IMG, false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess || NW != 8) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<T, CT, TH, WGC, NW, TPS, NSW, IMG, NW == 8>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -510,6 +573,9 @@ static hipError_t prepare_halo() {
 
 hipError_t conv_halo_prepare() {
     hipError_t e;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+        g_halo_cus = cus;
 #define X(T, CT, TH, WGC, NW, TPS, NSW, IMG) \
     if ((e = prepare_halo<T, CT, TH, WGC, NW, TPS, NSW, IMG>()) != hipSuccess) return e;
     CV_FOR_EACH_HALO(X, half_t)

@@ -15,10 +15,8 @@ enum ConvCfg {            // <channel tile> x <pixel tile> of one 256-thread wor
     kCfg128x128 = 2,      // Cout >= 128, few pixels (deep UNet / ResNet stages)
     kCfg128x256 = 3,      // Cout >= 128, many pixels
     kCfg128x256w8 = 4,    // 8 waves (two per SIMD), ring depth 3: the default for Cout >= 128
-    kCfg64x512w8 = 5,     // 8 waves, Cout == 64, ring depth 2
-    kCfg64x256w8 = 6,     // 8 waves, Cout == 64, 64ch x 32px per wave, ring depth 3
-    kCfg256x256w8 = 7,    // 8 waves as 4 x 2, 64ch x 128px per wave, ring 2: fewest L2->LDS bytes per MFMA (Cout % 256 == 0)
-    kNumConvCfg = 8
+    kCfg256x256w8 = 5,    // 8 waves as 4 x 2, 64ch x 128px per wave, ring 2: fewest L2->LDS bytes per MFMA (Cout % 256 == 0)
+    kNumConvCfg = 6
 };
 
 hipError_t conv_igemm_prepare();                                   // raise dynamic-LDS limits (once per device)

@@ -411,8 +411,6 @@ static hipError_t prepare_one() {
     X(T, 128, 128, 2, 2, 4, kCfg128x128)   \
     X(T, 128, 256, 2, 2, 4, kCfg128x256)   \
     X(T, 128, 256, 2, 3, 8, kCfg128x256w8) \
-    X(T, 64, 512, 1, 2, 8, kCfg64x512w8)   \
-    X(T, 64, 256, 1, 3, 8, kCfg64x256w8)   \
     X(T, 256, 256, 4, 2, 8, kCfg256x256w8)
 
 hipError_t conv_igemm_prepare() {
@@ -436,16 +434,15 @@ hipError_t conv_igemm_launch(int cfg, int ns, int dt, const ConvParams& p, hipSt
 }
 
 bool conv_cfg_has_ns(int cfg, int ns) {
-    if (cfg == kCfg128x256w8 || cfg == kCfg64x256w8) return ns == 3;
-    if (cfg == kCfg64x512w8 || cfg == kCfg256x256w8) return ns == 2;
+    if (cfg == kCfg128x256w8) return ns == 3;
+    if (cfg == kCfg256x256w8) return ns == 2;
     return ns == 2 || ns == 3;
 }
 int conv_cfg_ct(int cfg) {
     if (cfg == kCfg256x256w8) return 256;
-    return (cfg == kCfg64x256 || cfg == kCfg64x128 || cfg == kCfg64x512w8 || cfg == kCfg64x256w8) ? 64 : 128;
+    return (cfg == kCfg64x256 || cfg == kCfg64x128) ? 64 : 128;
 }
 int conv_cfg_pt(int cfg) {
-    if (cfg == kCfg64x512w8) return 512;
     return (cfg == kCfg64x128 || cfg == kCfg128x128) ? 128 : 256;
 }
 

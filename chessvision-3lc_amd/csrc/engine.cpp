@@ -250,8 +250,6 @@ int choose_cfg(int ct, int rows, int64_t pixels, int n_stages) {
     if (force_pt == 128 || force_pt == 256)
         return force_pt == 256 ? (wide ? kCfg128x256 : kCfg64x256) : (wide ? kCfg128x128 : kCfg64x128);
     if (!wide) {
-        if (w8 == 1) return kCfg64x512w8;
-        if (w8 == 2) return kCfg64x256w8;
         if (env_int("CV_N64", 1) == 1 && n_stages > 4 && blocks_for(rows, pixels, 64, 256) >= 512) return kCfg64x256;
         return kCfg64x128;
     }
