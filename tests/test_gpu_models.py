@@ -133,7 +133,7 @@ def test_resnet18_forward_matches_oracle(prec):
         assert agree == 1.0
     else:
         assert err <= 5e-3 * max(1.0, scale), (err, scale, layer_err)
-        assert p_err <= 2e-2, p_err
+        assert p_err <= 1e-3, p_err          # fp16 storage / fp32 accumulate, probabilities within 1e-3
         assert agree >= 0.99
 
 
