@@ -112,6 +112,12 @@ def max_over_ranks(value: float, device: torch.device) -> float:
     return float(t.item())
 
 
+def shutdown() -> None:
+    """Tear the process group down (quietly a no-op for single-process runs)."""
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
+
+
 def barrier(device: torch.device) -> None:
     if dist.is_initialized():
         if device.type == "cuda":
