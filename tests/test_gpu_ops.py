@@ -68,6 +68,9 @@ CONV_CASES = [
     ("cin128_c64_halo_4blocks", 8, 128, 64, 64, 64, 3, 1, True, False),
     ("layer2_like_8x8_packed_images_tail", 514, 128, 8, 8, 128, 3, 1, True, True),
     ("layer2_like_8x8_packed_c256", 516, 128, 8, 8, 256, 3, 1, False, False),
+    # >= 4 tiles per CU and K <= 72 stages: the persistent variants of the 8-wave halo tiles (with a ragged last image group)
+    ("persistent_halo128_residual", 64, 64, 64, 64, 128, 3, 1, True, True),
+    ("persistent_packed_8x8_tail", 4098, 128, 8, 8, 128, 3, 1, True, True),
 ]
 
 
