@@ -212,9 +212,18 @@ Status ConvLayer::get_koff(const TensorRef& x, const int** chunks, const int** b
     return Status();
 }
 
+// experiment switches (documented in DESIGN.md / r01_tuning.md); each is read from the environment once per process
 static int env_int(const char* name, int dflt) {
     const char* v = std::getenv(name);
     return v && *v ? std::atoi(v) : dflt;
+}
+struct Knobs {
+    int halo = env_int("CV_HALO", 1), ct256 = env_int("CV_CT256", 1), ct256_min_blocks = env_int("CV_CT256_MIN_BLOCKS", 256);
+    int n64 = env_int("CV_N64", 1), sep = env_int("CV_CONV_SEP", 1), fuse_pool = env_int("CV_FUSE_POOL", 1);
+};
+static const Knobs& knobs() {
+    static const Knobs k;
+    return k;
 }
 
 // Tile / ring-depth choice, from the r01 sweeps on MI355X (profiles/r01_tuning.md):
@@ -236,8 +245,8 @@ static int env_cached(int idx) {                      // 0: CV_CONV_W8, 1: CV_CO
 // L2->LDS bytes per MFMA: the r01 ablation shows the DMA side alone costs 60-85 % of a layer's time) are used when
 // the layer still fills the chip with 256x256 workgroups at the engine's chunk size.
 int choose_ct(int rows, int64_t pixels_hint, bool halo_ok) {
-    if (halo_ok && env_int("CV_HALO", 1)) return rows % 128 == 0 ? 128 : 64;   // the halo kernel has 64- and 128-row tiles
-    if (rows % 256 == 0 && env_int("CV_CT256", 1) && blocks_for(rows, pixels_hint, 256, 256) >= env_int("CV_CT256_MIN_BLOCKS", 256))
+    if (halo_ok && knobs().halo) return rows % 128 == 0 ? 128 : 64;   // the halo kernel has 64- and 128-row tiles
+    if (rows % 256 == 0 && knobs().ct256 && blocks_for(rows, pixels_hint, 256, 256) >= knobs().ct256_min_blocks)
         return 256;
     return rows % 128 == 0 ? 128 : 64;
 }
@@ -250,7 +259,7 @@ int choose_cfg(int ct, int rows, int64_t pixels, int n_stages) {
     if (force_pt == 128 || force_pt == 256)
         return force_pt == 256 ? (wide ? kCfg128x256 : kCfg64x256) : (wide ? kCfg128x128 : kCfg64x128);
     if (!wide) {
-        if (env_int("CV_N64", 1) == 1 && n_stages > 4 && blocks_for(rows, pixels, 64, 256) >= 512) return kCfg64x256;
+        if (knobs().n64 == 1 && n_stages > 4 && blocks_for(rows, pixels, 64, 256) >= 512) return kCfg64x256;
         return kCfg64x128;
     }
     if (w8 != 0 && blocks_for(rows, pixels, 128, 256) >= 256) return kCfg128x256w8;
@@ -294,7 +303,7 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
     p.x = reinterpret_cast<const char*>(x.base);
     p.w = reinterpret_cast<const char*>(L.w.ptr);
     p.koff = koff;
-    p.kbase = env_int("CV_CONV_SEP", 1) ? kbase : nullptr;
+    p.kbase = knobs().sep ? kbase : nullptr;
     p.scale = reinterpret_cast<const float*>(L.scale.ptr);
     p.shift = reinterpret_cast<const float*>(L.shift.ptr);
     p.res = nullptr;
@@ -321,9 +330,9 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
     p.nCt = (L.rows + conv_cfg_ct(cfg) - 1) / conv_cfg_ct(cfg);
     // 3x3 / stride-1 layers whose patch grid divides the image keep the input patch in LDS across the nine taps
     const bool halo = L.k == 3 && L.stride == 1 && !L.shuffle && kbase != nullptr && L.nStages % 9 == 0 &&
-                      env_int("CV_HALO", 1) && conv_halo_supported(ct, Ho, Wo) &&
+                      knobs().halo && conv_halo_supported(ct, Ho, Wo) &&
                       blocks_for(L.rows, p.M, ct, 256) >= 128;        // single boards: 128x128 tiles give more workgroups
-    const bool fuse_pool = pool_out && halo && !head && env_int("CV_FUSE_POOL", 1);
+    const bool fuse_pool = pool_out && halo && !head && knobs().fuse_pool;
     if (pool_out) {
         if (pool_out->H * 2 != y.H || pool_out->W * 2 != y.W || pool_out->C != y.C || pool_out->N != y.N)
             return fail(1, L.name + ": pooled output shape mismatch");
