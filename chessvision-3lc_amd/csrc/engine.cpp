@@ -266,12 +266,13 @@ int choose_cfg(int ct, int rows, int64_t pixels, int n_stages) {
     return kCfg128x128;
 }
 
-int choose_ns(int cfg, int dt, int rows, int64_t pixels) {
+int choose_ns(int cfg, int dt, int rows, int64_t pixels, int n_stages) {
     (void)dt;
     const int forced = env_cached(2);
     if ((forced == 2 || forced == 3) && conv_cfg_has_ns(cfg, forced)) return forced;
     if (cfg == kCfg128x128) return blocks_for(rows, pixels, 128, 128) > 256 ? 2 : 3;
     if (cfg == kCfg64x256) return 2;                    // 80 KB table-free -> two workgroups per CU
+    if (cfg == kCfg64x128 && n_stages <= 4) return 2;   // 3-stage first layer: 48 KB -> three workgroups per CU (+14 %, r01 step 23)
     return conv_cfg_has_ns(cfg, 3) ? 3 : 2;
 }
 
@@ -326,7 +327,7 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
         p.w = reinterpret_cast<const char*>(L.w_small.ptr);
     }
     const int cfg = choose_cfg(ct, L.rows, p.M, L.nStages);
-    const int ns = choose_ns(cfg, dt, L.rows, p.M);
+    const int ns = choose_ns(cfg, dt, L.rows, p.M, L.nStages);
     p.nCt = (L.rows + conv_cfg_ct(cfg) - 1) / conv_cfg_ct(cfg);
     // 3x3 / stride-1 layers whose patch grid divides the image keep the input patch in LDS across the nine taps
     const bool halo = L.k == 3 && L.stride == 1 && !L.shuffle && kbase != nullptr && L.nStages % 9 == 0 &&

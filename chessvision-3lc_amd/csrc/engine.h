@@ -142,7 +142,7 @@ class Engine {
 
 int choose_ct(int rows, int64_t pixels_hint, bool halo_ok);
 int choose_cfg(int ct, int rows, int64_t pixels, int n_stages);
-int choose_ns(int cfg, int dt, int rows, int64_t pixels);
+int choose_ns(int cfg, int dt, int rows, int64_t pixels, int n_stages);
 
 Status unet_load(Engine& e, const ParamMap& pm);
 Status unet_forward(Engine& e, const void* x, bool x_u8, int batch, float* logits, uint8_t* mask, float thr,
