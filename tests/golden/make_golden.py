@@ -129,9 +129,27 @@ def copy_reference_masks():
     json.dump(corners, open(HERE / "masks" / "corners.json", "w"), indent=1)
 
 
+def pack_all_reference_masks():
+    """All 631 label masks of the reference (data/board_extraction/masks, 0/255, 256x256) bit-packed with their annotated
+    corners (coordinates.json): the full pin of the mask -> quadrangle stage.  ~100 KB compressed."""
+    from PIL import Image
+    ann = {}
+    for line in open(REF / "data/board_extraction/coordinates.json"):
+        d = json.loads(line)
+        key = re.findall(r"([0-9a-f]{8}(?:-[0-9a-f]{4}){3}-[0-9a-f]{12})\.JPG", d["content"], flags=re.I)[-1]
+        if d["annotation"]:
+            ann[key] = d["annotation"][0]["points"][:4]
+    names = sorted(p.stem for p in (REF / "data/board_extraction/masks").glob("*.png") if p.stem in ann)
+    masks = np.stack([np.array(Image.open(REF / "data/board_extraction/masks" / f"{n}.png").convert("L")) for n in names])
+    assert set(np.unique(masks)) <= {0, 255}
+    np.savez_compressed(HERE / "masks_all.npz", names=np.array(names), bits=np.packbits(masks > 0, axis=-1),
+                        corners=np.array([ann[n] for n in names], dtype=np.float64))
+
+
 if __name__ == "__main__":
     make_ops()
     make_models()
     if REF.exists():
         copy_reference_masks()
+        pack_all_reference_masks()
     print("golden fixtures written to", HERE)

@@ -95,3 +95,29 @@ def test_degenerate_masks(find_quadrangle):
     one = np.zeros((32, 32), np.uint8)
     one[5, 7] = 255
     assert find_quadrangle(one) is None and ChessVision._find_quadrangle(one) is None
+
+
+def test_all_reference_label_masks_give_their_annotated_corners(find_quadrangle):
+    """Every one of the reference's 631 label masks (data/board_extraction/masks, bit-packed in golden/masks_all.npz by
+    make_golden.py) against its annotated corners (coordinates.json): all four corners within 2 px, each matched to a
+    different annotation, order top-right, top-left, bottom-left, bottom-right.  The numpy restatement must agree
+    bit for bit on a sample of them."""
+    from chessvision.hip_backend import find_quadrangles
+
+    z = np.load(G / "masks_all.npz")
+    masks = (np.unpackbits(z["bits"], axis=-1)[..., :256] * 255).astype(np.uint8)
+    corners = z["corners"] * 256.0
+    assert masks.shape == (631, 256, 256) and corners.shape == (631, 4, 2)
+    quads = find_quadrangles(masks)
+    worst = 0.0
+    for q, ann in zip(quads, corners):
+        assert q is not None
+        pts = q.reshape(4, 2).astype(np.float64)
+        d = np.sqrt(((pts[:, None, :] - ann[None, :, :]) ** 2).sum(-1))
+        assert sorted(d.argmin(axis=1).tolist()) == [0, 1, 2, 3]
+        worst = max(worst, float(d.min(axis=1).max()))
+        cx, cy = pts.mean(axis=0)
+        assert [("T" if y < cy else "B") + ("L" if x < cx else "R") for x, y in pts] == ["TR", "TL", "BL", "BR"]
+    assert worst <= 2.0, worst
+    for i in range(0, 631, 40):
+        assert _same(quads[i], ChessVision._find_quadrangle(masks[i]))
