@@ -39,7 +39,7 @@ def pmc_traffic(dtype, unet_chunk, resnet_chunk, unet_launches, resnet_launches)
     """Per-launch HBM bytes of the conv family from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json:
     separate --pmc FETCH_SIZE / WRITE_SIZE runs of the same chunk sizes, gfx950-corrected); None if not collected."""
     path = ROOT / "profiles" / "r01_pmc_traffic.json"
-    if not path.exists() or (unet_chunk, resnet_chunk) != (32, 8192):
+    if not path.exists() or (unet_chunk, resnet_chunk) != (64, 16384):
         return None
     t = json.load(open(path))
     u, r = t.get(f"{dtype}_unet"), t.get(f"{dtype}_resnet18")
@@ -143,8 +143,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--dtype", default=os.environ.get("CV_BENCH_DTYPE", "f16x3"), choices=["f32", "f16", "f16x3"])
     ap.add_argument("--boards", type=int, default=256, help="boards per GPU per step")
-    ap.add_argument("--unet-chunk", type=int, default=32)
-    ap.add_argument("--resnet-chunk", type=int, default=8192)
+    ap.add_argument("--unet-chunk", type=int, default=64)
+    ap.add_argument("--resnet-chunk", type=int, default=16384)
     ap.add_argument("--overlap", type=int, default=int(os.environ.get("CV_BENCH_OVERLAP", "0")),
                     help="1: enqueue the UNet pass and the ResNet pass of a step on two HIP streams (they are independent)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -236,8 +236,13 @@ def main():
     macs_board = eng.model_macs("unet") + 64 * eng.model_macs("resnet18")
     log(f"  step: {ms_per_step:.2f} ms; event-timed kernels {all_ms:.2f} ms; conv family {conv_ms:.2f} ms over {conv_n} launches")
 
-    ub, rb = conv_algorithmic_bytes(args.dtype, args.unet_chunk, args.resnet_chunk)
-    assert len(ub) * -(-B // args.unet_chunk) + len(rb) * -(-(B * 64) // args.resnet_chunk) == conv_n, (len(ub), len(rb), conv_n)
+    # effective chunk sizes from the launch counts (the f32 engine halves the classifier chunk to stay under 4 GiB per tensor)
+    n_unet_layers, n_resnet_layers = 22, 19
+    assert launches["unet"] % n_unet_layers == 0 and launches["resnet18"] % n_resnet_layers == 0, launches
+    eff_unet = B // (launches["unet"] // n_unet_layers)
+    eff_resnet = B * 64 // (launches["resnet18"] // n_resnet_layers)
+    ub, rb = conv_algorithmic_bytes(args.dtype, eff_unet, eff_resnet)
+    assert len(ub) == n_unet_layers and len(rb) == n_resnet_layers
     alg_bytes = (sum(ub) * launches["unet"] / len(ub) + sum(rb) * launches["resnet18"] / len(rb)) / conv_n   # per launch, as traffic
 
     result = {
@@ -248,8 +253,8 @@ def main():
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "e2e-cnn b=256/GPU: UNet(3->1, transposed-conv) 256x256 on 256 boards + ResNet-18(1ch,13cls) on "
                                "16384 64x64 squares per step per GPU (BASELINE configs[3]; configs[4] shape at 8 GPUs); inputs resident in HBM",
-                   "boards_per_gpu": B, "global_boards_per_step": world * B, "unet_chunk": args.unet_chunk,
-                   "resnet_chunk": args.resnet_chunk, "parallelism": f"replicas x{world}, boards sharded, weights RCCL-broadcast once",
+                   "boards_per_gpu": B, "global_boards_per_step": world * B, "unet_chunk": eff_unet,
+                   "resnet_chunk": eff_resnet, "parallelism": f"replicas x{world}, boards sharded, weights RCCL-broadcast once",
                    "gflop_per_board": round(2 * macs_board / 1e9, 3)},
         "e2e_tflops": round(2 * macs_board * value / 1e12, 2),
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",

@@ -112,8 +112,8 @@ class Engine {
     int device = 0;
     int dt = kF16;
     std::mutex mu;
-    int unet_chunk = 32;          // images per pass: every layer still launches >= 256 workgroups of 256x256 / 128x256
-    int resnet_chunk = 8192;      // squares per pass
+    int unet_chunk = 64;          // images per pass: every layer still launches >= 256 workgroups of 256x256 / 128x256
+    int resnet_chunk = 16384;      // squares per pass
 
     struct UNet;
     struct ResNet;

@@ -30,7 +30,11 @@ Status resnet_load(Engine& e, const ParamMap& pm) {
     auto m = std::make_unique<Engine::ResNet>();
     Engine::ResNet& R = *m;
     const int dt = e.dt;
+    // the f32 engine materialises the 32x32x64 stem output (34 x 34 x 64 x 4 B per square with its border): keep that
+    // tensor under the 4 GiB the 32-bit DMA offsets address
     R.cap = e.resnet_chunk;
+    if (dt == kF32)
+        while ((uint64_t)R.cap * 34 * 34 * 64 * 4 >= (1ull << 32) && R.cap > 1) R.cap /= 2;
     const int S = R.cap;
 
     {   // stem: conv1 (64,1,7,7) + bn1

@@ -88,7 +88,7 @@ int cv_load_unet(cv_engine_t* eng, const cv_param_t* params, int n_params);
 int cv_load_resnet18(cv_engine_t* eng, const cv_param_t* params, int n_params);
 
 /* Largest number of images (UNet) / squares (ResNet) processed per internal pass; larger batches are
- * looped inside the forward call.  0 = keep default (32 images / 8192 squares).  Must be called before the first forward. */
+ * looped inside the forward call.  0 = keep default (64 images / 16384 squares).  Must be called before the first forward. */
 int cv_engine_set_chunk(cv_engine_t* eng, int unet_images, int resnet_squares);
 
 /* ---- forward (the hot path) ---------------------------------------------------------------------- */

@@ -139,14 +139,14 @@ def test_resnet18_forward_matches_oracle(prec):
 
 @pytest.mark.parametrize("prec", ["f32", "f16x3"])
 def test_full_chunks_and_small_tail_launches(prec):
-    """Default chunk sizes (32 boards / 8192 squares): the full chunk runs the 256-row tiles and the halo kernel, the
+    """Chunks of 32 boards / 8192 squares: the full chunk runs the 256-row tiles and the halo kernel, the
     one-board / 64-square tail runs the same layers from the 128-row weight packing.  Both must match the oracle."""
     from chessvision.hip_backend import HipEngine
 
     unet, resnet = synth.make_unet(seed=1), synth.make_resnet(seed=2)
     x = synth.unet_input(seed=11, batch=33)
     sq = synth.squares_input(seed=12, n=8192 + 64)
-    eng = HipEngine(precision=prec)
+    eng = HipEngine(precision=prec, unet_chunk=32, resnet_chunk=8192)
     eng.load_unet(unet.state_dict())
     eng.load_resnet18(resnet.state_dict())
     out_u = eng.unet_forward(x).cpu()

@@ -8,7 +8,7 @@ from chessvision import synthetic
 from chessvision.hip_backend import HipEngine
 
 for prec in ("f16x3", "f32", "f16"):
-    eng = HipEngine(precision=prec, unet_chunk=32, resnet_chunk=8192)
+    eng = HipEngine(precision=prec, unet_chunk=64, resnet_chunk=16384)
     eng.load_unet(synthetic.unet_state_dict(1)); eng.load_resnet18(synthetic.resnet18_state_dict(2))
     x = torch.rand(1, 3, 256, 256, device="cuda"); sq = torch.rand(64, 1, 64, 64, device="cuda")
     for _ in range(5):

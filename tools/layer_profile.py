@@ -22,10 +22,10 @@ from chessvision import synthetic  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--prec", default="f16")
-    ap.add_argument("--unet-batch", type=int, default=64)
-    ap.add_argument("--squares", type=int, default=8192)
-    ap.add_argument("--chunk", type=int, default=32)
-    ap.add_argument("--sq-chunk", type=int, default=8192)
+    ap.add_argument("--unet-batch", type=int, default=128)
+    ap.add_argument("--squares", type=int, default=16384)
+    ap.add_argument("--chunk", type=int, default=64)
+    ap.add_argument("--sq-chunk", type=int, default=16384)
     ap.add_argument("--iters", type=int, default=3)
     args = ap.parse_args()
     eng = HipEngine(precision=args.prec, unet_chunk=args.chunk, resnet_chunk=args.sq_chunk)

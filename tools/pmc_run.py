@@ -12,9 +12,9 @@ from chessvision import synthetic  # noqa: E402
 from chessvision.hip_backend import HipEngine  # noqa: E402
 
 prec, model = sys.argv[1], sys.argv[2]
-batch = int(sys.argv[3]) if len(sys.argv) > 3 else (32 if model == "unet" else 8192)
+batch = int(sys.argv[3]) if len(sys.argv) > 3 else (64 if model == "unet" else 16384)
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 2
-eng = HipEngine(precision=prec, unet_chunk=32, resnet_chunk=8192)
+eng = HipEngine(precision=prec, unet_chunk=64, resnet_chunk=16384)
 g = torch.Generator(device="cuda"); g.manual_seed(7)
 if model == "unet":
     eng.load_unet(synthetic.unet_state_dict(1))
