@@ -191,8 +191,12 @@ class HipEngine:
         self.precision = _PREC_NAMES[_PRECISIONS[precision]]
         self._h = ctypes.c_void_p()
         _check(self._lib.cv_engine_create(dev.index, _PRECISIONS[precision], ctypes.byref(self._h)))
+        # workspace size = images / squares per pass (0 = library default 64 / 16384, ~20 GB of activations: sized for
+        # throughput; a single-image server can set CHESSVISION_HIP_UNET_CHUNK=1 CHESSVISION_HIP_RESNET_CHUNK=64)
+        unet_chunk = int(unet_chunk or os.environ.get("CHESSVISION_HIP_UNET_CHUNK", "0") or 0)
+        resnet_chunk = int(resnet_chunk or os.environ.get("CHESSVISION_HIP_RESNET_CHUNK", "0") or 0)
         if unet_chunk or resnet_chunk:
-            _check(self._lib.cv_engine_set_chunk(self._h, int(unet_chunk), int(resnet_chunk)))
+            _check(self._lib.cv_engine_set_chunk(self._h, unet_chunk, resnet_chunk))
         self.has_unet = False
         self.has_resnet = False
 
