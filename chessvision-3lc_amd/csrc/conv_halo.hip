@@ -541,7 +541,8 @@ static hipError_t launch_halo(const ConvParams& p, int n_images, hipStream_t str
     static_assert(halo_lds<CT, TH, NW, TPS, NSW, IMG>() <= 160 * 1024, "LDS budget");
     // persistent only where it pays (same-box A/B, r01_tuning.md step 22): several tiles per CU and a K loop short enough
     // for the hidden prologue to matter; long loops lose ~1 % to the single-row staging
-    if (NW == 8 && halo_persistent<NW>() && tiles >= 4 * g_halo_cus && p.nStages <= 72) {
+    static const int max_k = [] { const char* v = std::getenv("CV_HALO_PERSIST_MAXK"); return v && *v ? std::atoi(v) : 72; }();
+    if (NW == 8 && halo_persistent<NW>() && tiles >= 4 * g_halo_cus && p.nStages <= max_k) {
         auto kern = conv3x3_halo_kernel<T, CT, TH, WGC, NW, TPS, NSW, IMG, NW == 8>;
         const int grid = tiles < g_halo_cus ? tiles : g_halo_cus;
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * NW), lds, stream, p);
