@@ -106,6 +106,18 @@ template <int N> struct OutVec<split_t, N> {
             *reinterpret_cast<half8*>(p + i * 4 + (par ? 0 : 16)) = lo;
         }
     }
+    // one 16-byte half of the 32-byte group starting at ch0: the hi chunk (want_hi) or the lo chunk.  Lets two lanes that
+    // hold the same eight values share one store instruction (fused max-pool: both pixels of a pair hold the maximum).
+    static __device__ __forceinline__ void store_half(split_t* dst, int ch0, const float* v, bool want_hi) {
+        const int par = (ch0 >> 3) & 1;                  // even group: [hi, lo]; odd group: [lo, hi]
+        half8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const half_t hi = (half_t)v[j];
+            o[j] = want_hi ? hi : (half_t)(v[j] - (float)hi);
+        }
+        *reinterpret_cast<half8*>(reinterpret_cast<char*>(dst) + ((want_hi ? par : par ^ 1) ? 16 : 0)) = o;
+    }
     static __device__ __forceinline__ void add(const split_t* src, int ch0, float* v) {
         const char* p = reinterpret_cast<const char*>(src);
 #pragma unroll

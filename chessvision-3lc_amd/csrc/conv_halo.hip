@@ -477,12 +477,26 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 }
             }
             if (IMG == 0 && pbase) {                     // wave-uniform: fused 2x2 max-pool of the (post-ReLU) row pair
+                // The horizontal partner pixel is read from the staged row itself (values there are already ReLU'd:
+                // pooled layers carry no residual).  Lane shuffles would be eight dependent LDS round trips per unit
+                // and doubled this epilogue (r01_tuning.md step 25).
                 float m[UN];
 #pragma unroll
-                for (int j = 0; j < UN; ++j) {
-                    const float v = RG == 2 ? (w[0][j] > w[RG - 1][j] ? w[0][j] : w[RG - 1][j]) : w[0][j];
-                    const float o = __shfl_xor(v, UPP);  // the horizontal partner pixel sits UPP lanes away
-                    m[j] = v > o ? v : o;
+                for (int j = 0; j < UN; j += 4) {
+                    f4 best = *reinterpret_cast<const f4*>(stg + (px ^ 1) * SROW + (cu * UN + j) * 4);
+#pragma unroll
+                    for (int r = 1; r < RG; ++r) {
+                        const f4 t = *reinterpret_cast<const f4*>(stg + r * (16 * SROW) + (px ^ 1) * SROW + (cu * UN + j) * 4);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) best[k] = best[k] > t[k] ? best[k] : t[k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float v = w[0][j + k];
+#pragma unroll
+                        for (int r = 1; r < RG; ++r) v = v > w[r][j + k] ? v : w[r][j + k];
+                        m[j + k] = v > best[k] ? v : best[k];
+                    }
                 }
                 bool emit = true;
                 if constexpr (RG == 1) {                 // one row per pass: the upper row of a pair waits in registers
@@ -496,8 +510,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     }
                 }
                 const unsigned qb = (unsigned)((eN * p.pHp + ((oy0 + g0) >> 1) + 1) * p.pWp + ((eTx * 16 + px) >> 1) + 1);
-                if (emit && (px & 1) == 0 && co < p.rows)
-                    OutVec<T, UN>::store(pbase + (qb * (unsigned)p.pCs + (unsigned)(p.pCoff + co)), p.pCoff + co, m);
+                if constexpr (kSplit16) {                // both pixels of a pair hold the maximum: one stores hi, the other lo
+                    if (emit && co < p.rows)
+                        OutVec<T, UN>::store_half(pbase + (qb * (unsigned)p.pCs + (unsigned)(p.pCoff + co)), p.pCoff + co, m, (px & 1) == 0);
+                } else {
+                    if (emit && (px & 1) == 0 && co < p.rows)
+                        OutVec<T, UN>::store(pbase + (qb * (unsigned)p.pCs + (unsigned)(p.pCoff + co)), p.pCoff + co, m);
+                }
             }
         }
         asm volatile("" ::: "memory");
