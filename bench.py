@@ -208,6 +208,7 @@ def main():
     value = world * B * args.steps / elapsed
 
     if rank != 0:
+        cvd.barrier(device)                              # leave together with rank 0 (it still profiles and reports)
         cvd.shutdown()
         return
 
@@ -281,6 +282,7 @@ def main():
         except Exception as exc:                                          # extra figure only; never hides the headline
             result["pipeline_e2e"] = {"error": repr(exc)}
     print(json.dumps(result), flush=True)
+    cvd.barrier(device)
     cvd.shutdown()
 
 
