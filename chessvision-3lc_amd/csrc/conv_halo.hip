@@ -24,7 +24,8 @@
 
 namespace cv {
 
-// TPS = taps per stage (1, or 3 = one filter row: fewer, fatter stages for the 64-row tile); NSW = weight ring depth.
+// TPS = taps per weight stage and NSW = weight ring depth (1 and 3 in every shipped configuration: the pipelined loop is
+// written for them; a filter-row variant was measured and dropped, r01_tuning.md).
 // IMG = 0: one TH x 16 patch of one (large) image per workgroup.  IMG = 8: feature maps of 8 x 8 (ResNet layer2): the
 // 16 x 16 pixel tile is four whole images (2 x 2), whose zero-bordered 10 x 10 PHWC planes are contiguous in memory, so
 // the "halo" is simply 400 consecutive pixels and a fragment's 16 lanes read row y of two neighbouring images.
