@@ -168,6 +168,24 @@ def test_full_chunks_and_small_tail_launches(prec):
     assert max(err_u, err_r, err_one, err_few) <= 1e-3, (err_u, err_r, err_one, err_few)
 
 
+def test_forward_passes_are_deterministic():
+    """No atomics, fixed tile schedules: the same input gives bit-identical outputs run after run, and a board gives the
+    same logits whether it travels alone or inside a batch of the same launch class (chunk boundaries do not leak)."""
+    from chessvision.hip_backend import HipEngine
+
+    eng = HipEngine(precision="f16x3", unet_chunk=4, resnet_chunk=256)
+    eng.load_unet(synth.make_unet(seed=1).state_dict())
+    eng.load_resnet18(synth.make_resnet(seed=2).state_dict())
+    x = synth.unet_input(seed=31, batch=6).cuda()
+    sq = synth.squares_input(seed=32, n=300).cuda()
+    a, b = eng.unet_forward(x), eng.unet_forward(x)
+    c, d = eng.resnet18_forward(sq), eng.resnet18_forward(sq)
+    assert torch.equal(a, b) and torch.equal(c, d)
+    assert torch.equal(eng.unet_forward(x[:4]), a[:4])          # first chunk of the batch == the same four boards alone
+    assert torch.equal(eng.resnet18_forward(sq[:256]), c[:256])
+    eng.close()
+
+
 def test_empty_batches_are_no_ops():
     """B = 0 is legal at the seam (an image without a detected board yields no squares): shapes only, no launches."""
     from chessvision.hip_backend import HipEngine
