@@ -3,21 +3,23 @@
 
 One "step" = one pass of the hot path over one batch of synthetic boards, resident in HBM:
     UNet(3->1) forward on B 256x256 images  +  ResNet-18 forward on 64*B 64x64 squares
-(BASELINE.json configs[3]/[4]: the end-to-end batch of 256 boards per GPU; the classical-CV stages between
-the two models are SURVEY.md section 8(f) "next" rows and are not inside the timed region).
+(BASELINE.json configs[3]/[4]: the end-to-end batch of 256 boards per GPU; the classical-CV stages between the two models
+are SURVEY.md section 8(f) rows, reported in the `pipeline_e2e` block, never inside `value`).
 
-    python bench.py --gpus N --steps K --warmup W [--dtype f32|f16] [--boards B]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--dtype f16x3|f32|f16] [--unet-variant convT|bilinear] [--boards B]
 
-One process per GPU; weights are generated on rank 0 and replicated with ONE RCCL broadcast; boards are
-sharded (each rank owns B boards, no data-path collective) => "scaling": "weak".  Rank 0 prints one JSON line.
+N > 1 from a bare shell: the process re-launches itself under torch.distributed.run (one rank per GPU, RCCL) BEFORE anything
+touches the GPU, relays rank 0's JSON line and exits with the children's return code.  Under a launcher (WORLD_SIZE set) it
+runs as one rank.  Weights are generated on rank 0 and replicated with ONE RCCL broadcast; boards are sharded (each rank owns
+B boards, no data-path collective) => "scaling": "weak".  Rank 0 prints one JSON line.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -26,19 +28,44 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT / "chessvision-3lc_amd"))
 sys.path.insert(0, str(ROOT))
 
-import torch  # noqa: E402
+import torch  # noqa: E402  (importing torch does not initialise the GPU)
 
-# MI355X dense MFMA peaks (MI355X_MICROARCH.md, chip table): f32-input MFMA 157.3 TF, f16 MFMA ~2500 TF.
+# MI355X dense MFMA peaks (MI355X_MICROARCH.md, chip table): f32-input MFMA 157.3 TF, f16 MFMA ~2500 TF; HBM3E 8 TB/s.
 # f16x3 computes every algorithmic MAC with THREE f16 MFMA products (hi*hi + hi*lo + lo*hi), so the dense peak of
 # that arithmetic type is 2500 / 3 algorithmic TFLOP/s; the line also carries the fraction of the raw f16 peak.
 PEAK_TFLOPS = {"f32": 157.3, "f16": 2500.0, "f16x3": 2500.0 / 3.0}
 MFMA_PER_MAC = {"f32": 1, "f16": 1, "f16x3": 3}
+HBM_PEAK_GBS = 8000.0
+PMC_FILE = "profiles/r02_pmc_traffic.json"
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def relaunch_under_torchrun(args, argv) -> int:
+    """--gpus N > 1 without a launcher: start N ranks as a CHILD process tree (never exec: a process that has touched the GPU
+    must not be replaced, and this parent has not touched it yet) and hand back its return code."""
+    n_dev = torch.cuda.device_count()                       # counting devices does not initialise the GPU
+    if n_dev < args.gpus:
+        log(f"bench.py: --gpus {args.gpus} but only {n_dev} device(s) visible")
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + argv
+    log("bench.py: launching", " ".join(cmd))
+    return subprocess.run(cmd, env=env).returncode          # children inherit stdout: rank 0's JSON line is relayed as is
 
 
 def pmc_traffic(dtype, unet_chunk, resnet_chunk, unet_launches, resnet_launches):
-    """Per-launch HBM bytes of the conv family from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json:
-    separate --pmc FETCH_SIZE / WRITE_SIZE runs of the same chunk sizes, gfx950-corrected); None if not collected."""
-    path = ROOT / "profiles" / "r01_pmc_traffic.json"
+    """Per-launch HBM bytes of the conv family from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE
+    runs of the same chunk sizes, gfx950-corrected, tools/pmc_collect.sh).  Not measured by this run: the field carries its
+    source; None when no matching profile is committed."""
+    path = ROOT / PMC_FILE
     if not path.exists() or (unet_chunk, resnet_chunk) != (64, 16384):
         return None
     t = json.load(open(path))
@@ -49,176 +76,137 @@ def pmc_traffic(dtype, unet_chunk, resnet_chunk, unet_launches, resnet_launches)
     return total / max(1, unet_launches + resnet_launches)
 
 
-def conv_algorithmic_bytes(dtype, unet_chunk, resnet_chunk):
-    """Compulsory HBM bytes of the conv launches of one UNet chunk and one ResNet-18 chunk: every layer's input
-    (+ residual), output and weights moved once at the engine's storage width (f32 4 B, f16 2 B, f16x3 4 B = hi+lo)."""
-    esz = {"f32": 4, "f16": 2, "f16x3": 4}[dtype]
-    def conv(n, hw_out, cin, cout, k=3, stride=1, res=False, out_ch=None):
-        px = n * hw_out * hw_out
-        inp = px * (stride * stride if k == 3 else 1) * cin                  # a strided 1x1 reads every other pixel only
-        return (inp + px * (cout if out_ch is None else out_ch) * (2 if res else 1) + k * k * cin * cout) * esz
-    u, n = [], unet_chunk
-    u += [conv(n, 256, 8, 64), conv(n, 256, 64, 64)]                                   # 3 input channels stored as 8
-    u[-1] += n * 128 * 128 * 64 * esz                                                  # + the fused 2x2 max-pool's output
-    for hw, c in ((128, 64), (64, 128), (32, 256), (16, 512)):
-        u += [conv(n, hw, c, 2 * c), conv(n, hw, 2 * c, 2 * c)]
-        if hw > 16:
-            u[-1] += n * (hw // 2) ** 2 * 2 * c * esz
-    for hw, c in ((32, 1024), (64, 512), (128, 256), (256, 128)):                      # hw = output of the transposed conv
-        u.append((n * (hw // 2) ** 2 * c + n * hw * hw * (c // 2) + 4 * c * (c // 2)) * esz)
-        last = hw == 256
-        u += [conv(n, hw, c, c // 2), conv(n, hw, c // 2, c // 2, out_ch=1 if last else None)]   # fused 1x1 head: 1 channel out
-    r, n = [], resnet_chunk
-    r += [conv(n, 16, 64, 64), conv(n, 16, 64, 64, res=True)] * 2
-    for hw, c in ((8, 64), (4, 128), (2, 256)):
-        r += [conv(n, hw, c, 2 * c, stride=2), conv(n, hw, c, 2 * c, k=1, stride=2), conv(n, hw, 2 * c, 2 * c, res=True),
-              conv(n, hw, 2 * c, 2 * c), conv(n, hw, 2 * c, 2 * c, res=True)]
-    return u, r
-
-
-def log(*a):
-    print(*a, file=sys.stderr, flush=True)
-
-
-def cpu_baseline(x_cpu: torch.Tensor, sq_cpu: torch.Tensor, gpu_logits: torch.Tensor, gpu_cls: torch.Tensor,
-                 budget_s: float = 12.0, max_boards: int = 64):
-    """Time the oracle (torch-CPU restatement = the arithmetic the reference runs) the way the reference drives
-    it -- UNet batch 1 + classifier batch 64 per board (core.py:215-220,236-241) -- on a bounded sample, and
-    use the same outputs to check the GPU results.  This is the ONLY place bench.py touches oracle/."""
-    from oracle import synth
+# ---- CPU baseline leg: the ONLY place bench.py touches oracle/ (as the checker and the timed CPU port) -------------------
+def cpu_baseline(x_cpu, sq_cpu, gpu_logits, gpu_cls, e2e_images=None, budget_s: float = 12.0):
+    """Time the oracle (torch-CPU restatement = the arithmetic the reference runs) on a bounded sample:
+      (i)  the reference-style loop -- UNet batch 1 + classifier batch 64 per board (core.py:215-220,236-241) -- at the thread
+           count that is fastest on this box (swept: the default of one thread per logical core oversubscribes this loop);
+      (ii) batched (UNet b=8, ResNet-18 b=512), what a batched CPU implementation would reach.
+    The same outputs check the GPU results; with `e2e_images` the oracle pipeline also produces reference FENs."""
+    from oracle import pipeline_ref, synth
 
     unet, resnet = synth.make_unet(1), synth.make_resnet(2)
-    threads = torch.get_num_threads()
     unet = unet.to(memory_format=torch.channels_last)            # core.py:89
-    errs_u, errs_r = [], []
+    ncpu = os.cpu_count() or 1
+    default_threads = torch.get_num_threads()
+    sweep = {}
     with torch.no_grad():
         unet(x_cpu[:1]); resnet(sq_cpu[:64])                      # warm-up
+        for t in sorted({t for t in (8, 16, 32, 64, 128, default_threads) if t <= max(ncpu, 1)}):
+            torch.set_num_threads(t)
+            unet(x_cpu[:1]); resnet(sq_cpu[:64])
+            t0 = time.perf_counter()
+            for b in range(2):
+                unet(x_cpu[b:b + 1]); resnet(sq_cpu[b * 64:(b + 1) * 64])
+            sweep[t] = 2 / (time.perf_counter() - t0)
+        best = max(sweep, key=sweep.get)
+        torch.set_num_threads(best)
+        errs_u, errs_r, ref_u, ref_r = [], [], [], []
         t0 = time.perf_counter()
         done = 0
-        while done < min(max_boards, x_cpu.shape[0]):
+        while done < min(64, x_cpu.shape[0]):
             lo = unet(x_cpu[done:done + 1])
             cl = resnet(sq_cpu[done * 64:(done + 1) * 64])
             errs_u.append(float((lo - gpu_logits[done:done + 1]).abs().max()))
             errs_r.append(float((cl - gpu_cls[done * 64:(done + 1) * 64]).abs().max()))
+            ref_u.append(lo); ref_r.append(cl)
             done += 1
             if time.perf_counter() - t0 >= budget_s:
                 break
         dt = time.perf_counter() - t0
-    return ({"value": round(done / dt, 3), "unit": "boards/sec", "cores": threads, "kind": "port",
-             "sample": f"{done} boards, reference-style loop (UNet b=1 + ResNet-18 b=64 per board), torch {torch.__version__} CPU fp32, "
-                       f"{os.cpu_count()} logical CPUs"},
-            {"unet_logit_max_abs_err": max(errs_u), "resnet_logit_max_abs_err": max(errs_r), "boards_checked": done})
+        nb = min(8, x_cpu.shape[0])
+        unet(x_cpu[:nb]); resnet(sq_cpu[:nb * 64])
+        t1 = time.perf_counter()
+        unet(x_cpu[:nb]); resnet(sq_cpu[:nb * 64])
+        batched = nb / (time.perf_counter() - t1)
+        fens = None
+        if e2e_images is not None:
+            from chessvision import synthetic
+            from oracle.unet_ref import UNet
+            seg = UNet(3, 1, False)
+            seg.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.unet_state_dict(1, segmenting=True).items()}, strict=False)
+            ref = pipeline_ref.process_images(seg.eval(), resnet, e2e_images, fallback_quad=True)
+            fens = [(r.position.fen, r.position.original_fen, r.position.model_probabilities) for r in ref]
+        torch.set_num_threads(default_threads)
+    base = {"value": round(done / dt, 3), "unit": "boards/sec", "cores": best, "kind": "port",
+            "sample": f"{done} boards, reference-style loop (UNet b=1 + ResNet-18 b=64 per board), torch {torch.__version__} CPU fp32 "
+                      f"channels_last, {best} threads (fastest of the sweep), {ncpu} logical CPUs",
+            "thread_sweep_boards_per_sec": {str(k): round(v, 3) for k, v in sweep.items()},
+            "batched": {"value": round(batched, 3), "unit": "boards/sec", "cores": best,
+                        "sample": f"one pass of UNet b={nb} + ResNet-18 b={nb * 64} after one warm-up pass"}}
+    return (base, {"unet_logit_max_abs_err": max(errs_u), "resnet_logit_max_abs_err": max(errs_r), "boards_checked": done}, fens,
+            (torch.cat(ref_u), torch.cat(ref_r)))
 
 
-def pipeline_e2e(dtype: str, n_boards: int = 256):
+def pipeline_e2e(dtype: str, n_boards: int = 256, n_checked: int = 8):
     """BASELINE configs[3] end to end through the public API: 512x512 BGR photos on the HOST -> ChessVision.process_images
-    (H2D, resize, UNet, mask D2H, C++ contour, warp+split, ResNet-18, softmax, FEN).  Random-init weights never draw a
-    quadrangle, so fallback_quad routes every board through the classifier; reported beside the
-    headline, never as `value`."""
+    (staging, H2D, resize, UNet, mask D2H, C++ contour, warp+split, ResNet-18, softmax, D2H, C++ FEN).  The UNet weights are
+    random except for one rewired channel that makes it segment the synthetic photos (synthetic.make_segmenting), so the
+    contour stage sees realistic masks; boards without a quadrangle go through fallback_quad.  Reported beside the headline,
+    never as `value`.  Returns (block, images of the checked subset, results of the checked subset)."""
     import tempfile
-
-    import numpy as np
 
     from chessvision import ChessVision, synthetic
 
     with tempfile.TemporaryDirectory() as d:
-        pe, pc = synthetic.save_checkpoints(d)
+        pe, pc = synthetic.save_checkpoints(d, segmenting=True)
         cv = ChessVision(board_extractor_weights=str(pe), classifier_weights=str(pc), precision=dtype)
-        rng = np.random.default_rng(0)
-        images = [rng.integers(0, 256, (512, 512, 3), dtype=np.uint8) for _ in range(n_boards)]
-        cv.process_images(images[:80], fallback_quad=True)                # warm-up (lazy model init, pinned buffers)
-        t0 = time.perf_counter()
-        res = cv.process_images(images, fallback_quad=True)
-        dt = time.perf_counter() - t0
-    found = sum(r.position is not None for r in res)
-    return {"boards_per_sec": round(n_boards / dt, 1), "boards": n_boards, "classified": found,
-            "note": "host images in, FEN out, one host thread software-pipelined against the GPU in jobs of 64 boards; includes PCIe, "
-                    "the C++ contour stage and Python post-processing"}
+        images = [synthetic.board_photo(s) for s in range(n_boards)]
+        cv.process_images(images[:96], fallback_quad=True)                # warm-up (lazy model init, pinned buffers, workspace)
+        best, tm_best, res = None, None, None
+        for _ in range(3):
+            tm = {}
+            t0 = time.perf_counter()
+            res = cv.process_images(images, fallback_quad=True, timings=tm)
+            dt = time.perf_counter() - t0
+            if best is None or dt < best:
+                best, tm_best = dt, tm
+    classified = sum(r.position is not None for r in res)
+    whole = cv._scale_quadrangle(__import__("numpy").array([[[255, 0]], [[0, 0]], [[0, 255]], [[255, 255]]], "int32"), (512, 512))
+    found = sum(r.board_extraction.quadrangle is not None and not (r.board_extraction.quadrangle == whole).all() for r in res)
+    block = {"boards_per_sec": round(n_boards / best, 1), "boards": n_boards, "classified": classified, "quadrangles_found": found,
+             "stages": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in tm_best.items()},
+             "note": "host images in, FEN out (best of 3 calls); one host thread software-pipelined against the GPU in jobs of 64 boards, "
+                     "copies on side streams; stages: host seconds (*_s) and event-timed GPU milliseconds (*_ms) summed over the jobs"}
+    return block, images[:n_checked], res[:n_checked]
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--dtype", default=os.environ.get("CV_BENCH_DTYPE", "f16x3"), choices=["f32", "f16", "f16x3"])
-    ap.add_argument("--boards", type=int, default=256, help="boards per GPU per step")
-    ap.add_argument("--unet-chunk", type=int, default=64)
-    ap.add_argument("--resnet-chunk", type=int, default=16384)
-    ap.add_argument("--overlap", type=int, default=int(os.environ.get("CV_BENCH_OVERLAP", "0")),
-                    help="1: enqueue the UNet pass and the ResNet pass of a step on two HIP streams (they are independent)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=12.0)
-    args = ap.parse_args()
-
-    from chessvision import distributed as cvd
-    from chessvision import synthetic
-    from chessvision.hip_backend import HipEngine
-
-    rank, world, device = cvd.init_process_group()
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    if device.type != "cuda":
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-
-    # ---- weights: rank 0 generates, one RCCL broadcast replicates (SURVEY.md section 8e) ----
-    uspec, rspec = synthetic.unet_spec(False), synthetic.resnet18_spec()
-    usd = cvd.broadcast_state_dict(synthetic.unet_state_dict(1) if rank == 0 else None, uspec, device)
-    rsd = cvd.broadcast_state_dict(synthetic.resnet18_state_dict(2) if rank == 0 else None, rspec, device)
-    eng = HipEngine(device, precision=args.dtype, unet_chunk=args.unet_chunk, resnet_chunk=args.resnet_chunk)
-    eng.load_unet(usd)
-    eng.load_resnet18(rsd)
-
-    # ---- synthetic inputs, resident in HBM before the timed region ----
-    B = args.boards
-    gen = torch.Generator(device=device)
-    gen.manual_seed(1234 + rank)
-    x = (torch.randint(0, 256, (B, 3, 256, 256), dtype=torch.uint8, device=device, generator=gen).float() / 255)
-    sq = torch.randint(0, 256, (B * 64, 1, 64, 64), dtype=torch.uint8, device=device, generator=gen).float()
-    sq /= 255.0
-
-    streams = [torch.cuda.Stream(device), torch.cuda.Stream(device)] if args.overlap else None
-
+def measure(eng, x, sq, steps, warmup, device, cvd, streams=None):
+    """W warm-up steps, then exactly K timed steps bracketed by barrier + synchronize; returns (seconds, outputs of the last step)."""
     def step():
         if streams is None:
-            return eng.unet_forward(x), eng.resnet18_forward(sq)
+            return eng.unet_forward(x, check=False), eng.resnet18_forward(sq, check=False)
         cur = torch.cuda.current_stream(device)
         for st in streams:
             st.wait_stream(cur)
         with torch.cuda.stream(streams[0]):
-            a = eng.unet_forward(x)
+            a = eng.unet_forward(x, check=False)
         with torch.cuda.stream(streams[1]):
-            b = eng.resnet18_forward(sq)
+            b = eng.resnet18_forward(sq, check=False)
         for st in streams:
             cur.wait_stream(st)
         return a, b
 
-    for _ in range(args.warmup):
-        step()
+    for _ in range(warmup):
+        out = step()
     cvd.barrier(device)
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         out = step()
     torch.cuda.synchronize(device)
     cvd.barrier(device)
-    elapsed = time.perf_counter() - t0
-    elapsed = cvd.max_over_ranks(elapsed, device)
-    ms_per_step = elapsed / args.steps * 1e3
-    value = world * B * args.steps / elapsed
+    elapsed = cvd.max_over_ranks(time.perf_counter() - t0, device)
+    eng.check_numerics()                                           # the numeric guard, once for the whole run
+    return elapsed, out
 
-    if rank != 0:
-        cvd.barrier(device)                              # leave together with rank 0 (it still profiles and reports)
-        cvd.shutdown()
-        return
 
-    # ---- roofline of the dominant kernel (the implicit-GEMM conv family), HIP events on the launch stream ----
+def rooflines(eng, x, sq, dtype, B, quiet=False):
+    """HIP-event timing of every launch of one step on the launch stream (cv_profile_convs): the MFMA roofline of the conv
+    family and the HBM roofline of each memory-bound kernel (algorithmic bytes / event time / 8 TB/s)."""
     conv_ms = conv_n = 0
-    conv_flop = 0.0
-    all_ms = 0.0
-    table = {}
-    launches = {}
-    per_model = {}
+    conv_flop = conv_bytes = all_ms = 0.0
+    table, launches, per_model, hbm = {}, {}, {}, {}
     for model, inp in (("unet", x), ("resnet18", sq)):
         c_ms, c_n, a_ms, entries = eng.profile(model, inp, iters=1)
         conv_ms += c_ms; conv_n += c_n; all_ms += a_ms
@@ -227,60 +215,188 @@ def main():
         for e in entries:
             if e["conv"]:
                 conv_flop += 2.0 * e["macs"]
+                conv_bytes += e["bytes"]
                 per_model[model][1] += 2.0 * e["macs"]
-            t = table.setdefault(f"{model}:{e['name']}", [0.0, 0.0])
-            t[0] += e["ms"]; t[1] += 2.0 * e["macs"]
+            else:
+                h = hbm.setdefault(e["name"], [0.0, 0.0, 0])
+                h[0] += e["ms"]; h[1] += e["bytes"]; h[2] += 1
+            t = table.setdefault(f"{model}:{e['name']}", [0.0, 0.0, 0.0])
+            t[0] += e["ms"]; t[1] += 2.0 * e["macs"]; t[2] += e["bytes"]
+    if not quiet:
+        for k, (ms, fl, by) in table.items():
+            log(f"  {k:52s} {ms:9.3f} ms {fl / (ms * 1e-3) / 1e12 if ms > 0 else 0:8.1f} TFLOP/s {by / (ms * 1e-3) / 1e9 if ms > 0 else 0:9.1f} GB/s")
     achieved = conv_flop / (conv_ms * 1e-3) / 1e12
-    peak = PEAK_TFLOPS[args.dtype]
-    for k, (ms, fl) in table.items():
-        log(f"  {k:52s} {ms:9.3f} ms {fl / (ms * 1e-3) / 1e12 if ms > 0 else 0:8.1f} TFLOP/s")
+    peak = PEAK_TFLOPS[dtype]
+    roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4),
+            "algorithmic_bytes": conv_bytes / max(conv_n, 1),
+            "kernel": "cv::conv_igemm_kernel + cv::conv3x3_halo_kernel (the conv family, all instantiations)", "launches_per_step": conv_n,
+            "avg_launch_ms": round(conv_ms / max(conv_n, 1), 4), "algorithmic_gflop_per_step": round(conv_flop / 1e9, 2),
+            "by_model": {m: {"achieved": round(fl / (ms * 1e-3) / 1e12, 2), "frac": round(fl / (ms * 1e-3) / 1e12 / peak, 4)}
+                         for m, (ms, fl) in per_model.items()},       # north_star: >= 50 % on the UNet conv stages
+            "mfma_products_per_mac": MFMA_PER_MAC[dtype],
+            "mfma_issued_tflops": round(achieved * MFMA_PER_MAC[dtype], 2),
+            "frac_of_raw_mfma_peak": round(achieved * MFMA_PER_MAC[dtype] / (157.3 if dtype == "f32" else 2500.0), 4),
+            "conv_family_hbm_gbs": round(conv_bytes / (conv_ms * 1e-3) / 1e9, 1)}
+    roof_hbm = {name: {"bound": "hbm", "achieved": round(by / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "launches": cnt, "ms_per_step": round(ms, 4),
+                       "algorithmic_mb_per_launch": round(by / cnt / 1e6, 2)}
+                for name, (ms, by, cnt) in hbm.items() if ms > 0}
+    return roof, roof_hbm, launches, conv_ms, conv_n, all_ms
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--dtype", default=os.environ.get("CV_BENCH_DTYPE", "f16x3"), choices=["f32", "f16", "f16x3"])
+    ap.add_argument("--unet-variant", default="convT", choices=["convT", "bilinear"],
+                    help="UNet up-sampling: transposed conv (default checkpoint layout) or bilinear (train_unet.py:440,461-465)")
+    ap.add_argument("--boards", type=int, default=256, help="boards per GPU per step")
+    ap.add_argument("--unet-chunk", type=int, default=64)
+    ap.add_argument("--resnet-chunk", type=int, default=16384)
+    ap.add_argument("--overlap", type=int, default=int(os.environ.get("CV_BENCH_OVERLAP", "0")),
+                    help="1: enqueue the UNet pass and the ResNet pass of a step on two HIP streams (they are independent)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the by_dtype / by_variant / pipeline_e2e blocks")
+    ap.add_argument("--cpu-budget", type=float, default=12.0)
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch_under_torchrun(args, sys.argv[1:]))
+
+    from chessvision import distributed as cvd
+    from chessvision import synthetic
+    from chessvision.hip_backend import HipEngine
+
+    rank, world, device = cvd.init_process_group()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if device.type != "cuda":
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+
+    # ---- weights: rank 0 generates, one RCCL broadcast replicates ----
+    bilinear = args.unet_variant == "bilinear"
+    uspec, rspec = synthetic.unet_spec(bilinear), synthetic.resnet18_spec()
+    usd = cvd.broadcast_state_dict(synthetic.unet_state_dict(1, bilinear) if rank == 0 else None, uspec, device)
+    rsd = cvd.broadcast_state_dict(synthetic.resnet18_state_dict(2) if rank == 0 else None, rspec, device)
+    rccl_ranks = cvd.count_ranks(device)                         # an all-reduce of ones over RCCL: every rank really took part
+
+    def make_engine(dtype, unet_sd=usd):
+        e = HipEngine(device, precision=dtype, unet_chunk=args.unet_chunk, resnet_chunk=args.resnet_chunk)
+        e.load_unet(unet_sd)
+        e.load_resnet18(rsd)
+        return e
+
+    eng = make_engine(args.dtype)
+
+    # ---- synthetic inputs, resident in HBM before the timed region ----
+    B = args.boards
+    gen = torch.Generator(device=device)
+    gen.manual_seed(1234 + rank)
+    x = (torch.randint(0, 256, (B, 3, 256, 256), dtype=torch.uint8, device=device, generator=gen).float() / 255)
+    sq = torch.randint(0, 256, (B * 64, 1, 64, 64), dtype=torch.uint8, device=device, generator=gen).float()
+    sq /= 255.0
+    streams = [torch.cuda.Stream(device), torch.cuda.Stream(device)] if args.overlap else None
+
+    elapsed, out = measure(eng, x, sq, args.steps, args.warmup, device, cvd, streams)
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * B * args.steps / elapsed
+
+    if rank != 0:
+        cvd.barrier(device)                              # leave together with rank 0 (it still profiles and reports)
+        cvd.shutdown()
+        return
+
+    roof, roof_hbm, launches, conv_ms, conv_n, all_ms = rooflines(eng, x, sq, args.dtype, B)
     macs_board = eng.model_macs("unet") + 64 * eng.model_macs("resnet18")
     log(f"  step: {ms_per_step:.2f} ms; event-timed kernels {all_ms:.2f} ms; conv family {conv_ms:.2f} ms over {conv_n} launches")
 
     # effective chunk sizes from the launch counts (the f32 engine halves the classifier chunk to stay under 4 GiB per tensor)
-    n_unet_layers, n_resnet_layers = 22, 19
+    n_unet_layers, n_resnet_layers = (18 if bilinear else 22), 19
     assert launches["unet"] % n_unet_layers == 0 and launches["resnet18"] % n_resnet_layers == 0, launches
     eff_unet = B // (launches["unet"] // n_unet_layers)
     eff_resnet = B * 64 // (launches["resnet18"] // n_resnet_layers)
-    ub, rb = conv_algorithmic_bytes(args.dtype, eff_unet, eff_resnet)
-    assert len(ub) == n_unet_layers and len(rb) == n_resnet_layers
-    alg_bytes = (sum(ub) * launches["unet"] / len(ub) + sum(rb) * launches["resnet18"] / len(rb)) / conv_n   # per launch, as traffic
+    traffic = None if bilinear else pmc_traffic(args.dtype, args.unet_chunk, args.resnet_chunk, launches["unet"], launches["resnet18"])
+    roof["traffic"] = traffic
+    roof["traffic_source"] = (f"{PMC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950-corrected; a committed profile "
+                              "of this workload, NOT collected by this run)") if traffic is not None else None
+    roof["traffic_unit"] = "HBM bytes per conv launch; algorithmic_bytes = compulsory bytes per launch (cv_profile_entry_bytes)"
 
+    variant_name = "bilinear up-sampling" if bilinear else "transposed-conv"
     result = {
         "metric": "boards/sec (UNet 256x256 seg + 64-sq classify)",
         "value": round(value, 2), "unit": "boards/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "e2e-cnn b=256/GPU: UNet(3->1, transposed-conv) 256x256 on 256 boards + ResNet-18(1ch,13cls) on "
+        "config": {"workload": f"e2e-cnn b=256/GPU: UNet(3->1, {variant_name}) 256x256 on 256 boards + ResNet-18(1ch,13cls) on "
                                "16384 64x64 squares per step per GPU (BASELINE configs[3]; configs[4] shape at 8 GPUs); inputs resident in HBM",
                    "boards_per_gpu": B, "global_boards_per_step": world * B, "unet_chunk": eff_unet,
                    "resnet_chunk": eff_resnet, "parallelism": f"replicas x{world}, boards sharded, weights RCCL-broadcast once",
                    "gflop_per_board": round(2 * macs_board / 1e9, 3)},
+        "rccl_ranks_seen": rccl_ranks,
         "e2e_tflops": round(2 * macs_board * value / 1e12, 2),
-        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                     "frac": round(achieved / peak, 4),
-                     "traffic": pmc_traffic(args.dtype, args.unet_chunk, args.resnet_chunk, launches["unet"], launches["resnet18"]),
-                     "algorithmic_bytes": alg_bytes,
-                     "kernel": "cv::conv_igemm_kernel + cv::conv3x3_halo_kernel (the conv family, all instantiations)", "launches_per_step": conv_n,
-                     "avg_launch_ms": round(conv_ms / max(conv_n, 1), 4), "algorithmic_gflop_per_step": round(conv_flop / 1e9, 2),
-                     "by_model": {m: {"achieved": round(fl / (ms * 1e-3) / 1e12, 2), "frac": round(fl / (ms * 1e-3) / 1e12 / peak, 4)}
-                                  for m, (ms, fl) in per_model.items()},       # north_star: >= 50 % on the UNet conv stages
-                     "mfma_products_per_mac": MFMA_PER_MAC[args.dtype],
-                     "mfma_issued_tflops": round(achieved * MFMA_PER_MAC[args.dtype], 2),
-                     "frac_of_raw_mfma_peak": round(achieved * MFMA_PER_MAC[args.dtype] / (157.3 if args.dtype == "f32" else 2500.0), 4),
-                     "traffic_unit": "HBM bytes per conv launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json); algorithmic_bytes = compulsory bytes per launch"},
+        "roofline": roof,
+        "roofline_hbm": roof_hbm,
     }
+    oracle_out = None
     if world == 1 and not args.no_cpu_baseline:
+        e2e_block = e2e_imgs = e2e_res = None
+        if not args.no_extras:
+            try:
+                e2e_block, e2e_imgs, e2e_res = pipeline_e2e(args.dtype)
+            except Exception as exc:                                      # extra figure only; never hides the headline
+                e2e_block = {"error": repr(exc)}
         nchk = min(B, 64)
-        base, parity = cpu_baseline(x[:nchk].cpu(), sq[:nchk * 64].cpu(), out[0][:nchk].cpu(), out[1][:nchk * 64].cpu(),
-                                    budget_s=args.cpu_budget)
+        base, parity, ref_fens, oracle_out = cpu_baseline(x[:nchk].cpu(), sq[:nchk * 64].cpu(), out[0][:nchk].cpu(), out[1][:nchk * 64].cpu(),
+                                              e2e_images=e2e_imgs, budget_s=args.cpu_budget)
         result["cpu_baseline"] = base
         result["parity_vs_oracle"] = parity
-        try:
-            result["pipeline_e2e"] = pipeline_e2e(args.dtype)
-        except Exception as exc:                                          # extra figure only; never hides the headline
-            result["pipeline_e2e"] = {"error": repr(exc)}
+        if e2e_block is not None:
+            if ref_fens is not None and e2e_res is not None:
+                import numpy as np
+                mism = sum((r.position.fen, r.position.original_fen) != (f[0], f[1]) for r, f in zip(e2e_res, ref_fens))
+                perr = max(float(np.abs(r.position.model_probabilities - f[2]).max()) for r, f in zip(e2e_res, ref_fens))
+                e2e_block.update({"fen_checked": len(ref_fens), "fen_mismatches": mism, "prob_max_abs_err_vs_oracle": perr})
+            result["pipeline_e2e"] = e2e_block
+    if world == 1 and not args.no_extras:
+        # the other arithmetic types and the other checkpoint variant, 3 steps each, with their own roofline and parity
+        by_dtype = {}
+        for dt in ("f32", "f16"):
+            if dt == args.dtype:
+                continue
+            try:
+                e2 = make_engine(dt)
+                el, o2 = measure(e2, x, sq, 3, 1, device, cvd)
+                r2, _, _, _, _, _ = rooflines(e2, x, sq, dt, B, quiet=True)
+                entry = {"value": round(B * 3 / el, 2), "unit": "boards/sec", "ms_per_step": round(el / 3 * 1e3, 3), "steps": 3,
+                         "roofline": {k: r2[k] for k in ("bound", "achieved", "peak", "unit", "frac", "by_model")}}
+                if oracle_out is not None:                                # same oracle outputs as parity_vs_oracle above
+                    nb_ = oracle_out[0].shape[0]
+                    entry["parity_vs_oracle"] = {"unet_logit_max_abs_err": float((o2[0][:nb_].cpu() - oracle_out[0]).abs().max()),
+                                                 "resnet_logit_max_abs_err": float((o2[1][:nb_ * 64].cpu() - oracle_out[1]).abs().max()),
+                                                 "boards_checked": nb_}
+                by_dtype[dt] = entry
+                e2.close()
+            except Exception as exc:
+                by_dtype[dt] = {"error": repr(exc)}
+        result["by_dtype"] = by_dtype
+        if not bilinear:
+            try:
+                usd_b = synthetic.unet_state_dict(1, True)
+                e3 = make_engine(args.dtype, usd_b)
+                el, _ = measure(e3, x, sq, 3, 1, device, cvd)
+                r3, h3, _, _, _, _ = rooflines(e3, x, sq, args.dtype, B, quiet=True)
+                mb = e3.model_macs("unet") + 64 * e3.model_macs("resnet18")
+                result["by_variant"] = {"bilinear": {"value": round(B * 3 / el, 2), "unit": "boards/sec", "ms_per_step": round(el / 3 * 1e3, 3),
+                                                     "gflop_per_board": round(2 * mb / 1e9, 3),
+                                                     "roofline": {k: r3[k] for k in ("bound", "achieved", "peak", "unit", "frac", "by_model")},
+                                                     "roofline_hbm": {k: v for k, v in h3.items() if "upsample" in k}}}
+                e3.close()
+            except Exception as exc:
+                result["by_variant"] = {"bilinear": {"error": repr(exc)}}
     print(json.dumps(result), flush=True)
     cvd.barrier(device)
     cvd.shutdown()

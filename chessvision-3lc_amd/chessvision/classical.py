@@ -216,6 +216,23 @@ def get_perspective_transform(src: NDArray[np.float32], dst: NDArray[np.float32]
     return np.append(h, 1.0).reshape(3, 3)
 
 
+def get_perspective_transforms(src: NDArray[np.float32], dst: NDArray[np.float32]) -> NDArray[np.float64]:
+    """``get_perspective_transform`` for N quadrangles at once: src (N,4,2) -> (N,3,3).  One batched LAPACK solve of the
+    same 8x8 systems, so every matrix equals the per-quadrangle result bit for bit."""
+    src = np.asarray(src, dtype=np.float64).reshape(-1, 4, 2)
+    dst = np.asarray(dst, dtype=np.float64).reshape(4, 2)
+    n = src.shape[0]
+    x, y = src[:, :, 0], src[:, :, 1]
+    u, v = dst[None, :, 0], dst[None, :, 1]
+    one, zero = np.ones_like(x), np.zeros_like(x)
+    a = np.empty((n, 8, 8))
+    a[:, :4] = np.stack([x, y, one, zero, zero, zero, -x * u, -y * u], axis=-1)
+    a[:, 4:] = np.stack([zero, zero, zero, x, y, one, -x * v, -y * v], axis=-1)
+    b = np.concatenate([np.broadcast_to(u, (n, 4)), np.broadcast_to(v, (n, 4))], axis=1)
+    h = np.linalg.solve(a, b[..., None])[..., 0]
+    return np.concatenate([h, np.ones((n, 1))], axis=1).reshape(n, 3, 3)
+
+
 def warp_perspective(image: NDArray[np.uint8], m: NDArray[np.float64], size: tuple[int, int]) -> NDArray[np.uint8]:
     """dst(x, y) = bilinear(src, M^-1 (x, y, 1)), constant-zero border; source coordinates are snapped to 1/32
     pixel like OpenCV's fixed-point remap (INTER_BITS = 5)."""

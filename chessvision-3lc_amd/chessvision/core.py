@@ -59,6 +59,8 @@ class ChessVision:
         self._classifier_model_id = classifier_model_id
         self._precision = precision or os.environ.get("CHESSVISION_HIP_PRECISION", "f16x3")
         self._engine = None
+        self._streams = None
+        self._copy_pool = None
         self._init_lock = threading.RLock()
         if not lazy_load:
             logger.info("Eager loading models...")
@@ -169,24 +171,35 @@ class ChessVision:
                                                    square_crops=squares)
 
     def process_images(self, images: Sequence[NDArray[np.uint8]], threshold: float = 0.5, flip: bool = False,
-                       fallback_quad: bool = False, pipeline_chunk: int = 64) -> list[ChessVisionResult]:
-        """Batched pipeline (new; the reference processes one image per call).  Images stay on the device between
-        the two CNNs: INTER_AREA resize -> UNet (u8 in, logits + thresholded mask out); only the 64 KB masks come
-        back for the C++ contour stage; the quadrangles go back as 3x3 maps and ONE fused warp+gray+flip+split kernel
-        writes the classifier input; the classifier runs with softmax on device.  Work is cut into jobs of up to
-        ``pipeline_chunk`` equally sized images and software-pipelined on the host: while the GPU runs the UNet of job
-        k+1 the host finds the quadrangles of job k, and while it classifies job k the host writes the FENs of job k-1
-        (device->host copies land in pinned buffers behind events, so nothing blocks the stream).  Results are
-        identical in layout to ``process_image``'s."""
+                       fallback_quad: bool = False, pipeline_chunk: int = 64, return_crops: bool = False,
+                       timings: dict | None = None) -> list[ChessVisionResult]:
+        """Batched pipeline (new; the reference processes one image per call, core.py:152-195).
+
+        Images stay on the device between the two CNNs: INTER_AREA resize -> UNet (u8 in, logits + thresholded mask out);
+        only the 64 KB masks come back for the C++ contour stage; the quadrangles go back as 3x3 maps and ONE fused
+        warp+gray+flip+split kernel writes the classifier input; the classifier runs with softmax on device; labels, pawn
+        rule and FEN of a whole job are decoded by one native call.  Work is cut into jobs of up to ``pipeline_chunk``
+        equally sized images and software-pipelined: host->device copies run on their own stream out of a pinned staging
+        buffer filled by a few copy threads, device->host copies on a third stream behind events, and while the GPU runs
+        the UNet of job k+1 the host finds the quadrangles of job k and decodes job k-1.  Nothing on the host blocks the
+        compute stream.
+
+        Results have the layout of ``process_image``; their arrays are views into the page-locked result buffers of the
+        call (copy them if they must outlive a long-running server's memory budget).  ``return_crops=False`` (default)
+        leaves ``PositionResult.squares`` as None -- the crops are ``ChessVision.extract_squares(board_image)`` and cost a
+        256 KB copy per board; ``timings`` (a dict) receives host-side seconds per stage and event-timed GPU milliseconds."""
         started = time.time()
         for image in images:
             assert isinstance(image, np.ndarray) and image.dtype == np.uint8 and image.ndim == 3
         if not images:
             return []
         _ = self.board_extractor, self.classifier
-        from .hip_backend import find_quadrangles
+        from concurrent.futures import ThreadPoolExecutor
+
+        from .hip_backend import decode_positions, find_quadrangles
 
         eng = self._get_engine()
+        dev = self.device
         n = len(images)
         names = constants.SQUARE_NAMES_FLIPPED if flip else constants.SQUARE_NAMES_NORMAL
         w, h = constants.BOARD_SIZE
@@ -196,27 +209,72 @@ class ChessVision:
             groups.setdefault(im.shape, []).append(i)
         step = max(1, int(pipeline_chunk))
         jobs = [ids[k:k + step] for ids in groups.values() for k in range(0, len(ids), step)]
+        tm = timings if timings is not None else {}
+        for key in ("stage_s", "wait_masks_s", "contours_s", "homography_s", "wait_probs_s", "decode_s", "assemble_s"):
+            tm.setdefault(key, 0.0)
+        gpu_events: list[tuple[str, torch.cuda.Event, torch.cuda.Event]] = []
+
+        def clock(key, t0):
+            tm[key] += time.perf_counter() - t0
+
+        def gpu_timed(name, fn):
+            if timings is None:
+                return fn()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            out = fn()
+            b.record()
+            gpu_events.append((name, a, b))
+            return out
 
         def pinned(shape, dtype):
             return torch.empty(shape, dtype=dtype, pin_memory=True)
 
-        def segment(ids):                                   # host -> device, resize, UNet; masks start their way back
-            batch = torch.from_numpy(np.stack([images[i] for i in ids])).to(self.device, non_blocking=True)
-            small = eng.resize_area_u8(batch, (constants.INPUT_SIZE[1], constants.INPUT_SIZE[0]))
-            lg, mk = eng.unet_forward_u8(small, threshold=threshold, want_mask=True)
+        main = torch.cuda.current_stream(dev)
+        up, down = self._pipeline_streams()
+        pool = self._copy_pool
+        if pool is None:
+            pool = self._copy_pool = ThreadPoolExecutor(max_workers=4, thread_name_prefix="cv-stage")
+
+        def segment(ids):                                   # host -> device (own stream), resize, UNet; masks start back
+            t0 = time.perf_counter()
+            shape = images[ids[0]].shape
+            staged = pinned((len(ids),) + shape, torch.uint8)
+            view = staged.numpy()
+            list(pool.map(lambda k: np.copyto(view[k], images[ids[k]]), range(len(ids))))
+            clock("stage_s", t0)
+            with torch.cuda.stream(up):
+                batch = staged.to(dev, non_blocking=True)
+                arrived = torch.cuda.Event()
+                arrived.record()
+            main.wait_event(arrived)
+            batch.record_stream(main)
+            small = gpu_timed("resize_ms", lambda: eng.resize_area_u8(batch, (constants.INPUT_SIZE[1], constants.INPUT_SIZE[0])))
+            lg, mk = gpu_timed("unet_ms", lambda: eng.unet_forward_u8(small, threshold=threshold, want_mask=True))
+            done = torch.cuda.Event()
+            done.record()
             st = {"ids": ids, "batch": batch, "logits": pinned((len(ids), 256, 256), torch.float32),
-                  "masks": pinned((len(ids), 256, 256), torch.uint8), "ev": torch.cuda.Event()}
-            st["logits"].copy_(lg[:, 0], non_blocking=True)
-            st["masks"].copy_(mk, non_blocking=True)
-            st["ev"].record()
+                  "masks": pinned((len(ids), 256, 256), torch.uint8), "ev": torch.cuda.Event(), "keep": (lg, mk, staged)}
+            with torch.cuda.stream(down):
+                down.wait_event(done)
+                st["masks"].copy_(mk, non_blocking=True)     # masks first: the contour stage waits for them only
+                st["ev"].record()
+                st["logits"].copy_(lg[:, 0], non_blocking=True)
+                st["ev_logits"] = torch.cuda.Event()
+                st["ev_logits"].record()
             return st
 
         def classify(st):                                   # masks -> quadrangles (host) -> warp + split + classifier (device)
+            t0 = time.perf_counter()
             st["ev"].synchronize()
+            clock("wait_masks_s", t0)
             ids = st["ids"]
-            masks = st["masks"].numpy()
+            t0 = time.perf_counter()
+            found_quads = find_quadrangles(st["masks"].numpy())
+            clock("contours_s", t0)
+            t0 = time.perf_counter()
             quads = []
-            for k, q in enumerate(find_quadrangles(masks)):
+            for k, q in enumerate(found_quads):
                 if q is None and fallback_quad:
                     q = np.array([[[255, 0]], [[0, 0]], [[0, 255]], [[255, 255]]], dtype=np.int32)   # TR, TL, BL, BR
                 shape = images[ids[k]].shape
@@ -225,18 +283,24 @@ class ChessVision:
             found = [k for k in range(len(ids)) if quads[k] is not None]
             st["found"] = found
             if found:
-                inv = np.stack([np.linalg.inv(classical.get_perspective_transform(quads[k].reshape(4, 2), dest)) for k in found])
-                src = st["batch"] if len(found) == len(ids) else st["batch"][torch.as_tensor(found, device=self.device)]
-                squares_dev, boards_dev = eng.extract_squares_u8(src, inv)
-                probs_dev = eng.resnet18_forward_u8(squares_dev)
+                inv = np.linalg.inv(classical.get_perspective_transforms(np.stack([quads[k].reshape(4, 2) for k in found]), dest))
+                clock("homography_s", t0)
+                src = st["batch"] if len(found) == len(ids) else st["batch"][torch.as_tensor(found, device=dev)]
+                squares_dev, boards_dev = gpu_timed("warp_ms", lambda: eng.extract_squares_u8(src, inv))
+                probs_dev = gpu_timed("resnet_ms", lambda: eng.resnet18_forward_u8(squares_dev))
+                done = torch.cuda.Event()
+                done.record()
                 st["probs"] = pinned((len(found) * 64, constants.NUM_CLASSES), torch.float32)
-                st["squares"] = pinned((len(found) * 64, 64, 64), torch.uint8)
                 st["boards"] = pinned((len(found), h, w), torch.uint8)
-                st["probs"].copy_(probs_dev, non_blocking=True)
-                st["squares"].copy_(squares_dev, non_blocking=True)
-                st["boards"].copy_(boards_dev, non_blocking=True)
-                st["ev2"] = torch.cuda.Event()
-                st["ev2"].record()
+                st["keep2"] = (probs_dev, boards_dev, squares_dev)
+                with torch.cuda.stream(down):
+                    down.wait_event(done)
+                    st["probs"].copy_(probs_dev, non_blocking=True)
+                    st["boards"].copy_(boards_dev, non_blocking=True)
+                    st["ev2"] = torch.cuda.Event()
+                    st["ev2"].record()
+            else:
+                clock("homography_s", t0)
             st["batch"] = None
             return st
 
@@ -246,20 +310,34 @@ class ChessVision:
         boards: dict[int, NDArray[np.uint8]] = {}
         positions: dict[int, PositionResult] = {}
 
-        def finish(st):                                     # probabilities -> labels, FEN, pawn rule (host)
+        def finish(st):                                     # probabilities -> labels, FEN, pawn rule (one native call per job)
             ids = st["ids"]
+            t0 = time.perf_counter()
+            st["ev_logits"].synchronize()
             lg, mk = st["logits"].numpy(), st["masks"].numpy()
             for k, i in enumerate(ids):
                 logits_of[i], masks_of[i], quads_of[i] = lg[k], mk[k], st["quads"][k]
             if st["found"]:
                 st["ev2"].synchronize()
+                clock("wait_probs_s", t0)
+                t0 = time.perf_counter()
                 m = len(st["found"])
                 probs = st["probs"].numpy().reshape(m, 64, constants.NUM_CLASSES)
-                squares = st["squares"].numpy().reshape(m, 64, 64, 64, 1)
                 brd = st["boards"].numpy()
+                fens, origs, _, fixes = decode_positions(probs, flip)
+                fix_lists: list[list[ValidationFix]] = [[] for _ in range(m)]
+                for b, sq, old, new in fixes:
+                    fix_lists[b].append(ValidationFix(square_name=names[sq], original_piece=constants.LABEL_NAMES[old],
+                                                      corrected_piece=constants.LABEL_NAMES[new], rule_name="no_pawns_on_ends"))
                 for j, k in enumerate(st["found"]):
                     boards[ids[k]] = brd[j]
-                    positions[ids[k]] = self.process_position_probabilities(probs[j], names, squares[j])
+                    crops = self.extract_squares(brd[j]) if return_crops else None
+                    positions[ids[k]] = PositionResult(fen=fens[j], original_fen=origs[j], model_probabilities=probs[j],
+                                                       squares=crops, square_names=names, validation_fixes=fix_lists[j])
+                clock("decode_s", t0)
+            else:
+                clock("wait_probs_s", t0)
+            st["keep"] = st["keep2"] = None
 
         # software pipeline over the jobs: segment(k+1) is enqueued before the host works on job k
         seg = segment(jobs[0])
@@ -271,7 +349,9 @@ class ChessVision:
                 finish(cls)
             cls, seg = cur, nxt
         finish(cls)
+        eng.check_numerics()                               # one look at the numeric guard for the whole call
 
+        t0 = time.perf_counter()
         per_image = (time.time() - started) / n
         results = []
         for i in range(n):
@@ -279,7 +359,19 @@ class ChessVision:
                                                probabilities=logits_of[i])
             results.append(ChessVisionResult(board_extraction=extraction, position=positions.get(i),
                                              processing_time=per_image))
+        clock("assemble_s", t0)
+        if timings is not None:
+            for name, a, b in gpu_events:
+                tm[name] = tm.get(name, 0.0) + a.elapsed_time(b)
+            tm["jobs"] = len(jobs)
+            tm["total_s"] = time.time() - started
         return results
+
+    def _pipeline_streams(self):
+        """(host->device, device->host) side streams of ``process_images``, created once per instance."""
+        if self._streams is None:
+            self._streams = (torch.cuda.Stream(self.device), torch.cuda.Stream(self.device))
+        return self._streams
 
     # ---- host-side post-processing (static, usable without models) ----------------------------------
     @staticmethod

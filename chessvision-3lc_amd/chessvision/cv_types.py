@@ -40,7 +40,7 @@ class PositionResult:
     fen: str = _doc("piece placement after rule validation")
     original_fen: str = _doc("piece placement straight from the per-square argmax")
     model_probabilities: F32 = _doc("(64,13) class probabilities")
-    squares: U8 = _doc("(64,64,64,1) square crops, a8..h1 order")
+    squares: U8 | None = _doc("(64,64,64,1) square crops, a8..h1 order (None from process_images unless return_crops=True)")
     square_names: list[str] = _doc("coordinate of each row of the two arrays above")
     validation_fixes: list[ValidationFix] = _doc("rule corrections that were applied")
 

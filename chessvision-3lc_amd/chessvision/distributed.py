@@ -112,6 +112,15 @@ def max_over_ranks(value: float, device: torch.device) -> float:
     return float(t.item())
 
 
+def count_ranks(device: torch.device) -> int:
+    """All-reduce of a one per rank: the number of ranks that really took part in a collective (1 without a process group)."""
+    if not dist.is_initialized():
+        return 1
+    t = torch.ones(1, dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())
+
+
 def shutdown() -> None:
     """Tear the process group down (quietly a no-op for single-process runs)."""
     if dist.is_available() and dist.is_initialized():

@@ -80,6 +80,13 @@ SYMBOLS = [
     ("cv_find_quadrangles", _i, [_vp, _i, _i, _i, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), _i]),
     ("cv_resize_area_u8", _i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     ("cv_extract_squares_u8", _i, [_vp, _vp, _i, _i, _i, ctypes.POINTER(ctypes.c_double), _vp, _vp, _vp]),
+    ("cv_extract_squares_u8_dev", _i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    ("cv_engine_workspace_bytes", _i, [_vp, ctypes.POINTER(ctypes.c_size_t)]),
+    ("cv_engine_numeric_status", _i, [_vp, _vp]),
+    ("cv_get_activation_exponent", _i, [_vp, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(_i)]),
+    ("cv_profile_entry_bytes", _i, [_vp, _i, ctypes.POINTER(ctypes.c_double)]),
+    ("cv_decode_positions", _i, [_fp, _i, _i, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int8),
+                                 ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
 ]
 
 
@@ -172,6 +179,31 @@ def find_quadrangles(masks: np.ndarray, n_threads: int = 0) -> list:
     return [quads[i].reshape(4, 1, 2).copy() if found[i] else None for i in range(n)]
 
 
+def decode_positions(probabilities: np.ndarray, flip: bool = False):
+    """(N,64,13) float32 class probabilities -> (fens, original_fens, labels (N,64) int8, fixes) for the whole job in one
+    native call (csrc/position.cpp): per-square argmax, the pawn rule and both FEN strings, exactly as
+    ``ChessVision.process_position_probabilities`` computes them per board.  ``fixes`` is a list of
+    (board, square index, original class index, corrected class index).  Needs neither a GPU nor an engine."""
+    lib = load_library()
+    p = np.ascontiguousarray(probabilities, dtype=np.float32)
+    if p.ndim != 3 or p.shape[1:] != (64, 13):
+        raise HipBackendError("decode_positions expects (N,64,13) float32 probabilities")
+    n = p.shape[0]
+    fen = ctypes.create_string_buffer(max(1, n * 72))
+    orig = ctypes.create_string_buffer(max(1, n * 72))
+    labels = np.zeros((n, 64), dtype=np.int8)
+    fixes = np.zeros((max(1, n * 16), 4), dtype=np.int32)
+    n_fixes = ctypes.c_int32(0)
+    if n:
+        _check(lib.cv_decode_positions(p.ctypes.data_as(_fp), n, int(bool(flip)), fen, orig,
+                                       labels.ctypes.data_as(ctypes.POINTER(ctypes.c_int8)),
+                                       fixes.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), ctypes.byref(n_fixes)))
+    raw_f, raw_o = fen.raw, orig.raw
+    fens = [raw_f[i * 72:(i + 1) * 72].split(b"\0", 1)[0].decode() for i in range(n)]
+    origs = [raw_o[i * 72:(i + 1) * 72].split(b"\0", 1)[0].decode() for i in range(n)]
+    return fens, origs, labels, [tuple(int(v) for v in fixes[i]) for i in range(n_fixes.value)]
+
+
 class HipEngine:
     """One engine = one device + one arithmetic precision + packed weights + workspace."""
 
@@ -191,8 +223,8 @@ class HipEngine:
         self.precision = _PREC_NAMES[_PRECISIONS[precision]]
         self._h = ctypes.c_void_p()
         _check(self._lib.cv_engine_create(dev.index, _PRECISIONS[precision], ctypes.byref(self._h)))
-        # workspace size = images / squares per pass (0 = library default 64 / 16384, ~20 GB of activations: sized for
-        # throughput; a single-image server can set CHESSVISION_HIP_UNET_CHUNK=1 CHESSVISION_HIP_RESNET_CHUNK=64)
+        # chunk = images / squares per pass (0 = library default 64 / 16384).  The activation workspace is elastic: it is
+        # allocated for the largest batch seen so far (at most one chunk), so a single-image server stays under 1 GB.
         unet_chunk = int(unet_chunk or os.environ.get("CHESSVISION_HIP_UNET_CHUNK", "0") or 0)
         resnet_chunk = int(resnet_chunk or os.environ.get("CHESSVISION_HIP_RESNET_CHUNK", "0") or 0)
         if unet_chunk or resnet_chunk:
@@ -233,18 +265,34 @@ class HipEngine:
             raise HipBackendError(f"input shape {tuple(x.shape)} != (N,{','.join(map(str, shape_tail))})")
         return x.to(device=self.device, dtype=torch.float32).contiguous()
 
-    def unet_forward(self, x: torch.Tensor) -> torch.Tensor:
-        """(B,3,256,256) float32 in [0,1] -> (B,1,256,256) float32 logits (device tensor)."""
+    def check_numerics(self) -> None:
+        """Synchronise the current stream and raise ``HipBackendError`` naming the first layer that produced a non-finite
+        value since the last check (f16 range exceeded, NaN in the input); re-arms the guard."""
+        _check(self._lib.cv_engine_numeric_status(self._h, _stream_ptr(self.device)))
+
+    def workspace_bytes(self) -> int:
+        v = ctypes.c_size_t()
+        _check(self._lib.cv_engine_workspace_bytes(self._h, ctypes.byref(v)))
+        return int(v.value)
+
+    def unet_forward(self, x: torch.Tensor, check: bool = True) -> torch.Tensor:
+        """(B,3,256,256) float32 in [0,1] -> (B,1,256,256) float32 logits (device tensor).  ``check`` consults the
+        numeric guard (synchronises, like the ``.cpu()`` the reference does next); throughput loops pass False and call
+        ``check_numerics()`` once at the end."""
         x = self._dev_f32(x, (3, 256, 256))
         out = torch.empty((x.shape[0], 1, 256, 256), dtype=torch.float32, device=self.device)
         _check(self._lib.cv_unet_forward(self._h, _ptr(x), x.shape[0], _ptr(out), _stream_ptr(self.device)))
+        if check:
+            self.check_numerics()
         return out
 
-    def resnet18_forward(self, x: torch.Tensor) -> torch.Tensor:
+    def resnet18_forward(self, x: torch.Tensor, check: bool = True) -> torch.Tensor:
         """(N,1,64,64) float32 in [0,1] -> (N,13) float32 logits (device tensor)."""
         x = self._dev_f32(x, (1, 64, 64))
         out = torch.empty((x.shape[0], 13), dtype=torch.float32, device=self.device)
         _check(self._lib.cv_resnet18_forward(self._h, _ptr(x), x.shape[0], _ptr(out), _stream_ptr(self.device)))
+        if check:
+            self.check_numerics()
         return out
 
     def unet_forward_u8(self, x_u8: torch.Tensor, threshold: float = 0.5, want_mask: bool = True):
@@ -294,12 +342,14 @@ class HipEngine:
             raise HipBackendError("extract_squares_u8 expects (N,H,W,3) uint8")
         images = images.to(self.device).contiguous()
         n, h, w, _ = images.shape
-        inv = np.ascontiguousarray(inverse_maps, dtype=np.float64).reshape(n, 9)
+        # the matrices travel through a pinned staging tensor on the current stream; nothing here blocks the host, so the
+        # next job's UNet (already queued on this stream) does not hold the classifier of this job back
+        inv = torch.from_numpy(np.ascontiguousarray(inverse_maps, dtype=np.float64).reshape(n, 9)).pin_memory()
+        inv_dev = inv.to(self.device, non_blocking=True)
         squares = torch.empty((n * 64, 64, 64), dtype=torch.uint8, device=self.device)
         boards = torch.empty((n, 512, 512), dtype=torch.uint8, device=self.device) if want_boards else None
-        _check(self._lib.cv_extract_squares_u8(self._h, _ptr(images), n, h, w,
-                                               inv.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), _ptr(squares),
-                                               _ptr(boards) if want_boards else None, _stream_ptr(self.device)))
+        _check(self._lib.cv_extract_squares_u8_dev(self._h, _ptr(images), n, h, w, _ptr(inv_dev), _ptr(squares),
+                                                   _ptr(boards) if want_boards else None, _stream_ptr(self.device)))
         return squares, boards
 
     # -- introspection ----------------------------------------------------------------------------
@@ -310,6 +360,12 @@ class HipEngine:
         _check(self._lib.cv_get_activation(self._h, model.encode(), name.encode(), out.ctypes.data_as(_fp), out.size,
                                            dims))
         return out
+
+    def activation_exponent(self, model: str, name: str) -> int:
+        """Power-of-two exponent the tensor is stored with (stored = value * 2^-exponent), chosen by the load-time calibration."""
+        v = _i()
+        _check(self._lib.cv_get_activation_exponent(self._h, model.encode(), name.encode(), ctypes.byref(v)))
+        return int(v.value)
 
     def model_macs(self, model: str) -> int:
         v = ctypes.c_int64()
@@ -328,10 +384,12 @@ class HipEngine:
         entries = []
         idx = 0
         name = ctypes.create_string_buffer(128)
-        ms, macs, is_conv = _f(), ctypes.c_double(), _i()
+        ms, macs, is_conv, nbytes = _f(), ctypes.c_double(), _i(), ctypes.c_double()
         while self._lib.cv_profile_entry(self._h, idx, name, 128, ctypes.byref(ms), ctypes.byref(macs),
                                          ctypes.byref(is_conv)) == 0:
-            entries.append({"name": name.value.decode(), "ms": ms.value, "macs": macs.value, "conv": bool(is_conv.value)})
+            _check(self._lib.cv_profile_entry_bytes(self._h, idx, ctypes.byref(nbytes)))
+            entries.append({"name": name.value.decode(), "ms": ms.value, "macs": macs.value, "conv": bool(is_conv.value),
+                            "bytes": nbytes.value})
             idx += 1
         return conv_ms.value, launches.value, all_ms.value, entries
 

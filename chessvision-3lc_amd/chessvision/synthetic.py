@@ -127,8 +127,70 @@ def _fill(spec, seed: int, residual_gamma: float | None = None) -> "OrderedDict[
     return out
 
 
-def unet_state_dict(seed: int = 1, bilinear: bool = False):
-    return _fill(unet_spec(bilinear), seed)
+def unet_state_dict(seed: int = 1, bilinear: bool = False, segmenting: bool = False):
+    """Random-init UNet state dict.  ``segmenting=True`` rewires channel 0 of the full-resolution path so that the
+    network actually segments ``board_photo`` images (see ``make_segmenting``); every other weight stays random."""
+    sd = _fill(unet_spec(bilinear), seed)
+    return make_segmenting(sd) if segmenting else sd
+
+
+def make_segmenting(sd: "OrderedDict[str, np.ndarray]", gain: float = 24.0, offset: float = -12.0, noise: float = 0.25):
+    """Turn random UNet weights into a brightness segmenter without touching the architecture: channel 0 of
+    inc -> (skip) -> up4.conv carries the mean of the three input channels (centre taps, identity BatchNorm), and OutConv
+    reads it with weight ``gain`` and bias ``offset``; the other 63 OutConv weights are scaled by ``noise`` so the rest
+    of the (random) network still perturbs the logits by a few tenths.  Bright quadrilaterals on a dark background come
+    out as masks with real, slightly ragged contours -- what the contour / warp stages of the pipeline need to be
+    exercised end to end when no trained checkpoint exists (the reference ships none, README.md:39)."""
+    def identity_bn(prefix):
+        sd[prefix + ".weight"][0] = 1.0
+        sd[prefix + ".bias"][0] = 0.0
+        sd[prefix + ".running_mean"][0] = 0.0
+        sd[prefix + ".running_var"][0] = 1.0
+
+    w = sd["inc.double_conv.0.weight"]
+    w[0] = 0.0
+    w[0, :, 1, 1] = 1.0 / 3.0
+    identity_bn("inc.double_conv.1")
+    for conv, bn in (("inc.double_conv.3", "inc.double_conv.4"), ("up4.conv.double_conv.0", "up4.conv.double_conv.1"),
+                     ("up4.conv.double_conv.3", "up4.conv.double_conv.4")):
+        w = sd[conv + ".weight"]
+        w[0] = 0.0
+        w[0, 0, 1, 1] = 1.0                       # input channel 0 = the skip half of cat([skip, up]) for up4.conv
+        identity_bn(bn)
+    sd["outc.conv.weight"] *= np.float32(noise)
+    sd["outc.conv.weight"][0, 0, 0, 0] = gain
+    sd["outc.conv.bias"][0] = offset
+    return sd
+
+
+def board_photo(seed: int, size: int = 512) -> np.ndarray:
+    """(size,size,3) uint8 BGR "photo": a bright, slightly skewed convex quadrilateral with an 8x8 checker texture and a
+    few piece-like blobs on dark noise."""
+    rng = np.random.default_rng(seed)
+    s = size / 512.0
+    img = rng.integers(0, 36, (size, size, 3), dtype=np.uint8)
+    j = rng.uniform(-1.0, 1.0, 8)
+    corners = np.array([[95 + 30 * j[0], 75 + 25 * j[1]], [425 + 30 * j[2], 70 + 25 * j[3]],
+                        [435 + 30 * j[4], 430 + 25 * j[5]], [85 + 30 * j[6], 440 + 25 * j[7]]]) * s   # TL, TR, BR, BL
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float64)
+    inside = np.ones((size, size), bool)
+    for k in range(4):
+        (x0, y0), (x1, y1) = corners[k], corners[(k + 1) % 4]
+        inside &= (x1 - x0) * (yy - y0) - (y1 - y0) * (xx - x0) >= 0
+    # bilinear board coordinates (u, v) in [0,1]^2 from the corner frame, good enough for a texture
+    u = (xx - corners[0, 0]) / max(1.0, corners[1, 0] - corners[0, 0])
+    v = (yy - corners[0, 1]) / max(1.0, corners[3, 1] - corners[0, 1])
+    checker = ((np.floor(u * 8) + np.floor(v * 8)) % 2).astype(np.uint8)
+    base = (165 + 70 * checker).astype(np.uint8)
+    img[inside] = base[inside][:, None]
+    for _ in range(12):                                            # piece-like blobs, darker or lighter than the squares
+        cu, cv_ = rng.integers(0, 8, 2)
+        cx = corners[0, 0] + (cu + 0.5) / 8 * (corners[1, 0] - corners[0, 0])
+        cy = corners[0, 1] + (cv_ + 0.5) / 8 * (corners[3, 1] - corners[0, 1])
+        blob = ((xx - cx) ** 2 + (yy - cy) ** 2 <= (13 * s) ** 2) & inside
+        img[blob] = rng.integers(150, 256)
+    img[inside] = np.clip(img[inside].astype(np.int16) + rng.integers(-6, 7, (int(inside.sum()), 3)), 0, 255).astype(np.uint8)
+    return img
 
 
 def resnet18_state_dict(seed: int = 2):
@@ -136,7 +198,7 @@ def resnet18_state_dict(seed: int = 2):
     return _fill(resnet18_spec(), seed, residual_gamma=0.5)
 
 
-def save_checkpoints(directory, seed_unet: int = 1, seed_resnet: int = 2, bilinear: bool = False):
+def save_checkpoints(directory, seed_unet: int = 1, seed_resnet: int = 2, bilinear: bool = False, segmenting: bool = False):
     """Write random-init checkpoints in the reference's formats (train_unet.py:31-40, train_classifier.py:114-125)."""
     import torch
     from pathlib import Path
@@ -144,7 +206,7 @@ def save_checkpoints(directory, seed_unet: int = 1, seed_resnet: int = 2, biline
     d = Path(directory)
     d.mkdir(parents=True, exist_ok=True)
     meta = {"synthetic": True}
-    torch.save({"model_state_dict": {k: torch.from_numpy(v) for k, v in unet_state_dict(seed_unet, bilinear).items()},
+    torch.save({"model_state_dict": {k: torch.from_numpy(v) for k, v in unet_state_dict(seed_unet, bilinear, segmenting).items()},
                 "metadata": dict(meta, seed=seed_unet)}, d / "best_extractor.pth")
     torch.save({"model_state_dict": {k: torch.from_numpy(v) for k, v in resnet18_state_dict(seed_resnet).items()},
                 "optimizer_state_dict": {}, "metadata": dict(meta, seed=seed_resnet)}, d / "best_classifier.pth")

@@ -59,33 +59,35 @@ template <int N> __device__ __forceinline__ void wait_vm_barrier() {
 // (selects the [hi,lo] / [lo,hi] chunk order of split-f16 groups; unused otherwise).
 template <typename T, int N> struct OutVec;
 template <int N> struct OutVec<half_t, N> {
-    static __device__ __forceinline__ void store(half_t* dst, int, const float* v) {
+    static __device__ __forceinline__ void store(half_t* dst, int, const float* v, float& bad) {
 #pragma unroll
         for (int i = 0; i < N; i += 8) {
             half8 h;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) h[j] = (half_t)v[i + j];
+            for (int j = 0; j < 8; ++j) { h[j] = (half_t)v[i + j]; bad = __builtin_fmaf((float)h[j], 0.f, bad); }
             *reinterpret_cast<half8*>(dst + i) = h;
         }
     }
-    static __device__ __forceinline__ void add(const half_t* src, int, float* v) {
+    static __device__ __forceinline__ void add(const half_t* src, int, float* v, float mul) {
 #pragma unroll
         for (int i = 0; i < N; i += 8) {
             const half8 h = *reinterpret_cast<const half8*>(src + i);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[i + j] += (float)h[j];
+            for (int j = 0; j < 8; ++j) v[i + j] = __builtin_fmaf((float)h[j], mul, v[i + j]);
         }
     }
 };
 template <int N> struct OutVec<float, N> {
-    static __device__ __forceinline__ void store(float* dst, int, const float* v) {
+    static __device__ __forceinline__ void store(float* dst, int, const float* v, float& bad) {
 #pragma unroll
         for (int i = 0; i < N; i += 4) {
             f4 o = {v[i], v[i + 1], v[i + 2], v[i + 3]};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bad = __builtin_fmaf(o[j], 0.f, bad);
             *reinterpret_cast<f4*>(dst + i) = o;
         }
     }
-    static __device__ __forceinline__ void add(const float* src, int, float* v) {
+    static __device__ __forceinline__ void add(const float* src, int, float* v, float) {   // the f32 engine never rescales
 #pragma unroll
         for (int i = 0; i < N; i += 4) {
             const f4 o = *reinterpret_cast<const f4*>(src + i);
@@ -94,14 +96,19 @@ template <int N> struct OutVec<float, N> {
     }
 };
 template <int N> struct OutVec<split_t, N> {
-    static __device__ __forceinline__ void store(split_t* dst, int ch0, const float* v) {
+    static __device__ __forceinline__ void store(split_t* dst, int ch0, const float* v, float& bad) {
         char* p = reinterpret_cast<char*>(dst);
 #pragma unroll
         for (int i = 0; i < N; i += 8) {
             const int par = ((ch0 + i) >> 3) & 1;
             half8 hi, lo;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { hi[j] = (half_t)v[i + j]; lo[j] = (half_t)(v[i + j] - (float)hi[j]); }
+            for (int j = 0; j < 8; ++j) {
+                hi[j] = (half_t)v[i + j];
+                const float back = (float)hi[j];
+                bad = __builtin_fmaf(back, 0.f, bad);   // +-inf (|v| beyond the f16 range) and NaN turn `bad` into NaN
+                lo[j] = (half_t)(v[i + j] - back);
+            }
             *reinterpret_cast<half8*>(p + i * 4 + (par ? 16 : 0)) = hi;
             *reinterpret_cast<half8*>(p + i * 4 + (par ? 0 : 16)) = lo;
         }
@@ -118,17 +125,23 @@ template <int N> struct OutVec<split_t, N> {
         }
         *reinterpret_cast<half8*>(reinterpret_cast<char*>(dst) + ((want_hi ? par : par ^ 1) ? 16 : 0)) = o;
     }
-    static __device__ __forceinline__ void add(const split_t* src, int ch0, float* v) {
+    static __device__ __forceinline__ void add(const split_t* src, int ch0, float* v, float mul) {
         const char* p = reinterpret_cast<const char*>(src);
 #pragma unroll
         for (int i = 0; i < N; i += 8) {
             const half8 a = *reinterpret_cast<const half8*>(p + i * 4);
             const half8 b = *reinterpret_cast<const half8*>(p + i * 4 + 16);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[i + j] += (float)a[j] + (float)b[j];
+            for (int j = 0; j < 8; ++j) v[i + j] = __builtin_fmaf((float)a[j] + (float)b[j], mul, v[i + j]);
         }
     }
 };
 
+
+// A lane whose `bad` accumulator went NaN stored a non-finite value: record the launch's layer id (lowest id wins, so
+// the host names the FIRST layer that left the representable range).
+__device__ __forceinline__ void report_bad(const ConvParams& p, float bad) {
+    if (bad != bad && p.flag) atomicMin(p.flag, p.layer_id);
+}
 
 }  // namespace cv

@@ -390,6 +390,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 const float l = part + p.head_b[0];
                 p.head_logits[pix] = l;
                 if (p.head_mask) p.head_mask[pix] = (1.f / (1.f + __expf(-l))) > p.head_thr ? 255 : 0;
+                report_bad(p, l * 0.f);
             }
         }
 #if CV_STAMP
@@ -432,6 +433,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
     };
     float hold[UPL][UN];                                 // RG == 1 only
+    float bad = 0.f;
 #pragma unroll
     for (int g0 = 0; g0 < FP; g0 += RG) {
 #pragma unroll
@@ -468,13 +470,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 const unsigned ob = out_pixel(g0 + r, px, &live);
                 if (co < p.rows && live) {
                     if (rbase) {                         // tensors stay below 4 GiB (checked on the host): 32-bit element offsets
-                        OutVec<T, UN>::add(rbase + (ob * (unsigned)p.rCs + (unsigned)(p.rCoff + co)), p.rCoff + co, w[r]);
+                        OutVec<T, UN>::add(rbase + (ob * (unsigned)p.rCs + (unsigned)(p.rCoff + co)), p.rCoff + co, w[r], p.res_mul);
                         if (p.relu) {
 #pragma unroll
                             for (int j = 0; j < UN; ++j) w[r][j] = __builtin_fmaxf(w[r][j], 0.f);
                         }
                     }
-                    OutVec<T, UN>::store(ybase + (ob * (unsigned)p.yCs + (unsigned)(p.yCoff + co)), p.yCoff + co, w[r]);
+                    OutVec<T, UN>::store(ybase + (ob * (unsigned)p.yCs + (unsigned)(p.yCoff + co)), p.yCoff + co, w[r], bad);
                 }
             }
             if (IMG == 0 && pbase) {                     // wave-uniform: fused 2x2 max-pool of the (post-ReLU) row pair
@@ -516,7 +518,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
                         OutVec<T, UN>::store_half(pbase + (qb * (unsigned)p.pCs + (unsigned)(p.pCoff + co)), p.pCoff + co, m, (px & 1) == 0);
                 } else {
                     if (emit && (px & 1) == 0 && co < p.rows)
-                        OutVec<T, UN>::store(pbase + (qb * (unsigned)p.pCs + (unsigned)(p.pCoff + co)), p.pCoff + co, m);
+                        OutVec<T, UN>::store(pbase + (qb * (unsigned)p.pCs + (unsigned)(p.pCoff + co)), p.pCoff + co, m, bad);
                 }
             }
         }
@@ -532,6 +534,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         o[6] = st_e1 - st_t1;                            // ... until the last store is issued
     }
 #endif
+    report_bad(p, bad);
     if (!more_tiles) break;
     tile = nxt_tile;
     }

@@ -310,6 +310,7 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvParams p)
                 const float l = part + p.head_b[0];
                 p.head_logits[pix] = l;
                 if (p.head_mask) p.head_mask[pix] = (1.f / (1.f + __expf(-l))) > p.head_thr ? 255 : 0;
+                report_bad(p, l * 0.f);
             }
         }
         return;
@@ -330,6 +331,7 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvParams p)
     char* const stg = smem + wave * (16 * SROW);
     const int slab0 = ctTile * CT + wci * WCT;
     (void)co0; (void)dy; (void)dx;
+    float bad = 0.f;
 #pragma unroll
     for (int g = 0; g < FP; ++g) {
         const int pix = ptTile * PT + wpi * WPT + g * 16 + l15;
@@ -369,16 +371,17 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvParams p)
                 ob += (unsigned)((grp >> 1) * p.yWp + (grp & 1));
             }
             if (lv && row < p.rows) {
-                if (rbase) OutVec<T, UN>::add(rbase + (size_t)ob * p.rCs + p.rCoff + co, p.rCoff + co, w);
+                if (rbase) OutVec<T, UN>::add(rbase + (size_t)ob * p.rCs + p.rCoff + co, p.rCoff + co, w, p.res_mul);
                 if (p.relu) {
 #pragma unroll
                     for (int j = 0; j < UN; ++j) w[j] = w[j] > 0.f ? w[j] : 0.f;
                 }
-                OutVec<T, UN>::store(ybase + (size_t)ob * p.yCs + p.yCoff + co, p.yCoff + co, w);
+                OutVec<T, UN>::store(ybase + (size_t)ob * p.yCs + p.yCoff + co, p.yCoff + co, w, bad);
             }
         }
         asm volatile("" ::: "memory");
     }
+    report_bad(p, bad);
 }
 
 // ---- host-side launch -------------------------------------------------------------------------------

@@ -4,6 +4,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <new>
+#include <stdexcept>
 #include <thread>
 
 #include "engine.h"
@@ -11,6 +13,8 @@
 #include "pointwise.h"
 
 namespace cv {
+void decode_positions(const float* probs, int n_boards, int flip, char* fen, char* original_fen, int8_t* labels,
+                      int32_t* fixes, int32_t* n_fixes);
 bool find_quadrangle(const uint8_t* mask, int h, int w, int32_t quad[8]);
 hipError_t resize_area_u8(const uint8_t* src, int n, int h, int w, int c, uint8_t* dst, int oh, int ow, hipStream_t s);
 hipError_t extract_squares_u8(const uint8_t* images, int n, int h, int w, const double* inv, uint8_t* squares,
@@ -33,6 +37,26 @@ struct DeviceGuard {                       // every entry point runs on the engi
 
 int finish(const Status& s) { return s.code; }
 
+// No C++ exception may unwind through the C boundary (ctypes / cgo callers would abort): every entry point runs inside
+// this wrapper.  The out-of-memory message fits the small-string buffer, so reporting it allocates nothing.
+template <class F> int guarded(const char* what, F&& body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        try { set_error("out of memory"); } catch (...) {}
+        return CV_ERR_NOMEM;
+    } catch (const std::length_error&) {
+        try { set_error("out of memory"); } catch (...) {}
+        return CV_ERR_NOMEM;
+    } catch (const std::exception& ex) {
+        try { set_error(std::string(what) + ": " + ex.what()); } catch (...) {}
+        return CV_ERR_INVALID;
+    } catch (...) {
+        try { set_error("unknown C++ exception"); } catch (...) {}
+        return CV_ERR_INVALID;
+    }
+}
+
 Status to_map(const cv_param_t* params, int n, ParamMap& pm) {
     if (n < 0 || (n > 0 && !params)) return fail(CV_ERR_INVALID, "null parameter table");
     for (int i = 0; i < n; ++i) {
@@ -53,19 +77,16 @@ Status check_engine(cv_engine_t* eng) {
 
 }  // namespace
 
-extern "C" {
+// ---- implementations (may throw: std::vector / std::map / std::string allocations) ------------------------------
 
-int cv_abi_version(void) { return CV_ABI_VERSION; }
-const char* cv_last_error(void) { return get_error(); }
-
-int cv_device_count(int* count) {
+static int impl_cv_device_count(int* count) {
     if (!count) return finish(fail(CV_ERR_INVALID, "null count"));
     hipError_t e = hipGetDeviceCount(count);
     if (e != hipSuccess) { *count = 0; return finish(hip_fail(e, "hipGetDeviceCount")); }
     return CV_OK;
 }
 
-int cv_engine_create(int device, int precision, cv_engine_t** out) {
+static int impl_cv_engine_create(int device, int precision, cv_engine_t** out) {
     if (!out) return finish(fail(CV_ERR_INVALID, "null out pointer"));
     *out = nullptr;
     if (precision != CV_PREC_F32 && precision != CV_PREC_F16 && precision != CV_PREC_F16X3)
@@ -87,11 +108,13 @@ int cv_engine_create(int device, int precision, cv_engine_t** out) {
     if (!eng) return finish(fail(CV_ERR_NOMEM, "out of host memory"));
     eng->impl.device = device;
     eng->impl.dt = precision;                      // CV_PREC_* values equal cv::DType
+    Status gs = eng->impl.guard_init();
+    if (!gs.ok()) { delete eng; return finish(gs); }
     *out = eng;
     return CV_OK;
 }
 
-int cv_engine_destroy(cv_engine_t* eng) {
+static int impl_cv_engine_destroy(cv_engine_t* eng) {
     if (!eng) return CV_OK;
     {
         DeviceGuard g(eng->impl.device);
@@ -103,7 +126,7 @@ int cv_engine_destroy(cv_engine_t* eng) {
     return CV_OK;
 }
 
-int cv_engine_set_chunk(cv_engine_t* eng, int unet_images, int resnet_squares) {
+static int impl_cv_engine_set_chunk(cv_engine_t* eng, int unet_images, int resnet_squares) {
     Status s = check_engine(eng);
     if (!s.ok()) return finish(s);
     std::lock_guard<std::mutex> lk(eng->impl.mu);
@@ -114,7 +137,7 @@ int cv_engine_set_chunk(cv_engine_t* eng, int unet_images, int resnet_squares) {
     return CV_OK;
 }
 
-int cv_load_unet(cv_engine_t* eng, const cv_param_t* params, int n_params) {
+static int impl_cv_load_unet(cv_engine_t* eng, const cv_param_t* params, int n_params) {
     Status s = check_engine(eng);
     if (!s.ok()) return finish(s);
     std::lock_guard<std::mutex> lk(eng->impl.mu);
@@ -125,7 +148,7 @@ int cv_load_unet(cv_engine_t* eng, const cv_param_t* params, int n_params) {
     return finish(s);
 }
 
-int cv_load_resnet18(cv_engine_t* eng, const cv_param_t* params, int n_params) {
+static int impl_cv_load_resnet18(cv_engine_t* eng, const cv_param_t* params, int n_params) {
     Status s = check_engine(eng);
     if (!s.ok()) return finish(s);
     std::lock_guard<std::mutex> lk(eng->impl.mu);
@@ -136,7 +159,7 @@ int cv_load_resnet18(cv_engine_t* eng, const cv_param_t* params, int n_params) {
     return finish(s);
 }
 
-int cv_unet_forward(cv_engine_t* eng, const float* x, int batch, float* logits, void* stream) {
+static int impl_cv_unet_forward(cv_engine_t* eng, const float* x, int batch, float* logits, void* stream) {
     Status s = check_engine(eng);
     if (!s.ok()) return finish(s);
     std::lock_guard<std::mutex> lk(eng->impl.mu);
@@ -144,7 +167,7 @@ int cv_unet_forward(cv_engine_t* eng, const float* x, int batch, float* logits, 
     return finish(unet_forward(eng->impl, x, false, batch, logits, nullptr, 0.5f, (hipStream_t)stream));
 }
 
-int cv_unet_forward_u8(cv_engine_t* eng, const uint8_t* x_u8, int batch, float* logits, uint8_t* mask,
+static int impl_cv_unet_forward_u8(cv_engine_t* eng, const uint8_t* x_u8, int batch, float* logits, uint8_t* mask,
                        float threshold, void* stream) {
     Status s = check_engine(eng);
     if (!s.ok()) return finish(s);
@@ -154,7 +177,7 @@ int cv_unet_forward_u8(cv_engine_t* eng, const uint8_t* x_u8, int batch, float* 
     return finish(unet_forward(eng->impl, x_u8, true, batch, logits, mask, threshold, (hipStream_t)stream));
 }
 
-int cv_resnet18_forward(cv_engine_t* eng, const float* x, int n, float* logits, void* stream) {
+static int impl_cv_resnet18_forward(cv_engine_t* eng, const float* x, int n, float* logits, void* stream) {
     Status s = check_engine(eng);
     if (!s.ok()) return finish(s);
     std::lock_guard<std::mutex> lk(eng->impl.mu);
@@ -162,7 +185,7 @@ int cv_resnet18_forward(cv_engine_t* eng, const float* x, int n, float* logits, 
     return finish(resnet_forward(eng->impl, x, false, n, logits, false, (hipStream_t)stream));
 }
 
-int cv_resnet18_forward_u8(cv_engine_t* eng, const uint8_t* squares_u8, int n, float* probs, void* stream) {
+static int impl_cv_resnet18_forward_u8(cv_engine_t* eng, const uint8_t* squares_u8, int n, float* probs, void* stream) {
     Status s = check_engine(eng);
     if (!s.ok()) return finish(s);
     std::lock_guard<std::mutex> lk(eng->impl.mu);
@@ -170,7 +193,7 @@ int cv_resnet18_forward_u8(cv_engine_t* eng, const uint8_t* squares_u8, int n, f
     return finish(resnet_forward(eng->impl, squares_u8, true, n, probs, true, (hipStream_t)stream));
 }
 
-int cv_softmax13(cv_engine_t* eng, const float* logits, int n, float* probs, void* stream) {
+static int impl_cv_softmax13(cv_engine_t* eng, const float* logits, int n, float* probs, void* stream) {
     Status s = check_engine(eng);
     if (!s.ok()) return finish(s);
     if (n < 0 || (n > 0 && (!logits || !probs))) return finish(fail(CV_ERR_INVALID, "cv_softmax13: null tensor"));
@@ -181,7 +204,7 @@ int cv_softmax13(cv_engine_t* eng, const float* logits, int n, float* probs, voi
     return CV_OK;
 }
 
-int cv_get_activation(cv_engine_t* eng, const char* model, const char* name, float* out_host, size_t out_capacity,
+static int impl_cv_get_activation(cv_engine_t* eng, const char* model, const char* name, float* out_host, size_t out_capacity,
                       int64_t dims[4]) {
     Status s = check_engine(eng);
     if (!s.ok()) return finish(s);
@@ -207,7 +230,7 @@ int cv_get_activation(cv_engine_t* eng, const char* model, const char* name, flo
     return CV_OK;
 }
 
-int cv_model_macs(cv_engine_t* eng, const char* model, int64_t* macs) {
+static int impl_cv_model_macs(cv_engine_t* eng, const char* model, int64_t* macs) {
     Status s = check_engine(eng);
     if (!s.ok()) return finish(s);
     if (!model || !macs) return finish(fail(CV_ERR_INVALID, "null argument"));
@@ -218,7 +241,7 @@ int cv_model_macs(cv_engine_t* eng, const char* model, int64_t* macs) {
     return CV_OK;
 }
 
-int cv_profile_convs(cv_engine_t* eng, const char* model, const void* x, int batch, void* out, int iters,
+static int impl_cv_profile_convs(cv_engine_t* eng, const char* model, const void* x, int batch, void* out, int iters,
                      void* stream, float* conv_ms_total, int* conv_launches, float* all_ms_total) {
     Status s = check_engine(eng);
     if (!s.ok()) return finish(s);
@@ -245,7 +268,7 @@ int cv_profile_convs(cv_engine_t* eng, const char* model, const void* x, int bat
     return CV_OK;
 }
 
-int cv_profile_entry(cv_engine_t* eng, int index, char* name, int name_cap, float* ms, double* macs, int* is_conv) {
+static int impl_cv_profile_entry(cv_engine_t* eng, int index, char* name, int name_cap, float* ms, double* macs, int* is_conv) {
     Status s = check_engine(eng);
     if (!s.ok()) return finish(s);
     std::lock_guard<std::mutex> lk(eng->impl.mu);
@@ -261,7 +284,7 @@ int cv_profile_entry(cv_engine_t* eng, int index, char* name, int name_cap, floa
 // ---- single-layer entry points (parity tests) -------------------------------------------------------
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-int cv_op_conv2d(cv_engine_t* eng, const float* x, int n, int cin, int h, int w_, const float* w_host, int cout,
+static int impl_cv_op_conv2d(cv_engine_t* eng, const float* x, int n, int cin, int h, int w_, const float* w_host, int cout,
                  int k, int stride, const float* scale_host, const float* shift_host, const float* residual,
                  int relu, float* y, void* stream) {
     Status s = check_engine(eng);
@@ -282,11 +305,11 @@ int cv_op_conv2d(cv_engine_t* eng, const float* x, int n, int cin, int h, int w_
     if (!s.ok()) return finish(s);
     Activation ax, ay, ar;
     if ((s = ax.create(n, h, w_, cinPad, e.dt)).ok() && (s = ay.create(n, ho, wo, cout, e.dt)).ok()) {
-        hipError_t err = pack_nchw_f32(e.dt, x, cin, ax.ref(n), st);
+        hipError_t err = pack_nchw_f32(e.dt, x, cin, ax.ref(n), e.guard_ptr(), st);
         TensorRef rr;
         if (err == hipSuccess && residual) {
             s = ar.create(n, ho, wo, cout, e.dt);
-            if (s.ok()) { err = pack_nchw_f32(e.dt, residual, cout, ar.ref(n), st); rr = ar.ref(n); }
+            if (s.ok()) { err = pack_nchw_f32(e.dt, residual, cout, ar.ref(n), e.guard_ptr(), st); rr = ar.ref(n); }
         }
         if (s.ok() && err == hipSuccess) s = e.run_conv(L, ax.ref(n), ay.ref(n), residual ? &rr : nullptr, relu != 0, st);
         if (s.ok() && err == hipSuccess) err = unpack_nchw_f32(e.dt, ay.ref(n), y, st);
@@ -296,7 +319,7 @@ int cv_op_conv2d(cv_engine_t* eng, const float* x, int n, int cin, int h, int w_
     return finish(s);
 }
 
-int cv_op_conv_transpose2x2(cv_engine_t* eng, const float* x, int n, int cin, int h, int w_, const float* w_host,
+static int impl_cv_op_conv_transpose2x2(cv_engine_t* eng, const float* x, int n, int cin, int h, int w_, const float* w_host,
                             int cout, const float* bias_host, float* y, void* stream) {
     Status s = check_engine(eng);
     if (!s.ok()) return finish(s);
@@ -310,7 +333,7 @@ int cv_op_conv_transpose2x2(cv_engine_t* eng, const float* x, int n, int cin, in
     if (!s.ok()) return finish(s);
     Activation ax, ay;
     if ((s = ax.create(n, h, w_, cin, e.dt)).ok() && (s = ay.create(n, 2 * h, 2 * w_, cout, e.dt)).ok()) {
-        hipError_t err = pack_nchw_f32(e.dt, x, cin, ax.ref(n), st);
+        hipError_t err = pack_nchw_f32(e.dt, x, cin, ax.ref(n), e.guard_ptr(), st);
         if (err == hipSuccess) s = e.run_conv(L, ax.ref(n), ay.ref(n), nullptr, false, st);
         if (s.ok() && err == hipSuccess) err = unpack_nchw_f32(e.dt, ay.ref(n), y, st);
         if (s.ok() && err == hipSuccess) err = hipStreamSynchronize(st);
@@ -320,6 +343,9 @@ int cv_op_conv_transpose2x2(cv_engine_t* eng, const float* x, int n, int cin, in
 }
 
 typedef hipError_t (*pool_fn)(int, const TensorRef&, const TensorRef&, hipStream_t);
+static hipError_t upsample_plain(int dt, const TensorRef& a, const TensorRef& b, hipStream_t s) {
+    return upsample_bilinear2x(dt, a, b, nullptr, 0u, s);
+}
 static int pool_like(cv_engine_t* eng, const float* x, int n, int c, int h, int w_, int ho, int wo, float* y,
                      void* stream, pool_fn fn, const char* what) {
     Status s = check_engine(eng);
@@ -332,7 +358,7 @@ static int pool_like(cv_engine_t* eng, const float* x, int n, int c, int h, int 
     const int cp = round_up(c, 8);
     Activation ax, ay;
     if ((s = ax.create(n, h, w_, cp, e.dt)).ok() && (s = ay.create(n, ho, wo, cp, e.dt)).ok()) {
-        hipError_t err = pack_nchw_f32(e.dt, x, c, ax.ref(n), st);
+        hipError_t err = pack_nchw_f32(e.dt, x, c, ax.ref(n), e.guard_ptr(), st);
         if (err == hipSuccess) err = fn(e.dt, ax.ref(n), ay.ref(n), st);
         if (err == hipSuccess) err = unpack_nchw_f32(e.dt, ay.ref(n, 0, c), y, st);
         if (err == hipSuccess) err = hipStreamSynchronize(st);
@@ -341,24 +367,24 @@ static int pool_like(cv_engine_t* eng, const float* x, int n, int c, int h, int 
     return finish(s);
 }
 
-int cv_op_maxpool2x2(cv_engine_t* eng, const float* x, int n, int c, int h, int w_, float* y, void* stream) {
+static int impl_cv_op_maxpool2x2(cv_engine_t* eng, const float* x, int n, int c, int h, int w_, float* y, void* stream) {
     return pool_like(eng, x, n, c, h, w_, h / 2, w_ / 2, y, stream, maxpool2x2, "cv_op_maxpool2x2");
 }
-int cv_op_maxpool3x3s2(cv_engine_t* eng, const float* x, int n, int c, int h, int w_, float* y, void* stream) {
+static int impl_cv_op_maxpool3x3s2(cv_engine_t* eng, const float* x, int n, int c, int h, int w_, float* y, void* stream) {
     return pool_like(eng, x, n, c, h, w_, (h + 2 - 3) / 2 + 1, (w_ + 2 - 3) / 2 + 1, y, stream, maxpool3x3s2, "cv_op_maxpool3x3s2");
 }
-int cv_op_upsample_bilinear2x(cv_engine_t* eng, const float* x, int n, int c, int h, int w_, float* y, void* stream) {
-    return pool_like(eng, x, n, c, h, w_, 2 * h, 2 * w_, y, stream, upsample_bilinear2x, "cv_op_upsample_bilinear2x");
+static int impl_cv_op_upsample_bilinear2x(cv_engine_t* eng, const float* x, int n, int c, int h, int w_, float* y, void* stream) {
+    return pool_like(eng, x, n, c, h, w_, 2 * h, 2 * w_, y, stream, upsample_plain, "cv_op_upsample_bilinear2x");
 }
 
 // ---- classical stages either side of the CNNs -----------------------------------------
-int cv_find_quadrangle(const uint8_t* mask, int h, int w, int32_t quad[8], int* found) {
+static int impl_cv_find_quadrangle(const uint8_t* mask, int h, int w, int32_t quad[8], int* found) {
     if (!mask || !quad || !found || h <= 0 || w <= 0) return finish(fail(CV_ERR_INVALID, "cv_find_quadrangle: bad argument"));
     *found = find_quadrangle(mask, h, w, quad) ? 1 : 0;
     return CV_OK;
 }
 
-int cv_find_quadrangles(const uint8_t* masks, int n, int h, int w, int32_t* quads, int32_t* found, int n_threads) {
+static int impl_cv_find_quadrangles(const uint8_t* masks, int n, int h, int w, int32_t* quads, int32_t* found, int n_threads) {
     if (!masks || !quads || !found || n < 0 || h <= 0 || w <= 0) return finish(fail(CV_ERR_INVALID, "cv_find_quadrangles: bad argument"));
     int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
     nt = std::max(1, std::min(nt, std::min(n, 32)));
@@ -373,7 +399,7 @@ int cv_find_quadrangles(const uint8_t* masks, int n, int h, int w, int32_t* quad
     return CV_OK;
 }
 
-int cv_resize_area_u8(cv_engine_t* eng, const uint8_t* src, int n, int h, int w_, int channels, uint8_t* dst, int out_h,
+static int impl_cv_resize_area_u8(cv_engine_t* eng, const uint8_t* src, int n, int h, int w_, int channels, uint8_t* dst, int out_h,
                       int out_w, void* stream) {
     Status s = check_engine(eng);
     if (!s.ok()) return finish(s);
@@ -385,7 +411,7 @@ int cv_resize_area_u8(cv_engine_t* eng, const uint8_t* src, int n, int h, int w_
     return CV_OK;
 }
 
-int cv_extract_squares_u8(cv_engine_t* eng, const uint8_t* images, int n, int h, int w_, const double* inv_host,
+static int impl_cv_extract_squares_u8(cv_engine_t* eng, const uint8_t* images, int n, int h, int w_, const double* inv_host,
                           uint8_t* squares, uint8_t* boards, void* stream) {
     Status s = check_engine(eng);
     if (!s.ok()) return finish(s);
@@ -404,7 +430,67 @@ int cv_extract_squares_u8(cv_engine_t* eng, const uint8_t* images, int n, int h,
     return CV_OK;
 }
 
-int cv_selftest_mfma(cv_engine_t* eng, float* max_err_f16, float* max_err_f32) {
+static int impl_cv_profile_entry_bytes(cv_engine_t* eng, int index, double* bytes) {
+    Status s = check_engine(eng);
+    if (!s.ok()) return finish(s);
+    std::lock_guard<std::mutex> lk(eng->impl.mu);
+    if (!bytes || index < 0 || index >= (int)eng->impl.prof.size()) return finish(fail(CV_ERR_INVALID, "profile index out of range"));
+    *bytes = eng->impl.prof[index].bytes;
+    return CV_OK;
+}
+
+static int impl_cv_engine_numeric_status(cv_engine_t* eng, void* stream) {
+    Status s = check_engine(eng);
+    if (!s.ok()) return finish(s);
+    std::lock_guard<std::mutex> lk(eng->impl.mu);
+    DeviceGuard g(eng->impl.device);
+    return finish(eng->impl.guard_check((hipStream_t)stream));
+}
+
+static int impl_cv_engine_workspace_bytes(cv_engine_t* eng, size_t* bytes) {
+    Status s = check_engine(eng);
+    if (!s.ok()) return finish(s);
+    if (!bytes) return finish(fail(CV_ERR_INVALID, "null argument"));
+    std::lock_guard<std::mutex> lk(eng->impl.mu);
+    *bytes = eng->impl.workspace_bytes();
+    return CV_OK;
+}
+
+static int impl_cv_get_activation_exponent(cv_engine_t* eng, const char* model, const char* name, int* exponent) {
+    Status s = check_engine(eng);
+    if (!s.ok()) return finish(s);
+    if (!model || !name || !exponent) return finish(fail(CV_ERR_INVALID, "null argument"));
+    std::lock_guard<std::mutex> lk(eng->impl.mu);
+    TensorRef t;
+    if (std::strcmp(model, "unet") == 0) s = unet_activation(eng->impl, name, &t);
+    else if (std::strcmp(model, "resnet18") == 0) s = resnet_activation(eng->impl, name, &t);
+    else s = fail(CV_ERR_INVALID, "model must be 'unet' or 'resnet18'");
+    if (!s.ok()) return finish(s);
+    *exponent = t.exp;
+    return CV_OK;
+}
+
+static int impl_cv_decode_positions(const float* probs, int n_boards, int flip, char* fen, char* original_fen, int8_t* labels,
+                                    int32_t* fixes, int32_t* n_fixes) {
+    if (n_boards < 0 || (n_boards > 0 && (!probs || !fen || !original_fen || !labels || !fixes || !n_fixes)))
+        return finish(fail(CV_ERR_INVALID, "cv_decode_positions: bad argument"));
+    decode_positions(probs, n_boards, flip, fen, original_fen, labels, fixes, n_fixes);
+    return CV_OK;
+}
+
+static int impl_cv_extract_squares_u8_dev(cv_engine_t* eng, const uint8_t* images, int n, int h, int w_, const double* inv_dev,
+                                          uint8_t* squares, uint8_t* boards, void* stream) {
+    Status s = check_engine(eng);
+    if (!s.ok()) return finish(s);
+    if (!images || !inv_dev || !squares || n <= 0 || h <= 0 || w_ <= 0)
+        return finish(fail(CV_ERR_INVALID, "cv_extract_squares_u8_dev: bad argument"));
+    DeviceGuard g(eng->impl.device);
+    hipError_t err = extract_squares_u8(images, n, h, w_, inv_dev, squares, boards, (hipStream_t)stream);
+    if (err != hipSuccess) return finish(hip_fail(err, "extract_squares_u8"));
+    return CV_OK;
+}
+
+static int impl_cv_selftest_mfma(cv_engine_t* eng, float* max_err_f16, float* max_err_f32) {
     Status s = check_engine(eng);
     if (!s.ok()) return finish(s);
     DeviceGuard g(eng->impl.device);
@@ -438,6 +524,151 @@ int cv_selftest_mfma(cv_engine_t* eng, float* max_err_f16, float* max_err_f32) {
     if (max_err_f16) *max_err_f16 = err16;
     if (max_err_f32) *max_err_f32 = err32;
     return CV_OK;
+}
+
+
+// ---- the exported C surface: every entry point is exception-tight -----------------------------------------------
+extern "C" {
+
+int cv_abi_version(void) { return CV_ABI_VERSION; }
+const char* cv_last_error(void) { return get_error(); }
+
+int cv_device_count(int* count) {
+    return guarded("cv_device_count", [&]() -> int { return impl_cv_device_count(count); });
+}
+
+int cv_engine_create(int device, int precision, cv_engine_t** out) {
+    return guarded("cv_engine_create", [&]() -> int { return impl_cv_engine_create(device, precision, out); });
+}
+
+int cv_engine_destroy(cv_engine_t* eng) {
+    return guarded("cv_engine_destroy", [&]() -> int { return impl_cv_engine_destroy(eng); });
+}
+
+int cv_engine_set_chunk(cv_engine_t* eng, int unet_images, int resnet_squares) {
+    return guarded("cv_engine_set_chunk", [&]() -> int { return impl_cv_engine_set_chunk(eng, unet_images, resnet_squares); });
+}
+
+int cv_load_unet(cv_engine_t* eng, const cv_param_t* params, int n_params) {
+    return guarded("cv_load_unet", [&]() -> int { return impl_cv_load_unet(eng, params, n_params); });
+}
+
+int cv_load_resnet18(cv_engine_t* eng, const cv_param_t* params, int n_params) {
+    return guarded("cv_load_resnet18", [&]() -> int { return impl_cv_load_resnet18(eng, params, n_params); });
+}
+
+int cv_unet_forward(cv_engine_t* eng, const float* x, int batch, float* logits, void* stream) {
+    return guarded("cv_unet_forward", [&]() -> int { return impl_cv_unet_forward(eng, x, batch, logits, stream); });
+}
+
+int cv_unet_forward_u8(cv_engine_t* eng, const uint8_t* x_u8, int batch, float* logits, uint8_t* mask,
+                       float threshold, void* stream) {
+    return guarded("cv_unet_forward_u8", [&]() -> int { return impl_cv_unet_forward_u8(eng, x_u8, batch, logits, mask, threshold, stream); });
+}
+
+int cv_resnet18_forward(cv_engine_t* eng, const float* x, int n, float* logits, void* stream) {
+    return guarded("cv_resnet18_forward", [&]() -> int { return impl_cv_resnet18_forward(eng, x, n, logits, stream); });
+}
+
+int cv_resnet18_forward_u8(cv_engine_t* eng, const uint8_t* squares_u8, int n, float* probs, void* stream) {
+    return guarded("cv_resnet18_forward_u8", [&]() -> int { return impl_cv_resnet18_forward_u8(eng, squares_u8, n, probs, stream); });
+}
+
+int cv_softmax13(cv_engine_t* eng, const float* logits, int n, float* probs, void* stream) {
+    return guarded("cv_softmax13", [&]() -> int { return impl_cv_softmax13(eng, logits, n, probs, stream); });
+}
+
+int cv_get_activation(cv_engine_t* eng, const char* model, const char* name, float* out_host, size_t out_capacity,
+                      int64_t dims[4]) {
+    return guarded("cv_get_activation", [&]() -> int { return impl_cv_get_activation(eng, model, name, out_host, out_capacity, dims); });
+}
+
+int cv_model_macs(cv_engine_t* eng, const char* model, int64_t* macs) {
+    return guarded("cv_model_macs", [&]() -> int { return impl_cv_model_macs(eng, model, macs); });
+}
+
+int cv_profile_convs(cv_engine_t* eng, const char* model, const void* x, int batch, void* out, int iters,
+                     void* stream, float* conv_ms_total, int* conv_launches, float* all_ms_total) {
+    return guarded("cv_profile_convs", [&]() -> int { return impl_cv_profile_convs(eng, model, x, batch, out, iters, stream, conv_ms_total, conv_launches, all_ms_total); });
+}
+
+int cv_profile_entry(cv_engine_t* eng, int index, char* name, int name_cap, float* ms, double* macs, int* is_conv) {
+    return guarded("cv_profile_entry", [&]() -> int { return impl_cv_profile_entry(eng, index, name, name_cap, ms, macs, is_conv); });
+}
+
+int cv_op_conv2d(cv_engine_t* eng, const float* x, int n, int cin, int h, int w_, const float* w_host, int cout,
+                 int k, int stride, const float* scale_host, const float* shift_host, const float* residual,
+                 int relu, float* y, void* stream) {
+    return guarded("cv_op_conv2d", [&]() -> int { return impl_cv_op_conv2d(eng, x, n, cin, h, w_, w_host, cout, k, stride, scale_host, shift_host, residual, relu, y, stream); });
+}
+
+int cv_op_conv_transpose2x2(cv_engine_t* eng, const float* x, int n, int cin, int h, int w_, const float* w_host,
+                            int cout, const float* bias_host, float* y, void* stream) {
+    return guarded("cv_op_conv_transpose2x2", [&]() -> int { return impl_cv_op_conv_transpose2x2(eng, x, n, cin, h, w_, w_host, cout, bias_host, y, stream); });
+}
+
+int cv_op_maxpool2x2(cv_engine_t* eng, const float* x, int n, int c, int h, int w_, float* y, void* stream) {
+    return guarded("cv_op_maxpool2x2", [&]() -> int { return impl_cv_op_maxpool2x2(eng, x, n, c, h, w_, y, stream); });
+}
+
+int cv_op_maxpool3x3s2(cv_engine_t* eng, const float* x, int n, int c, int h, int w_, float* y, void* stream) {
+    return guarded("cv_op_maxpool3x3s2", [&]() -> int { return impl_cv_op_maxpool3x3s2(eng, x, n, c, h, w_, y, stream); });
+}
+
+int cv_op_upsample_bilinear2x(cv_engine_t* eng, const float* x, int n, int c, int h, int w_, float* y, void* stream) {
+    return guarded("cv_op_upsample_bilinear2x", [&]() -> int { return impl_cv_op_upsample_bilinear2x(eng, x, n, c, h, w_, y, stream); });
+}
+
+int cv_find_quadrangle(const uint8_t* mask, int h, int w, int32_t quad[8], int* found) {
+    return guarded("cv_find_quadrangle", [&]() -> int { return impl_cv_find_quadrangle(mask, h, w, quad, found); });
+}
+
+int cv_find_quadrangles(const uint8_t* masks, int n, int h, int w, int32_t* quads, int32_t* found, int n_threads) {
+    return guarded("cv_find_quadrangles", [&]() -> int { return impl_cv_find_quadrangles(masks, n, h, w, quads, found, n_threads); });
+}
+
+int cv_resize_area_u8(cv_engine_t* eng, const uint8_t* src, int n, int h, int w_, int channels, uint8_t* dst, int out_h,
+                      int out_w, void* stream) {
+    return guarded("cv_resize_area_u8", [&]() -> int { return impl_cv_resize_area_u8(eng, src, n, h, w_, channels, dst, out_h, out_w, stream); });
+}
+
+int cv_extract_squares_u8(cv_engine_t* eng, const uint8_t* images, int n, int h, int w_, const double* inv_host,
+                          uint8_t* squares, uint8_t* boards, void* stream) {
+    return guarded("cv_extract_squares_u8", [&]() -> int { return impl_cv_extract_squares_u8(eng, images, n, h, w_, inv_host, squares, boards, stream); });
+}
+
+int cv_selftest_mfma(cv_engine_t* eng, float* max_err_f16, float* max_err_f32) {
+    return guarded("cv_selftest_mfma", [&]() -> int { return impl_cv_selftest_mfma(eng, max_err_f16, max_err_f32); });
+}
+
+int cv_profile_entry_bytes(cv_engine_t* eng, int index, double* bytes) {
+    return guarded("cv_profile_entry_bytes", [&]() -> int { return impl_cv_profile_entry_bytes(eng, index, bytes); });
+}
+
+int cv_engine_numeric_status(cv_engine_t* eng, void* stream) {
+    return guarded("cv_engine_numeric_status", [&]() -> int { return impl_cv_engine_numeric_status(eng, stream); });
+}
+
+int cv_engine_workspace_bytes(cv_engine_t* eng, size_t* bytes) {
+    return guarded("cv_engine_workspace_bytes", [&]() -> int { return impl_cv_engine_workspace_bytes(eng, bytes); });
+}
+
+int cv_get_activation_exponent(cv_engine_t* eng, const char* model, const char* name, int* exponent) {
+    return guarded("cv_get_activation_exponent", [&]() -> int { return impl_cv_get_activation_exponent(eng, model, name, exponent); });
+}
+
+int cv_decode_positions(const float* probs, int n_boards, int flip, char* fen, char* original_fen, int8_t* labels,
+                        int32_t* fixes, int32_t* n_fixes) {
+    return guarded("cv_decode_positions", [&]() -> int {
+        return impl_cv_decode_positions(probs, n_boards, flip, fen, original_fen, labels, fixes, n_fixes);
+    });
+}
+
+int cv_extract_squares_u8_dev(cv_engine_t* eng, const uint8_t* images, int n, int h, int w_, const double* inv_dev,
+                              uint8_t* squares, uint8_t* boards, void* stream) {
+    return guarded("cv_extract_squares_u8_dev", [&]() -> int {
+        return impl_cv_extract_squares_u8_dev(eng, images, n, h, w_, inv_dev, squares, boards, stream);
+    });
 }
 
 }  // extern "C"

@@ -37,6 +37,10 @@ struct TensorRef {            // a channel slice of a PHWC tensor
     int Cs;                   // channel stride of the underlying buffer (elements)
     int Coff;                 // first channel of the slice
     int C;                    // channels in the slice
+    // host-side bookkeeping (no kernel reads these): the tensor holds real_value * 2^-exp (power-of-two range scaling of
+    // the f16 / split-f16 engines, engine.h: Activation); owner = the Activation the slice belongs to
+    int exp;
+    void* owner;
 };
 
 // Implicit-GEMM convolution:  D[ch][pix] = sum_k Wt[ch][k] * X[pix][k]
@@ -46,9 +50,10 @@ struct ConvParams {
     const char* w;            // packed weights: [ctTile][stage][CT rows][8 x 16 B, XOR-swizzled]
     const int* koff;          // [nStages*8] byte offset of each 16-B K chunk relative to a pixel's base
     const int* kbase;         // [nStages] or null: per-stage base when koff[s*8+c] == kbase[s] + 16*c for every stage
-    const float* scale;       // [rows] epilogue scale  (BN gamma / sqrt(var + eps), or 1)
-    const float* shift;       // [rows] epilogue shift  (BN beta - mean*scale, or conv bias)
+    const float* scale;       // [rows] epilogue scale  (BN gamma / sqrt(var + eps), or 1) x the power-of-two range factors
+    const float* shift;       // [rows] epilogue shift  (BN beta - mean*scale, or conv bias) x 2^-out_exp
     const char* res;          // optional residual PHWC base (same pixel grid as the output), or null
+    float res_mul;            // residual multiplier 2^(res_exp - out_exp): brings the shortcut tensor to the output's scale
     char* y;                  // output PHWC base
     int M;                    // output pixels = N*Ho*Wo
     int Ho, Wo;               // output pixel grid per image
@@ -77,6 +82,10 @@ struct ConvParams {
     char* pool_y;             // null = no pooled output
     int pHp, pWp;             // its padded dims (Ho/2 + 2, Wo/2 + 2)
     int pCs, pCoff;           // its channel stride / first channel
+    // numeric guard: a lane that stores a non-finite value (f16 range exceeded, NaN input) records the launch's layer id
+    // with atomicMin; the host turns it into CV_ERR_NUMERIC naming the layer (cv_engine_numeric_status).  Null = off.
+    unsigned* flag;
+    unsigned layer_id;
     unsigned long long* stamp;   // diagnostic builds (-DCV_STAMP=1) only: per-workgroup cycle stamps, else null
 };
 

@@ -42,8 +42,8 @@ Status DeviceBuffer::upload(const void* host, size_t n) {
     return Status();
 }
 
-Status Activation::create(int cap_, int h, int w, int c, int dt_) {
-    cap = cap_; H = h; W = w; C = c; dt = dt_;
+Status Activation::reserve(int cap_) {
+    cap = cap_;
     const size_t total = bytes_per_image() * (size_t)cap;
     if (total >= ((size_t)1 << 32))
         return fail(1, "activation buffer >= 4 GiB: lower the chunk size (32-bit DMA offsets)");
@@ -93,12 +93,39 @@ static void pack_rows(int dt, std::vector<char>& out, int CT, int nCt, int nStag
             }
 }
 
-static Status finish_layer(ConvLayer& L, const std::vector<float>& Wk, int K, const std::vector<float>& scale,
+static Status finish_layer(ConvLayer& L, std::vector<float>& Wk, int K, const std::vector<float>& scale,
                            const std::vector<float>& shift) {
     const int CT = L.ct = choose_ct(L.rows, L.pixels_hint, L.halo_ok);
     L.nStages = (chunks_for(L.dt, K) + 7) / 8;
     L.nCt = (L.rows + CT - 1) / CT;
     L.rowsPad = L.nCt * CT;
+    // Loud failure instead of silent NaNs downstream: a checkpoint with non-finite weights or a BatchNorm whose
+    // running_var + eps is not positive cannot be evaluated in any precision.
+    for (size_t i = 0; i < Wk.size(); ++i)
+        if (!std::isfinite(Wk[i])) return fail(1, L.name + ": non-finite weight in the state dict");
+    for (int r = 0; r < L.rows; ++r)
+        if (!std::isfinite(scale[r]) || !std::isfinite(shift[r]))
+            return fail(1, L.name + ": non-finite BatchNorm scale/shift for output channel " + std::to_string(r) +
+                           " (running_var + eps <= 0, or non-finite statistics)");
+    // Row normalisation (f16 / split-f16): row r is stored as w * 2^-e_r with max |w| in [0.5, 1) and 2^e_r goes into the
+    // f32 epilogue scale -- exact, and it keeps the lo halves of small trained weights out of the f16 subnormals
+    // (|w| ~ 1e-2 would otherwise keep 17 of its 22 bits, |w| ~ 1e-3 only 14).
+    L.h_scale.assign(L.rowsPad, 0.f);
+    L.h_shift.assign(L.rowsPad, 0.f);
+    for (int r = 0; r < L.rows; ++r) {
+        int e = 0;
+        if (L.dt != kF32) {
+            float m = 0.f;
+            for (int k = 0; k < K; ++k) m = std::max(m, std::fabs(Wk[(size_t)r * K + k]));
+            if (m > 0.f) {
+                (void)std::frexp(m, &e);
+                for (int k = 0; k < K; ++k) Wk[(size_t)r * K + k] = std::ldexp(Wk[(size_t)r * K + k], -e);
+            }
+        }
+        L.h_scale[r] = std::ldexp(scale[r], e);
+        L.h_shift[r] = shift[r];
+        if (!std::isfinite(L.h_scale[r])) return fail(1, L.name + ": weight magnitude x BatchNorm scale leaves the f32 range");
+    }
     std::vector<char> packed;
     pack_rows(L.dt, packed, CT, L.nCt, L.nStages, L.rows, K, Wk);
     CV_TRY(L.w.upload(packed.data(), packed.size()));
@@ -108,12 +135,26 @@ static Status finish_layer(ConvLayer& L, const std::vector<float>& Wk, int K, co
         pack_rows(L.dt, packed, 128, L.rows / 128, L.nStages, L.rows, K, Wk);
         CV_TRY(L.w_small.upload(packed.data(), packed.size()));
     }
-    std::vector<float> sc(L.rowsPad, 0.f), sh(L.rowsPad, 0.f);
-    std::memcpy(sc.data(), scale.data(), sizeof(float) * L.rows);
-    std::memcpy(sh.data(), shift.data(), sizeof(float) * L.rows);
-    CV_TRY(L.scale.upload(sc.data(), sc.size() * sizeof(float)));
-    CV_TRY(L.shift.upload(sh.data(), sh.size() * sizeof(float)));
+    L.in_exp = L.out_exp = 0;
+    CV_TRY(L.scale.upload(L.h_scale.data(), L.h_scale.size() * sizeof(float)));
+    CV_TRY(L.shift.upload(L.h_shift.data(), L.h_shift.size() * sizeof(float)));
     L.koff.clear();
+    return Status();
+}
+
+// Re-fold the tensor exponents into the device copies of the epilogue constants (only when they change: calibration).
+Status ConvLayer::set_exps(int in_exp_, int out_exp_, hipStream_t s) {
+    if (in_exp_ == in_exp && out_exp_ == out_exp) return Status();
+    CV_HIP(hipStreamSynchronize(s));                     // launches that still read the old constants
+    std::vector<float> sc(h_scale.size()), sh(h_shift.size());
+    for (size_t i = 0; i < sc.size(); ++i) {
+        sc[i] = std::ldexp(h_scale[i], in_exp_ - out_exp_);
+        sh[i] = std::ldexp(h_shift[i], -out_exp_);
+        if (!std::isfinite(sc[i]) || !std::isfinite(sh[i])) return fail(1, name + ": range factors leave the f32 range");
+    }
+    CV_HIP(hipMemcpy(scale.ptr, sc.data(), sc.size() * sizeof(float), hipMemcpyHostToDevice));
+    CV_HIP(hipMemcpy(shift.ptr, sh.data(), sh.size() * sizeof(float), hipMemcpyHostToDevice));
+    in_exp = in_exp_; out_exp = out_exp_;
     return Status();
 }
 
@@ -276,9 +317,67 @@ int choose_ns(int cfg, int dt, int rows, int64_t pixels, int n_stages) {
     return conv_cfg_has_ns(cfg, 3) ? 3 : 2;
 }
 
+bool calibration_enabled() {
+    static const bool on = env_int("CV_CALIBRATE", 1) != 0;
+    return on;
+}
+
 // ---- engine --------------------------------------------------------------------------------------
-Engine::Engine() {}
+Engine::Engine() { layer_names.push_back("input tensor"); }
 Engine::~Engine() { prof_clear(); }
+
+unsigned Engine::register_layer(const std::string& name) {
+    for (size_t i = 0; i < layer_names.size(); ++i)
+        if (layer_names[i] == name) return (unsigned)i;
+    layer_names.push_back(name);
+    return (unsigned)(layer_names.size() - 1);
+}
+
+Status Engine::guard_init() {
+    if (guard.ptr) return Status();
+    CV_TRY(guard.alloc(sizeof(unsigned), false));
+    CV_HIP(hipMemset(guard.ptr, 0xff, sizeof(unsigned)));
+    CV_TRY(cal_word.alloc(sizeof(unsigned), true));
+    return Status();
+}
+
+Status Engine::guard_check(hipStream_t s) {
+    if (!guard.ptr) return Status();
+    unsigned v = 0xffffffffu;
+    CV_HIP(hipMemcpyAsync(&v, guard.ptr, sizeof(v), hipMemcpyDeviceToHost, s));
+    CV_HIP(hipStreamSynchronize(s));
+    if (v == 0xffffffffu) return Status();
+    CV_HIP(hipMemset(guard.ptr, 0xff, sizeof(unsigned)));
+    const std::string who = v < layer_names.size() ? layer_names[v] : ("layer #" + std::to_string(v));
+    if (v == 0) return fail(5, "non-finite value (NaN / inf) in the input tensor");
+    return fail(5, "non-finite value produced by '" + who + "': an activation left the range the " +
+                       (dt == kF32 ? std::string("f32") : std::string("f16-based")) +
+                       " engine can hold (|x| > 65504 * 2^exp after calibration) or a NaN reached it; results of this "
+                       "call are invalid -- use precision f32 for this checkpoint");
+}
+
+// calibration: real-valued absolute maximum of the tensor just produced
+Status Engine::measure(const TensorRef& t, hipStream_t s) {
+    Activation* a = static_cast<Activation*>(t.owner);
+    if (!a) return Status();
+    CV_HIP(hipMemsetAsync(cal_word.ptr, 0, sizeof(unsigned), s));
+    CV_HIP(absmax(dt, t, reinterpret_cast<unsigned*>(cal_word.ptr), s));
+    unsigned bits = 0;
+    CV_HIP(hipMemcpyAsync(&bits, cal_word.ptr, sizeof(bits), hipMemcpyDeviceToHost, s));
+    CV_HIP(hipStreamSynchronize(s));
+    if (bits >= 0x7f800000u) { a->seen_bad = true; return Status(); }
+    float stored;
+    std::memcpy(&stored, &bits, sizeof(stored));
+    a->seen_max = std::max(a->seen_max, std::ldexp(stored, t.exp));
+    return Status();
+}
+
+size_t Engine::workspace_bytes() const {
+    size_t total = 0;
+    if (unet) for (const Activation* a : unet->acts) total += a->buf.bytes;
+    if (resnet) for (const Activation* a : resnet->acts) total += a->buf.bytes;
+    return total;
+}
 
 Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, const TensorRef* res, bool relu,
                         hipStream_t s, const Head* head, const TensorRef* pool_out) {
@@ -305,13 +404,20 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
     p.w = reinterpret_cast<const char*>(L.w.ptr);
     p.koff = koff;
     p.kbase = knobs().sep ? kbase : nullptr;
+    // tensor exponents (Activation): the fused head writes f32 logits, i.e. an output at exponent 0
+    const int out_exp = head ? 0 : y.exp;
+    CV_TRY(L.set_exps(x.exp, out_exp, s));
     p.scale = reinterpret_cast<const float*>(L.scale.ptr);
     p.shift = reinterpret_cast<const float*>(L.shift.ptr);
     p.res = nullptr;
+    p.res_mul = 1.f;
     if (res) {
         if (res->H != y.H || res->W != y.W || res->C != y.C) return fail(1, L.name + ": residual shape mismatch");
         p.res = reinterpret_cast<const char*>(res->base); p.rCs = res->Cs; p.rCoff = res->Coff;
+        p.res_mul = std::ldexp(1.f, res->exp - out_exp);
     }
+    p.flag = guard_ptr();
+    p.layer_id = L.layer_id;
     p.y = reinterpret_cast<char*>(y.base);
     p.M = x.N * Ho * Wo; p.Ho = Ho; p.Wo = Wo;
     p.xHp = x.H + 2; p.xWp = x.W + 2; p.stride = L.stride; p.xCs = x.Cs; p.xCoffBytes = x.Coff * esz;
@@ -350,7 +456,17 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
         stamp_n = ((size_t)p.M / 128 + 1) * (size_t)p.nCt * 8 * 8;
         if (hipMalloc(&stamp_dev, stamp_n * 8) == hipSuccess) { (void)hipMemsetAsync(stamp_dev, 0, stamp_n * 8, s); p.stamp = stamp_dev; }
     }
-    if (profiling) prof_begin(L.name, true, (double)L.macs_per_out_pixel() * (double)p.M, s);
+    if (profiling) {
+        // compulsory bytes: the input slice once (a strided 1x1 touches every other pixel only), output (+ pooled copy,
+        // + residual) once, weights once -- at the engine's storage width; the fused head writes one f32 (+ mask byte)
+        const double in_px = (L.k == 1 && L.stride == 2) ? (double)p.M : (double)x.N * x.H * x.W;
+        const double out_px = L.shuffle ? 4.0 * p.M : (double)p.M;
+        double b = in_px * L.cinPad * esz + (double)L.rows * L.k * L.k * L.cin * esz;
+        b += head ? (double)p.M * (4 + (head->mask ? 1 : 0)) : out_px * L.cout * esz;
+        if (res) b += out_px * L.cout * esz;
+        if (pool_out) b += out_px / 4 * L.cout * esz;
+        prof_begin(L.name, true, (double)L.macs_per_out_pixel() * (double)p.M, s, b);
+    }
     hipError_t e = halo ? conv_halo_launch(ct, dt, p, x.N, s) : conv_igemm_launch(cfg, ns, dt, p, s);
     if (profiling) prof_end(s);
     if (stamp_dev) {
@@ -376,6 +492,8 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
         }
     }
     if (e != hipSuccess) return hip_fail(e, ("conv launch " + L.name).c_str());
+    if (calibrating && !head) CV_TRY(measure(y, s));
+    if (pool_out && pool_out->exp != y.exp) return fail(1, L.name + ": pooled copy must share the exponent of its source");
     if (pool_out && !fuse_pool) {
         if (profiling) prof_begin("maxpool2x2", false, 0, s);
         e = maxpool2x2(dt, y, *pool_out, s);
@@ -385,9 +503,9 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
     return Status();
 }
 
-void Engine::prof_begin(const std::string& name, bool is_conv, double macs, hipStream_t s) {
+void Engine::prof_begin(const std::string& name, bool is_conv, double macs, hipStream_t s, double bytes) {
     ProfileEntry pe;
-    pe.name = name; pe.is_conv = is_conv; pe.macs = macs;
+    pe.name = name; pe.is_conv = is_conv; pe.macs = macs; pe.bytes = bytes;
     (void)hipEventCreate(&pe.e0);
     (void)hipEventCreate(&pe.e1);
     (void)hipEventRecord(pe.e0, s);

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdint>
 #include <map>
 #include <memory>
@@ -56,14 +57,31 @@ struct DeviceBuffer {
 };
 
 // a PHWC activation buffer sized for `cap` images
+//
+// Range scaling (f16 / split-f16 engines): the buffer holds real_value * 2^-exp.  f16 carries 5 exponent bits, and the lo
+// half of a split-f16 value goes subnormal below 2^-14, so a tensor is only f32-grade while its magnitudes sit in roughly
+// [2^-3, 2^15].  `exp` is chosen per tensor at load time by a calibration pass (models: calibrate()) so that the largest
+// magnitude seen lands in [16, 32): 2^11 of head-room before the f16 range ends, full lo precision down to 2^-7 of the
+// maximum, absolute error 2^-25 below that.  The factors are powers of two and are folded into the f32 epilogue
+// scale/shift of the producing layer and of every consumer, so they cost nothing and change no rounding of the real
+// values; what still leaves the range trips the numeric guard (ConvParams::flag).  Always 0 for the f32 engine.
 struct Activation {
     DeviceBuffer buf;
     int cap = 0, H = 0, W = 0, C = 0;
     int dt = kF16;
-    Status create(int cap_, int h, int w, int c, int dt_);
+    int exp = 0;
+    // calibration statistics of the current pass (real-valued maximum = stored maximum * 2^exp) and policy
+    float seen_max = 0.f;
+    bool seen_bad = false;
+    bool fixed_exp = false;                         // inputs: exp is set by construction, not measured
+    Activation* tie = nullptr;                      // same exp as `tie` (pooled copy of a tensor, concat halves)
+    void shape(int h, int w, int c, int dt_) { H = h; W = w; C = c; dt = dt_; }
+    Status reserve(int cap_);                       // (re)allocate for cap_ images, zero-filled; exp and shape stay
+    Status create(int cap_, int h, int w, int c, int dt_) { shape(h, w, c, dt_); return reserve(cap_); }
     TensorRef ref(int n, int coff = 0, int c = -1) const {
         TensorRef t;
         t.base = buf.ptr; t.N = n; t.H = H; t.W = W; t.Cs = C; t.Coff = coff; t.C = c < 0 ? C - coff : c;
+        t.exp = exp; t.owner = const_cast<Activation*>(this);
         return t;
     }
     size_t bytes_per_image() const { return (size_t)(H + 2) * (W + 2) * C * dtype_size(dt); }
@@ -82,6 +100,13 @@ struct ConvLayer {
     int dt = kF16;
     DeviceBuffer w, scale, shift;
     DeviceBuffer w_small;                           // ct == 256 layers only: the same weights packed for 128-row tiles
+    // Per-row epilogue constants on the host: h_scale already contains 2^(row exponent) of the weight normalisation
+    // (f16 / split-f16: every weight row is stored as w * 2^-e with its largest magnitude in [0.5, 1), so small trained
+    // weights keep all 22 bits).  The device copies are h_scale * 2^(in_exp - out_exp) and h_shift * 2^-out_exp for the
+    // tensor exponents the layer currently runs with (set_exps).
+    std::vector<float> h_scale, h_shift;
+    int in_exp = 0, out_exp = 0;
+    unsigned layer_id = 0xfffffffeu;                // numeric guard id (Engine::register_layer)
     // koff tables are geometry dependent: keyed by (xWp, xCs, xCoff)
     struct KoffKey { int xWp, xCs, xCoff; bool operator<(const KoffKey& o) const {
         if (xWp != o.xWp) return xWp < o.xWp; if (xCs != o.xCs) return xCs < o.xCs; return xCoff < o.xCoff; } };
@@ -96,6 +121,7 @@ struct ConvLayer {
     Status build_convT(const std::string& name_, int dt_, const float* w_iohw, int cin_, int cout_,
                        const float* bias, int64_t pixels_hint_ = 0);
     Status get_koff(const TensorRef& x, const int** chunks, const int** bases);
+    Status set_exps(int in_exp_, int out_exp_, hipStream_t s);
     int64_t macs_per_out_pixel() const { return shuffle ? (int64_t)cin * cout * 4 : (int64_t)cin * k * k * cout; }
 };
 
@@ -103,6 +129,7 @@ struct ProfileEntry {
     std::string name;
     bool is_conv = false;
     double macs = 0;
+    double bytes = 0;                               // algorithmic HBM bytes of the launch (inputs + outputs + weights, once each)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     float ms = 0.f;
 };
@@ -122,6 +149,21 @@ class Engine {
 
     DeviceBuffer scratch;                               // small per-call parameter blocks (homographies)
 
+    // numeric guard: one device word, 0xffffffff = clean, else the lowest id of a layer that stored a non-finite value
+    DeviceBuffer guard;
+    std::vector<std::string> layer_names;               // id -> name; id 0 = the caller's input tensor
+    unsigned register_layer(const std::string& name);
+    unsigned* guard_ptr() const { return reinterpret_cast<unsigned*>(guard.ptr); }
+    Status guard_init();
+    Status guard_check(hipStream_t s);                  // synchronises; fails with the layer name and re-arms
+
+    // range calibration (see Activation): while set, every producer measures its output tensor after the launch
+    bool calibrating = false;
+    DeviceBuffer cal_word;
+    Status measure(const TensorRef& t, hipStream_t s);
+    template <class Fwd> Status calibrate(const std::vector<Activation*>& acts, Fwd&& forward, hipStream_t s, const char* what);
+    size_t workspace_bytes() const;
+
     // profiling (cv_profile_convs)
     bool profiling = false;
     std::vector<ProfileEntry> prof;
@@ -134,12 +176,13 @@ class Engine {
     // otherwise by the stand-alone pooling kernel right after it
     Status run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, const TensorRef* res, bool relu,
                     hipStream_t s, const Head* head = nullptr, const TensorRef* pool_out = nullptr);
-    void prof_begin(const std::string& name, bool is_conv, double macs, hipStream_t s);
+    void prof_begin(const std::string& name, bool is_conv, double macs, hipStream_t s, double bytes = 0);
     void prof_end(hipStream_t s);
     Status prof_collect();
     void prof_clear();
 };
 
+bool calibration_enabled();                         // CV_CALIBRATE=0 switches the activation exponents off (tests of the guard)
 int choose_ct(int rows, int64_t pixels_hint, bool halo_ok);
 int choose_cfg(int ct, int rows, int64_t pixels, int n_stages);
 int choose_ns(int cfg, int dt, int rows, int64_t pixels, int n_stages);
@@ -154,5 +197,39 @@ Status resnet_load(Engine& e, const ParamMap& pm);
 Status resnet_forward(Engine& e, const void* x, bool x_u8, int n, float* out, bool softmax, hipStream_t s);
 Status resnet_activation(Engine& e, const std::string& name, TensorRef* out);
 int64_t resnet_macs(Engine& e);
+
+// Iterate calibration passes until every tensor exponent is stable (hysteresis: an exponent stays while the measured
+// maximum is inside [8, 64) of stored units).  `forward` runs one forward over the calibration batch with e.calibrating set.
+template <class Fwd>
+Status Engine::calibrate(const std::vector<Activation*>& acts, Fwd&& forward, hipStream_t s, const char* what) {
+    if (dt == kF32 || !calibration_enabled()) return Status();
+    for (int pass = 0; pass < 10; ++pass) {
+        for (Activation* a : acts) { a->seen_max = 0.f; a->seen_bad = false; }
+        calibrating = true;
+        Status st = forward();
+        calibrating = false;
+        if (!st.ok()) return st;
+        CV_HIP(hipStreamSynchronize(s));
+        CV_HIP(hipMemset(guard.ptr, 0xff, sizeof(unsigned)));      // overflow during calibration is expected, not an error
+        bool changed = false;
+        for (Activation* a : acts) {
+            if (a->fixed_exp || a->tie) continue;
+            int want = a->exp;
+            if (a->seen_bad) want = a->exp + 12;
+            else if (a->seen_max > 0.f) {
+                int e2;
+                (void)std::frexp(a->seen_max, &e2);                // seen_max = f * 2^e2, f in [0.5, 1)
+                const int stored_e = e2 - a->exp;                  // stored maximum in [2^(stored_e-1), 2^stored_e)
+                if (stored_e < 4 || stored_e > 6) want = e2 - 5;   // re-centre on [16, 32)
+            }
+            want = want < -60 ? -60 : want > 60 ? 60 : want;
+            if (want != a->exp) { a->exp = want; changed = true; }
+        }
+        for (Activation* a : acts)
+            if (a->tie && a->exp != a->tie->exp) { a->exp = a->tie->exp; changed = true; }
+        if (!changed) return Status();
+    }
+    return fail(1, std::string(what) + ": activation range calibration did not converge (non-finite weights or activations beyond f32?)");
+}
 
 }  // namespace cv

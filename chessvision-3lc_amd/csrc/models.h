@@ -4,33 +4,47 @@
 
 namespace cv {
 
+// Workspaces are elastic: a model is loaded with no activation memory beyond what the range calibration needs and
+// `reserve(n)` (re)allocates every tensor for min(n, engine chunk) images the first time a batch of that size arrives --
+// a single-image server (the reference's Flask endpoint) stays under 1 GB, a throughput job grows once to its chunk.
 struct Engine::UNet {
     bool bilinear = false;
     bool fuse_head = true;                          // OutConv fused into up4's last conv epilogue
-    int cap = 0;                                    // images per chunk
+    int cap = 0;                                    // images the workspace currently holds
+    int max_cap = 64;                               // engine chunk: images per pass
     int last_n = 0;                                 // images in the most recent chunk
     // channel plan
     int c1 = 64, c2 = 128, c3 = 256, c4 = 512, c5 = 1024;
     ConvLayer inc0, inc1, d[4][2], upT[4], u[4][2];
+    unsigned up_id[4] = {0, 0, 0, 0}, outc_id = 0;  // numeric-guard ids of the non-conv producers
     DeviceBuffer outc_w, outc_b;
     // activations
     Activation in8, a_inc0, cat[4], pool[4], dmid[4], bott, umid[4], uout[4];
+    std::vector<Activation*> acts;                  // every tensor above that exists in this variant
     std::map<std::string, TensorRef> taps;          // module name -> tensor produced (capacity-sized refs)
     int64_t macs = 0;
 };
 
 struct Engine::ResNet {
     int cap = 0;
+    int max_cap = 16384;
     int last_n = 0;
     DeviceBuffer stem_w, stem_wpk, stem_scale, stem_shift, fc_w, fc_b;
+    std::vector<float> h_stem_scale, h_stem_shift;  // row exponents of the normalised stem filters folded in (ConvLayer::h_scale)
+    int stem_out_exp = 0;                           // exponent the device copies are currently folded for
+    unsigned stem_id = 0, head_id = 0;
     struct Block {
         ConvLayer conv1, conv2, down;
         bool has_down = false;
         Activation mid, out, sc;                     // conv1 output, block output, shortcut (if downsampled)
     } blocks[8];
     Activation stem_out, pool_out;
+    std::vector<Activation*> acts;
     std::map<std::string, TensorRef> taps;
     int64_t macs = 0;
 };
+
+// x in [0,1] is held as x * 2^7 inside the f16-based engines (both models' inputs)
+constexpr int kInputExp = -7;
 
 }  // namespace cv

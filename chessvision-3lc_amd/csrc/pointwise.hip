@@ -11,6 +11,9 @@
 // packing of core.py:215-216 / 236-237.
 #include "pointwise.h"
 
+#include <algorithm>
+#include <cmath>
+
 namespace cv {
 
 // A "group" = the channels one lane moves per access: 8 (f16: 16 B; split-f16: 16 B hi + 16 B lo) or 4 (f32: 16 B).
@@ -28,6 +31,11 @@ template <> struct Grp<half_t> {
         for (int j = 0; j < 8; ++j) h[j] = (half_t)v[j];
         *reinterpret_cast<half8*>(p) = h;
     }
+    static __device__ __forceinline__ void store(char* p, int par, const float* v, float& bad) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bad = __builtin_fmaf((float)(half_t)v[j], 0.f, bad);
+        store(p, par, v);
+    }
 };
 template <> struct Grp<float> {
     static constexpr int N = 4, BYTES = 16;
@@ -37,6 +45,11 @@ template <> struct Grp<float> {
     }
     static __device__ __forceinline__ void store(char* p, int, const float* v) {
         *reinterpret_cast<f4*>(p) = f4{v[0], v[1], v[2], v[3]};
+    }
+    static __device__ __forceinline__ void store(char* p, int par, const float* v, float& bad) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bad = __builtin_fmaf(v[j], 0.f, bad);
+        store(p, par, v);
     }
 };
 template <> struct Grp<split_t> {              // [hi x8][lo x8] for even groups, [lo x8][hi x8] for odd ones
@@ -54,7 +67,17 @@ template <> struct Grp<split_t> {              // [hi x8][lo x8] for even groups
         *reinterpret_cast<half8*>(p + (parity ? 16 : 0)) = hi;
         *reinterpret_cast<half8*>(p + (parity ? 0 : 16)) = lo;
     }
+    static __device__ __forceinline__ void store(char* p, int parity, const float* v, float& bad) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bad = __builtin_fmaf((float)(half_t)v[j], 0.f, bad);   // inf / NaN -> NaN
+        store(p, parity, v);
+    }
 };
+
+// numeric guard (cv_kernels.h: ConvParams::flag): the lowest layer id that stored a non-finite value wins
+__device__ __forceinline__ void report_bad(unsigned* flag, unsigned layer_id, float bad) {
+    if (bad != bad && flag) atomicMin(flag, layer_id);
+}
 
 __device__ __forceinline__ size_t pix_index(const TensorRef& t, int n, int y, int x) {
     return (size_t)(n * (t.H + 2) + y + 1) * (t.W + 2) + (x + 1);
@@ -89,7 +112,7 @@ template <typename T> __device__ __forceinline__ PG decode_pg(const TensorRef& t
 
 // ---- packing ----------------------------------------------------------------------------------------
 template <typename T>
-__global__ void pack_nchw_f32_kernel(const float* __restrict__ src, int c, TensorRef dst) {
+__global__ void pack_nchw_f32_kernel(const float* __restrict__ src, int c, TensorRef dst, float mul, unsigned* flag) {
     constexpr int GN = Grp<T>::N;
     const PG p = decode_pg<T>(dst);
     if (!p.live) return;
@@ -97,15 +120,17 @@ __global__ void pack_nchw_f32_kernel(const float* __restrict__ src, int c, Tenso
 #pragma unroll
     for (int j = 0; j < GN; ++j) {
         const int ch = p.g * GN + j;
-        v[j] = ch < c ? src[((size_t)(p.n * c + ch) * dst.H + p.y) * dst.W + p.x] : 0.f;
+        v[j] = ch < c ? src[((size_t)(p.n * c + ch) * dst.H + p.y) * dst.W + p.x] * mul : 0.f;
     }
     int par;
     char* d = grp_ptr<T>(dst, pix_index(dst, p.n, p.y, p.x), p.g, &par);
-    Grp<T>::store(d, par, v);
+    float bad = 0.f;
+    Grp<T>::store(d, par, v, bad);
+    report_bad(flag, 0u, bad);                               // layer id 0 = the caller's input tensor
 }
 
 template <typename T>
-__global__ void pack_hwc3_u8_kernel(const uint8_t* __restrict__ src, TensorRef dst) {
+__global__ void pack_hwc3_u8_kernel(const uint8_t* __restrict__ src, TensorRef dst, float mul) {
     constexpr int GN = Grp<T>::N;
     const size_t total = (size_t)dst.N * dst.H * dst.W;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -115,7 +140,8 @@ __global__ void pack_hwc3_u8_kernel(const uint8_t* __restrict__ src, TensorRef d
     const int y = (int)(pix % dst.H);
     const int n = (int)(pix / dst.H);
     const uint8_t* s = src + idx * 3;
-    const float f[8] = {(float)s[0] / 255.f, (float)s[1] / 255.f, (float)s[2] / 255.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // /255 first (the reference's arithmetic, core.py:215), then the power-of-two range factor (exact)
+    const float f[8] = {(float)s[0] / 255.f * mul, (float)s[1] / 255.f * mul, (float)s[2] / 255.f * mul, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int g = 0; g < 8 / GN; ++g) {
         int par;
@@ -125,7 +151,7 @@ __global__ void pack_hwc3_u8_kernel(const uint8_t* __restrict__ src, TensorRef d
 }
 
 template <typename T>
-__global__ void unpack_nchw_f32_kernel(TensorRef src, float* __restrict__ dst) {
+__global__ void unpack_nchw_f32_kernel(TensorRef src, float* __restrict__ dst, float mul) {
     constexpr int GN = Grp<T>::N;
     const size_t total = (size_t)src.N * src.C * src.H * src.W;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -142,7 +168,35 @@ __global__ void unpack_nchw_f32_kernel(TensorRef src, float* __restrict__ dst) {
     float out = v[0];
 #pragma unroll
     for (int j = 1; j < GN; ++j) out = (c % GN) == j ? v[j] : out;
-    dst[idx] = out;
+    dst[idx] = out * mul;
+}
+
+// ---- range calibration: max |stored value| over the interior of a slice, as the bits of a non-negative float ------
+// (unsigned order == float order there; NaN bit patterns sort above +inf, so "non-finite" reads as >= 0x7f800000)
+template <typename T>
+__global__ void absmax_kernel(TensorRef src, unsigned* __restrict__ out) {
+    constexpr int GN = Grp<T>::N;
+    const int groups = src.C / GN;
+    const size_t total = (size_t)src.N * src.H * src.W * groups;
+    unsigned m = 0;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int g = (int)(idx % groups);
+        size_t pix = idx / groups;
+        const int x = (int)(pix % src.W); pix /= src.W;
+        const int y = (int)(pix % src.H);
+        const int n = (int)(pix / src.H);
+        int par;
+        float v[GN];
+        Grp<T>::load(grp_ptr<T>(src, pix_index(src, n, y, x), g, &par), par, v);
+#pragma unroll
+        for (int j = 0; j < GN; ++j) {
+            const unsigned b = __float_as_uint(v[j]) & 0x7fffffffu;
+            m = b > m ? b : m;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)m, o); m = t > m ? t : m; }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
 
 // ---- pooling / upsampling --------------------------------------------------------------------------
@@ -193,7 +247,7 @@ __global__ void maxpool3x3s2_kernel(TensorRef src, TensorRef dst) {
 
 // torch upsample_bilinear2d, align_corners=True: src = dst * (in-1)/(out-1); weights (1-l, l) in f32
 template <typename T>
-__global__ void upsample_bilinear2x_kernel(TensorRef src, TensorRef dst) {
+__global__ void upsample_bilinear2x_kernel(TensorRef src, TensorRef dst, float mul, unsigned* flag, unsigned layer_id) {
     constexpr int GN = Grp<T>::N;
     const PG p = decode_pg<T>(dst);
     if (!p.live) return;
@@ -212,16 +266,19 @@ __global__ void upsample_bilinear2x_kernel(TensorRef src, TensorRef dst) {
     Grp<T>::load(grp_ptr<T>(src, pix_index(src, p.n, y1, x1), p.g, &par), par, v11);
 #pragma unroll
     for (int j = 0; j < GN; ++j)
-        o[j] = ly0 * (lx0 * v00[j] + lx1 * v01[j]) + ly1 * (lx0 * v10[j] + lx1 * v11[j]);
+        o[j] = (ly0 * (lx0 * v00[j] + lx1 * v01[j]) + ly1 * (lx0 * v10[j] + lx1 * v11[j])) * mul;   // mul = 2^k: exact
     char* d = grp_ptr<T>(dst, pix_index(dst, p.n, p.y, p.x), p.g, &par);
-    Grp<T>::store(d, par, o);
+    float bad = 0.f;
+    Grp<T>::store(d, par, o, bad);
+    report_bad(flag, layer_id, bad);
 }
 
 // ---- OutConv 1x1 (C -> 1) + bias, fused sigmoid/threshold mask ------------------------------------
 // C/N lanes share one pixel (one group each); xor-shuffle reduce inside the lane group.
 template <typename T>
-__global__ void outc_1x1_kernel(TensorRef src, const float* __restrict__ w, const float* __restrict__ bias,
-                                float* __restrict__ logits, uint8_t* __restrict__ mask, float thr) {
+__global__ void outc_1x1_kernel(TensorRef src, const float* __restrict__ w, const float* __restrict__ bias, float mul,
+                                float* __restrict__ logits, uint8_t* __restrict__ mask, float thr, unsigned* flag,
+                                unsigned layer_id) {
     constexpr int GN = Grp<T>::N;
     const int lpp = src.C / GN;                               // power of two, <= 64
     const size_t npix = (size_t)src.N * src.H * src.W;
@@ -242,9 +299,10 @@ __global__ void outc_1x1_kernel(TensorRef src, const float* __restrict__ w, cons
     for (int j = 0; j < GN; ++j) acc += v[j] * w[part * GN + j];
     for (int m = 1; m < lpp; m <<= 1) acc += __shfl_xor(acc, m);
     if (live && part == 0) {
-        const float l = acc + bias[0];
+        const float l = acc * mul + bias[0];
         logits[pix] = l;
         if (mask) mask[pix] = (1.f / (1.f + __expf(-l))) > thr ? 255 : 0;
+        report_bad(flag, layer_id, l * 0.f);
     }
 }
 
@@ -316,7 +374,8 @@ template <typename T, typename XT>
 __global__ __launch_bounds__(256) void stem_pool_mfma_kernel(const XT* __restrict__ x, int n,
                                                              const half8* __restrict__ wpk,
                                                              const float* __restrict__ scale,
-                                                             const float* __restrict__ shift, TensorRef dst) {
+                                                             const float* __restrict__ shift, float in_mul, TensorRef dst,
+                                                             unsigned* flag, unsigned layer_id) {
     constexpr bool SPLIT = sizeof(T) == 4;
     constexpr int LD = 98, ROWS = 72, PAD = 5;              // LD/2 = 49 dwords: odd rows land on the other bank half
     __shared__ __attribute__((aligned(16))) half_t plane[SPLIT ? 2 : 1][ROWS * LD];
@@ -339,12 +398,14 @@ __global__ __launch_bounds__(256) void stem_pool_mfma_kernel(const XT* __restric
     const unsigned* p32h = reinterpret_cast<const unsigned*>(&plane[0][0]);
     const unsigned* p32l = reinterpret_cast<const unsigned*>(&plane[SPLIT ? 1 : 0][0]);
 
+    float bad = 0.f;
     for (int sq = blockIdx.x; sq < n; sq += gridDim.x) {
         __syncthreads();                                     // all fragment reads of the previous square are done
         const XT* xs = x + (size_t)sq * 4096;
         for (int i = tid; i < 4096; i += 256) {
             float v = (float)xs[i];
             if (sizeof(XT) == 1) v = v / 255.f;
+            v *= in_mul;                                     // power-of-two range factor of the input plane (exact)
             const half_t hi = (half_t)v;
             const int at = ((i >> 6) + PAD) * LD + (i & 63) + PAD;
             plane[0][at] = hi;
@@ -394,18 +455,19 @@ __global__ __launch_bounds__(256) void stem_pool_mfma_kernel(const XT* __restric
             for (int i = 0; i < 16; i += Grp<T>::N) {
                 int par;
                 char* d = grp_ptr<T>(dst, opix, (q * 16 + i) / Grp<T>::N, &par);
-                Grp<T>::store(d, par, best + i);
+                Grp<T>::store(d, par, best + i, bad);
             }
         }
     }
+    report_bad(flag, layer_id, bad);
 }
 
 // ---- head: adaptive_avg_pool2d(1) + Linear(C -> 13) (+ softmax) ------------------------------------
 // One wave per square; lane owns channel groups lane, lane+64, ...; 13 wave-wide xor-butterfly reductions.
 template <typename T>
 __global__ __launch_bounds__(256) void head_kernel(TensorRef src, const float* __restrict__ w,
-                                                   const float* __restrict__ b, float* __restrict__ out,
-                                                   int softmax) {
+                                                   const float* __restrict__ b, float mul, float* __restrict__ out,
+                                                   int softmax, unsigned* flag, unsigned layer_id) {
     constexpr int NC = 13;
     constexpr int GN = Grp<T>::N;
     const int lane = threadIdx.x & 63;
@@ -414,7 +476,7 @@ __global__ __launch_bounds__(256) void head_kernel(TensorRef src, const float* _
     float acc[NC];
 #pragma unroll
     for (int j = 0; j < NC; ++j) acc[j] = 0.f;
-    const float inv = 1.f / (float)(src.H * src.W);
+    const float inv = mul / (float)(src.H * src.W);           // mul = 2^exp of the stored tensor (exact)
     const int groups = src.C / GN;
     for (int g = lane; g < groups; g += 64) {
         float s[GN], v[GN];
@@ -439,6 +501,12 @@ __global__ __launch_bounds__(256) void head_kernel(TensorRef src, const float* _
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) acc[j] += __shfl_xor(acc[j], m);
         acc[j] += b[j];
+    }
+    {
+        float bad = 0.f;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) bad = __builtin_fmaf(acc[j], 0.f, bad);
+        if (lane == 0) report_bad(flag, layer_id, bad);
     }
     if (softmax) {
         float mx = acc[0];
@@ -505,17 +573,28 @@ __global__ void mfma_probe_f32_kernel(const float* a, const float* b, float* d) 
         return hipGetLastError();                                                                            \
     } while (0)
 
-hipError_t pack_nchw_f32(int dt, const float* src, int c, const TensorRef& dst, hipStream_t s) {
+static inline float pow2f(int e) { return ldexpf(1.f, e); }
+
+hipError_t pack_nchw_f32(int dt, const float* src, int c, const TensorRef& dst, unsigned* flag, hipStream_t s) {
     if (dst.C % dtype_group(dt) || dst.Coff % dtype_group(dt)) return hipErrorInvalidValue;
-    CV_DISPATCH(pack_nchw_f32_kernel, (size_t)dst.N * dst.H * dst.W * (dst.C / dtype_group(dt)), src, c, dst);
+    CV_DISPATCH(pack_nchw_f32_kernel, (size_t)dst.N * dst.H * dst.W * (dst.C / dtype_group(dt)), src, c, dst, pow2f(-dst.exp), flag);
 }
 hipError_t pack_hwc3_u8(int dt, const uint8_t* src, const TensorRef& dst, hipStream_t s) {
     if (dst.C != 8 || dst.Coff % 8) return hipErrorInvalidValue;
-    CV_DISPATCH(pack_hwc3_u8_kernel, (size_t)dst.N * dst.H * dst.W, src, dst);
+    CV_DISPATCH(pack_hwc3_u8_kernel, (size_t)dst.N * dst.H * dst.W, src, dst, pow2f(-dst.exp));
 }
 hipError_t unpack_nchw_f32(int dt, const TensorRef& src, float* dst, hipStream_t s) {
     if (src.Coff % dtype_group(dt)) return hipErrorInvalidValue;
-    CV_DISPATCH(unpack_nchw_f32_kernel, (size_t)src.N * src.C * src.H * src.W, src, dst);
+    CV_DISPATCH(unpack_nchw_f32_kernel, (size_t)src.N * src.C * src.H * src.W, src, dst, pow2f(src.exp));
+}
+hipError_t absmax(int dt, const TensorRef& src, unsigned* out, hipStream_t s) {
+    if (src.C % dtype_group(dt) || src.Coff % dtype_group(dt)) return hipErrorInvalidValue;
+    const size_t work = (size_t)src.N * src.H * src.W * (src.C / dtype_group(dt));
+    const dim3 g_((unsigned)std::min<size_t>(grid_for(work), 4096)), b_(256);
+    if (dt == kF16) hipLaunchKernelGGL(absmax_kernel<half_t>, g_, b_, 0, s, src, out);
+    else if (dt == kSplit) hipLaunchKernelGGL(absmax_kernel<split_t>, g_, b_, 0, s, src, out);
+    else hipLaunchKernelGGL(absmax_kernel<float>, g_, b_, 0, s, src, out);
+    return hipGetLastError();
 }
 hipError_t maxpool2x2(int dt, const TensorRef& src, const TensorRef& dst, hipStream_t s) {
     CV_DISPATCH(maxpool2x2_kernel, (size_t)dst.N * dst.H * dst.W * (dst.C / dtype_group(dt)), src, dst);
@@ -523,14 +602,17 @@ hipError_t maxpool2x2(int dt, const TensorRef& src, const TensorRef& dst, hipStr
 hipError_t maxpool3x3s2(int dt, const TensorRef& src, const TensorRef& dst, hipStream_t s) {
     CV_DISPATCH(maxpool3x3s2_kernel, (size_t)dst.N * dst.H * dst.W * (dst.C / dtype_group(dt)), src, dst);
 }
-hipError_t upsample_bilinear2x(int dt, const TensorRef& src, const TensorRef& dst, hipStream_t s) {
-    CV_DISPATCH(upsample_bilinear2x_kernel, (size_t)dst.N * dst.H * dst.W * (dst.C / dtype_group(dt)), src, dst);
+hipError_t upsample_bilinear2x(int dt, const TensorRef& src, const TensorRef& dst, unsigned* flag, unsigned layer_id,
+                               hipStream_t s) {
+    CV_DISPATCH(upsample_bilinear2x_kernel, (size_t)dst.N * dst.H * dst.W * (dst.C / dtype_group(dt)), src, dst,
+                pow2f(src.exp - dst.exp), flag, layer_id);
 }
 hipError_t outc_1x1(int dt, const TensorRef& src, const float* w, const float* bias, float* logits,
-                    uint8_t* mask, float threshold, hipStream_t s) {
+                    uint8_t* mask, float threshold, unsigned* flag, unsigned layer_id, hipStream_t s) {
     const int lpp = src.C / dtype_group(dt);
     if (lpp < 1 || lpp > 64 || (lpp & (lpp - 1))) return hipErrorInvalidValue;
-    CV_DISPATCH(outc_1x1_kernel, (size_t)src.N * src.H * src.W * lpp, src, w, bias, logits, mask, threshold);
+    CV_DISPATCH(outc_1x1_kernel, (size_t)src.N * src.H * src.W * lpp, src, w, bias, pow2f(src.exp), logits, mask, threshold,
+                flag, layer_id);
 }
 hipError_t stem7x7(int dt, const void* x, bool x_is_u8, int n, const float* w, const float* scale,
                    const float* shift, const TensorRef& dst, hipStream_t s) {
@@ -546,26 +628,29 @@ hipError_t stem7x7(int dt, const void* x, bool x_is_u8, int n, const float* w, c
     return hipGetLastError();
 }
 hipError_t stem_pool_mfma(int dt, const void* x, bool x_is_u8, int n, const void* wpk, const float* scale,
-                          const float* shift, const TensorRef& dst, hipStream_t s) {
+                          const float* shift, int in_exp, const TensorRef& dst, unsigned* flag, unsigned layer_id,
+                          hipStream_t s) {
     if (dt == kF32 || dst.C != 64 || dst.H != 16 || dst.W != 16 || dst.Coff != 0) return hipErrorInvalidValue;
     const dim3 g((unsigned)(n < 2048 ? n : 2048)), b(256);
     const half8* w = reinterpret_cast<const half8*>(wpk);
+    const float im = pow2f(-in_exp);
     if (dt == kF16) {
-        if (x_is_u8) hipLaunchKernelGGL((stem_pool_mfma_kernel<half_t, uint8_t>), g, b, 0, s, (const uint8_t*)x, n, w, scale, shift, dst);
-        else hipLaunchKernelGGL((stem_pool_mfma_kernel<half_t, float>), g, b, 0, s, (const float*)x, n, w, scale, shift, dst);
+        if (x_is_u8) hipLaunchKernelGGL((stem_pool_mfma_kernel<half_t, uint8_t>), g, b, 0, s, (const uint8_t*)x, n, w, scale, shift, im, dst, flag, layer_id);
+        else hipLaunchKernelGGL((stem_pool_mfma_kernel<half_t, float>), g, b, 0, s, (const float*)x, n, w, scale, shift, im, dst, flag, layer_id);
     } else {
-        if (x_is_u8) hipLaunchKernelGGL((stem_pool_mfma_kernel<split_t, uint8_t>), g, b, 0, s, (const uint8_t*)x, n, w, scale, shift, dst);
-        else hipLaunchKernelGGL((stem_pool_mfma_kernel<split_t, float>), g, b, 0, s, (const float*)x, n, w, scale, shift, dst);
+        if (x_is_u8) hipLaunchKernelGGL((stem_pool_mfma_kernel<split_t, uint8_t>), g, b, 0, s, (const uint8_t*)x, n, w, scale, shift, im, dst, flag, layer_id);
+        else hipLaunchKernelGGL((stem_pool_mfma_kernel<split_t, float>), g, b, 0, s, (const float*)x, n, w, scale, shift, im, dst, flag, layer_id);
     }
     return hipGetLastError();
 }
 hipError_t head_avgpool_fc(int dt, const TensorRef& src, const float* w, const float* b, float* out,
-                           int softmax, hipStream_t s) {
+                           int softmax, unsigned* flag, unsigned layer_id, hipStream_t s) {
     if (src.C % dtype_group(dt)) return hipErrorInvalidValue;
     const dim3 g((unsigned)((src.N + 3) / 4)), blk(256);
-    if (dt == kF16) hipLaunchKernelGGL(head_kernel<half_t>, g, blk, 0, s, src, w, b, out, softmax);
-    else if (dt == kSplit) hipLaunchKernelGGL(head_kernel<split_t>, g, blk, 0, s, src, w, b, out, softmax);
-    else hipLaunchKernelGGL(head_kernel<float>, g, blk, 0, s, src, w, b, out, softmax);
+    const float mul = pow2f(src.exp);
+    if (dt == kF16) hipLaunchKernelGGL(head_kernel<half_t>, g, blk, 0, s, src, w, b, mul, out, softmax, flag, layer_id);
+    else if (dt == kSplit) hipLaunchKernelGGL(head_kernel<split_t>, g, blk, 0, s, src, w, b, mul, out, softmax, flag, layer_id);
+    else hipLaunchKernelGGL(head_kernel<float>, g, blk, 0, s, src, w, b, mul, out, softmax, flag, layer_id);
     return hipGetLastError();
 }
 hipError_t softmax13(const float* logits, int n, float* probs, hipStream_t s) {

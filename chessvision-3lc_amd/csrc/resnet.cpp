@@ -13,16 +13,30 @@
 
 namespace cv {
 
-Status build_conv_bn_public(ConvLayer& L, int dt, const ParamMap& pm, const std::string& conv_key,
+Status build_conv_bn_public(Engine& e, ConvLayer& L, const ParamMap& pm, const std::string& conv_key,
                             const std::string& bn_key, int cout, int cin, int k, int stride, int cinPad,
                             int64_t pixels, int out_hw);
+Status need_public(const ParamMap& pm, const std::string& key, std::vector<int64_t> shape, const float** out);
+Status bn_fold_public(const ParamMap& pm, const std::string& prefix, int c, std::vector<float>& scale, std::vector<float>& shift);
+Status reject_unknown_keys_public(const ParamMap& pm, const std::vector<std::string>& known, const char* model);
 
+static Status resnet_reserve(Engine& e, int n);
+static Status resnet_chunk(Engine& e, const void* x, bool x_u8, int n, float* out, bool softmax, hipStream_t s);
 
-static Status need2(const ParamMap& pm, const std::string& key, std::vector<int64_t> shape, const float** out) {
-    auto it = pm.find(key);
-    if (it == pm.end()) return fail(1, "state dict is missing key '" + key + "'");
-    if (it->second.shape != shape) return fail(1, "state dict key '" + key + "' has an unexpected shape");
-    *out = it->second.data;
+static void bn_keys(std::vector<std::string>& out, const std::string& p) {
+    for (const char* leaf : {".weight", ".bias", ".running_mean", ".running_var"}) out.push_back(p + leaf);
+}
+
+// fold the stem's output exponent into the device copies of its epilogue constants (ConvLayer::set_exps for the stem)
+static Status stem_set_exp(Engine::ResNet& R, int dt, int out_exp, hipStream_t s) {
+    if (R.stem_scale.ptr && out_exp == R.stem_out_exp) return Status();
+    if (R.stem_scale.ptr) CV_HIP(hipStreamSynchronize(s));
+    std::vector<float> sc(64), sh(64);
+    const int in_exp = dt == kF32 ? 0 : kInputExp;
+    for (int i = 0; i < 64; ++i) { sc[i] = std::ldexp(R.h_stem_scale[i], in_exp - out_exp); sh[i] = std::ldexp(R.h_stem_shift[i], -out_exp); }
+    CV_TRY(R.stem_scale.upload(sc.data(), 64 * sizeof(float)));
+    CV_TRY(R.stem_shift.upload(sh.data(), 64 * sizeof(float)));
+    R.stem_out_exp = out_exp;
     return Status();
 }
 
@@ -30,23 +44,39 @@ Status resnet_load(Engine& e, const ParamMap& pm) {
     auto m = std::make_unique<Engine::ResNet>();
     Engine::ResNet& R = *m;
     const int dt = e.dt;
+    CV_TRY(e.guard_init());
     // the f32 engine materialises the 32x32x64 stem output (34 x 34 x 64 x 4 B per square with its border): keep that
     // tensor under the 4 GiB the 32-bit DMA offsets address
-    R.cap = e.resnet_chunk;
+    R.max_cap = e.resnet_chunk;
     if (dt == kF32)
-        while ((uint64_t)R.cap * 34 * 34 * 64 * 4 >= (1ull << 32) && R.cap > 1) R.cap /= 2;
-    const int S = R.cap;
+        while ((uint64_t)R.max_cap * 34 * 34 * 64 * 4 >= (1ull << 32) && R.max_cap > 1) R.max_cap /= 2;
+    const int S = R.max_cap;
+    std::vector<std::string> known;
 
     {   // stem: conv1 (64,1,7,7) + bn1
-        const float *w, *g, *b, *mu, *var;
-        CV_TRY(need2(pm, "conv1.weight", {64, 1, 7, 7}, &w));
-        CV_TRY(need2(pm, "bn1.weight", {64}, &g));
-        CV_TRY(need2(pm, "bn1.bias", {64}, &b));
-        CV_TRY(need2(pm, "bn1.running_mean", {64}, &mu));
-        CV_TRY(need2(pm, "bn1.running_var", {64}, &var));
-        std::vector<float> sc(64), sh(64);
-        for (int i = 0; i < 64; ++i) { sc[i] = g[i] / std::sqrt(var[i] + 1e-5f); sh[i] = b[i] - mu[i] * sc[i]; }
-        CV_TRY(R.stem_w.upload(w, 64 * 49 * sizeof(float)));
+        const float* w;
+        CV_TRY(need_public(pm, "conv1.weight", {64, 1, 7, 7}, &w));
+        std::vector<float> sc, sh;
+        CV_TRY(bn_fold_public(pm, "bn1", 64, sc, sh));
+        known.push_back("conv1.weight"); bn_keys(known, "bn1");
+        std::vector<float> wn(w, w + 64 * 49);
+        R.h_stem_scale.assign(64, 0.f); R.h_stem_shift.assign(64, 0.f);
+        for (int ch = 0; ch < 64; ++ch) {
+            int ex = 0;
+            float mx = 0.f;
+            for (int k = 0; k < 49; ++k) {
+                if (!std::isfinite(w[ch * 49 + k])) return fail(1, "conv1: non-finite weight in the state dict");
+                mx = std::max(mx, std::fabs(w[ch * 49 + k]));
+            }
+            if (!std::isfinite(sc[ch]) || !std::isfinite(sh[ch])) return fail(1, "bn1: non-finite BatchNorm scale/shift (running_var + eps <= 0?)");
+            if (dt != kF32 && mx > 0.f) {                   // filter normalisation, as ConvLayer rows (engine.cpp: finish_layer)
+                (void)std::frexp(mx, &ex);
+                for (int k = 0; k < 49; ++k) wn[ch * 49 + k] = std::ldexp(wn[ch * 49 + k], -ex);
+            }
+            R.h_stem_scale[ch] = std::ldexp(sc[ch], ex);
+            R.h_stem_shift[ch] = sh[ch];
+        }
+        CV_TRY(R.stem_w.upload(wn.data(), 64 * 49 * sizeof(float)));
         if (dt != kF32) {
             // MFMA A-operand image of the 64x(7x7) filter bank: k-slot (ks, q, j) = filter tap (ky = 4*ks + q, kx = j),
             // MFMA row i of fragment f = channel 16*(i/4) + 4*f + i%4 (the conv epilogue's lane-contiguous order)
@@ -58,20 +88,19 @@ Status resnet_load(Engine& e, const ParamMap& pm) {
                             const int i = lane & 15, q = lane >> 4, ky = ks * 4 + q;
                             const int ch = 16 * (i / 4) + 4 * f + (i % 4);
                             for (int j = 0; j < 8; ++j) {
-                                const float v = (ky < 7 && j < 7) ? w[ch * 49 + ky * 7 + j] : 0.f;
+                                const float v = (ky < 7 && j < 7) ? wn[ch * 49 + ky * 7 + j] : 0.f;
                                 const _Float16 hi = (_Float16)v;
                                 pk[((((size_t)hl * 2 + ks) * 4 + f) * 64 + lane) * 8 + j] = hl ? (_Float16)(v - (float)hi) : hi;
                             }
                         }
             CV_TRY(R.stem_wpk.upload(pk.data(), pk.size() * sizeof(_Float16)));
         }
-        CV_TRY(R.stem_scale.upload(sc.data(), 64 * sizeof(float)));
-        CV_TRY(R.stem_shift.upload(sh.data(), 64 * sizeof(float)));
+        R.stem_id = e.register_layer("conv1");
+        CV_TRY(stem_set_exp(R, dt, 0, nullptr));
     }
-    if (dt == kF32) CV_TRY(R.stem_out.create(S, 32, 32, 64, dt));   // other engines fuse stem + pool
-    CV_TRY(R.pool_out.create(S, 16, 16, 64, dt));
-    if (dt == kF32) R.taps["act1"] = R.stem_out.ref(S);
-    R.taps["maxpool"] = R.pool_out.ref(S);
+    if (dt == kF32) { R.stem_out.shape(32, 32, 64, dt); R.acts.push_back(&R.stem_out); }   // other engines fuse stem + pool
+    R.pool_out.shape(16, 16, 64, dt);
+    R.acts.push_back(&R.pool_out);
 
     const int widths[4] = {64, 128, 256, 512};
     const int res[4] = {16, 8, 4, 2};
@@ -84,34 +113,100 @@ Status resnet_load(Engine& e, const ParamMap& pm) {
             const int w = widths[l];
             const int stride = (bi == 0 && l > 0) ? 2 : 1;
             const int64_t px = (int64_t)S * res[l] * res[l];
-            CV_TRY(build_conv_bn_public(B.conv1, dt, pm, p + ".conv1", p + ".bn1", w, cin, 3, stride, cin, px, res[l]));
-            CV_TRY(build_conv_bn_public(B.conv2, dt, pm, p + ".conv2", p + ".bn2", w, w, 3, 1, w, px, res[l]));
+            known.push_back(p + ".conv1.weight"); bn_keys(known, p + ".bn1");
+            known.push_back(p + ".conv2.weight"); bn_keys(known, p + ".bn2");
+            CV_TRY(build_conv_bn_public(e, B.conv1, pm, p + ".conv1", p + ".bn1", w, cin, 3, stride, cin, px, res[l]));
+            CV_TRY(build_conv_bn_public(e, B.conv2, pm, p + ".conv2", p + ".bn2", w, w, 3, 1, w, px, res[l]));
             B.has_down = (stride != 1 || cin != w);
             if (B.has_down) {
-                CV_TRY(build_conv_bn_public(B.down, dt, pm, p + ".downsample.0", p + ".downsample.1", w, cin, 1, stride, cin, px, res[l]));
-                CV_TRY(B.sc.create(S, res[l], res[l], w, dt));
+                known.push_back(p + ".downsample.0.weight"); bn_keys(known, p + ".downsample.1");
+                CV_TRY(build_conv_bn_public(e, B.down, pm, p + ".downsample.0", p + ".downsample.1", w, cin, 1, stride, cin, px, res[l]));
+                B.sc.shape(res[l], res[l], w, dt);
+                R.acts.push_back(&B.sc);
                 macs += (int64_t)cin * w * res[l] * res[l];
             }
-            CV_TRY(B.mid.create(S, res[l], res[l], w, dt));
-            CV_TRY(B.out.create(S, res[l], res[l], w, dt));
+            B.mid.shape(res[l], res[l], w, dt);
+            B.out.shape(res[l], res[l], w, dt);
+            R.acts.push_back(&B.mid); R.acts.push_back(&B.out);
             macs += ((int64_t)cin * 9 * w + (int64_t)w * 9 * w) * res[l] * res[l];
-            R.taps[p + ".act1"] = B.mid.ref(S);
-            R.taps[p] = B.out.ref(S);
-            if (B.has_down) R.taps[p + ".downsample"] = B.sc.ref(S);
             cin = w;
         }
-        R.taps["layer" + std::to_string(l + 1)] = R.blocks[l * 2 + 1].out.ref(S);
     }
     {
         const float *w, *b;
-        CV_TRY(need2(pm, "fc.weight", {13, 512}, &w));
-        CV_TRY(need2(pm, "fc.bias", {13}, &b));
+        CV_TRY(need_public(pm, "fc.weight", {13, 512}, &w));
+        CV_TRY(need_public(pm, "fc.bias", {13}, &b));
+        known.push_back("fc.weight"); known.push_back("fc.bias");
+        for (int i = 0; i < 13 * 512; ++i)
+            if (!std::isfinite(w[i])) return fail(1, "fc: non-finite weight in the state dict");
+        for (int i = 0; i < 13; ++i)
+            if (!std::isfinite(b[i])) return fail(1, "fc: non-finite bias in the state dict");
         CV_TRY(R.fc_w.upload(w, 13 * 512 * sizeof(float)));
         CV_TRY(R.fc_b.upload(b, 13 * sizeof(float)));
+        R.head_id = e.register_layer("fc");
         macs += 13 * 512;
     }
+    CV_TRY(reject_unknown_keys_public(pm, known, "resnet18(in_chans=1, num_classes=13)"));
     R.macs = macs;
     e.resnet = std::move(m);
+
+    // range calibration on 128 squares: noise, flat grey levels, gradients and checkers (what board crops look like)
+    Status st = resnet_reserve(e, 128);
+    if (st.ok() && dt != kF32 && calibration_enabled()) {
+        std::vector<float> host((size_t)128 * 4096);
+        uint32_t rs = 0x2545F491u;
+        auto rnd = [&]() { rs = rs * 1664525u + 1013904223u; return (rs >> 24) & 0xffu; };
+        for (int q = 0; q < 128; ++q)
+            for (int y = 0; y < 64; ++y)
+                for (int x = 0; x < 64; ++x) {
+                    float v;
+                    if (q < 48) v = (float)rnd();
+                    else if (q < 80) v = (float)((q - 48) * 8 + 3);                                   // flat levels 3..251
+                    else if (q < 104) v = (float)(((x * (q - 79)) + y * 3) & 255);                      // ramps
+                    else v = (((x >> (q & 3)) + (y >> ((q >> 2) & 3))) & 1) ? 235.f : (float)(20 + (q - 104) * 6);   // checkers
+                    host[((size_t)q * 64 + y) * 64 + x] = v / 255.f;
+                }
+        DeviceBuffer xin, lout;
+        st = xin.upload(host.data(), host.size() * sizeof(float));
+        if (st.ok()) st = lout.alloc((size_t)128 * 13 * sizeof(float), false);
+        if (st.ok())
+            st = e.calibrate(e.resnet->acts, [&]() -> Status {                 // the statistics accumulate over the chunks
+                for (int off = 0; off < 128; off += e.resnet->cap) {
+                    const int c = std::min(e.resnet->cap, 128 - off);
+                    CV_TRY(resnet_chunk(e, (const float*)xin.ptr + (size_t)off * 4096, false, c, (float*)lout.ptr + (size_t)off * 13, false, nullptr));
+                }
+                return Status();
+            }, nullptr, "ResNet-18");
+        if (st.ok()) {
+            hipError_t he = hipDeviceSynchronize();
+            if (he != hipSuccess) st = hip_fail(he, "ResNet-18 calibration");
+        }
+    }
+    if (!st.ok()) e.resnet.reset();
+    return st;
+}
+
+static Status resnet_reserve(Engine& e, int n) {
+    Engine::ResNet& R = *e.resnet;
+    const int want = std::min(R.max_cap, std::max(n, 1));
+    if (want <= R.cap) return Status();
+    CV_HIP(hipDeviceSynchronize());
+    for (Activation* a : R.acts) CV_TRY(a->reserve(want));
+    R.cap = want;
+    const int S = want;
+    R.taps.clear();
+    if (e.dt == kF32) R.taps["act1"] = R.stem_out.ref(S);
+    R.taps["maxpool"] = R.pool_out.ref(S);
+    for (int l = 0; l < 4; ++l) {
+        for (int bi = 0; bi < 2; ++bi) {
+            Engine::ResNet::Block& B = R.blocks[l * 2 + bi];
+            const std::string p = "layer" + std::to_string(l + 1) + "." + std::to_string(bi);
+            R.taps[p + ".act1"] = B.mid.ref(S);
+            R.taps[p] = B.out.ref(S);
+            if (B.has_down) R.taps[p + ".downsample"] = B.sc.ref(S);
+        }
+        R.taps["layer" + std::to_string(l + 1)] = R.blocks[l * 2 + 1].out.ref(S);
+    }
     return Status();
 }
 
@@ -122,6 +217,7 @@ Status resnet_activation(Engine& e, const std::string& name, TensorRef* out) {
     auto it = e.resnet->taps.find(name);
     if (it == e.resnet->taps.end()) return fail(1, "unknown ResNet activation '" + name + "'");
     *out = it->second;
+    out->exp = static_cast<Activation*>(out->owner)->exp;
     out->N = e.resnet->last_n;
     return Status();
 }
@@ -130,22 +226,26 @@ static Status resnet_chunk(Engine& e, const void* x, bool x_u8, int n, float* ou
     Engine::ResNet& R = *e.resnet;
     R.last_n = n;
     const int dt = e.dt;
-    auto begin = [&](const char* name, double macs) { if (e.profiling) e.prof_begin(name, false, macs, s); };
+    const double esz = dtype_size(dt), in_b = x_u8 ? 1.0 : 4.0;
+    auto begin = [&](const char* name, double macs, double bytes) { if (e.profiling) e.prof_begin(name, false, macs, s, bytes); };
     auto end = [&](const char* name, hipError_t err) -> Status {
         if (e.profiling) e.prof_end(s);
         if (err != hipSuccess) return hip_fail(err, name);
         return Status();
     };
     if (dt == kF32) {
-        begin("stem7x7", 49.0 * 64 * 1024 * n);
+        begin("stem7x7", 49.0 * 64 * 1024 * n, (double)n * (4096 * in_b + 1024 * 64 * esz));
         CV_TRY(end("stem7x7", stem7x7(dt, x, x_u8, n, (const float*)R.stem_w.ptr, (const float*)R.stem_scale.ptr,
                                        (const float*)R.stem_shift.ptr, R.stem_out.ref(n), s)));
-        begin("maxpool3x3s2", 0);
+        begin("maxpool3x3s2", 0, (double)n * (1024 + 256) * 64 * esz);
         CV_TRY(end("maxpool3x3s2", maxpool3x3s2(dt, R.stem_out.ref(n), R.pool_out.ref(n), s)));
     } else {
-        begin("stem7x7+maxpool (mfma)", 49.0 * 64 * 1024 * n);
+        CV_TRY(stem_set_exp(R, dt, R.pool_out.exp, s));
+        begin("stem7x7+maxpool (mfma)", 49.0 * 64 * 1024 * n, (double)n * (4096 * in_b + 256 * 64 * esz));
         CV_TRY(end("stem_pool_mfma", stem_pool_mfma(dt, x, x_u8, n, R.stem_wpk.ptr, (const float*)R.stem_scale.ptr,
-                                                     (const float*)R.stem_shift.ptr, R.pool_out.ref(n), s)));
+                                                     (const float*)R.stem_shift.ptr, kInputExp, R.pool_out.ref(n),
+                                                     e.guard_ptr(), R.stem_id, s)));
+        if (e.calibrating) CV_TRY(e.measure(R.pool_out.ref(n), s));
     }
     TensorRef cur = R.pool_out.ref(n);
     for (int i = 0; i < 8; ++i) {
@@ -159,15 +259,17 @@ static Status resnet_chunk(Engine& e, const void* x, bool x_u8, int n, float* ou
         CV_TRY(e.run_conv(B.conv2, B.mid.ref(n), B.out.ref(n), &shortcut, true, s));
         cur = B.out.ref(n);
     }
-    begin("head_avgpool_fc", 13.0 * 512 * n);
+    begin("head_avgpool_fc", 13.0 * 512 * n, (double)n * (cur.H * cur.W * 512 * esz + 13 * 4));
     CV_TRY(end("head_avgpool_fc", head_avgpool_fc(dt, cur, (const float*)R.fc_w.ptr, (const float*)R.fc_b.ptr, out,
-                                                   softmax ? 1 : 0, s)));
+                                                   softmax ? 1 : 0, e.guard_ptr(), R.head_id, s)));
     return Status();
 }
 
 Status resnet_forward(Engine& e, const void* x, bool x_u8, int n, float* out, bool softmax, hipStream_t s) {
     if (!e.resnet) return fail(3, "ResNet-18 weights not loaded (call cv_load_resnet18 first)");
     if (n < 0 || (n > 0 && (!x || !out))) return fail(1, "cv_resnet18_forward: null tensor or negative batch");
+    if (n == 0) return Status();
+    CV_TRY(resnet_reserve(e, n));
     const size_t in_stride = (size_t)64 * 64 * (x_u8 ? 1 : 4);
     for (int off = 0; off < n; off += e.resnet->cap) {
         const int c = std::min(e.resnet->cap, n - off);

@@ -29,6 +29,9 @@ static Status need(const ParamMap& pm, const std::string& key, std::vector<int64
     *out = it->second.data;
     return Status();
 }
+Status need_public(const ParamMap& pm, const std::string& key, std::vector<int64_t> shape, const float** out) {
+    return need(pm, key, std::move(shape), out);
+}
 
 // BatchNorm2d(eval): y = (x - mean) / sqrt(var + eps) * gamma + beta  ->  scale, shift
 static Status bn_fold(const ParamMap& pm, const std::string& prefix, int c, std::vector<float>& scale,
@@ -46,51 +49,107 @@ static Status bn_fold(const ParamMap& pm, const std::string& prefix, int c, std:
     }
     return Status();
 }
+Status bn_fold_public(const ParamMap& pm, const std::string& prefix, int c, std::vector<float>& scale, std::vector<float>& shift) {
+    return bn_fold(pm, prefix, c, scale, shift);
+}
 
-static Status build_conv_bn(ConvLayer& L, int dt, const ParamMap& pm, const std::string& conv_key,
+static Status build_conv_bn(Engine& e, ConvLayer& L, const ParamMap& pm, const std::string& conv_key,
                             const std::string& bn_key, int cout, int cin, int k, int stride, int cinPad,
                             int64_t pixels, int out_hw = 0) {
     const float* w;
     CV_TRY(need(pm, conv_key + ".weight", {cout, cin, k, k}, &w));
     std::vector<float> sc, sh;
     CV_TRY(bn_fold(pm, bn_key, cout, sc, sh));
-    return L.build_conv(conv_key, dt, w, cout, cin, k, stride, sc.data(), sh.data(), cinPad, pixels, out_hw);
+    CV_TRY(L.build_conv(conv_key, e.dt, w, cout, cin, k, stride, sc.data(), sh.data(), cinPad, pixels, out_hw));
+    L.layer_id = e.register_layer(conv_key);
+    return Status();
 }
-Status build_conv_bn_public(ConvLayer& L, int dt, const ParamMap& pm, const std::string& conv_key,
+Status build_conv_bn_public(Engine& e, ConvLayer& L, const ParamMap& pm, const std::string& conv_key,
                             const std::string& bn_key, int cout, int cin, int k, int stride, int cinPad,
                             int64_t pixels, int out_hw) {
-    return build_conv_bn(L, dt, pm, conv_key, bn_key, cout, cin, k, stride, cinPad, pixels, out_hw);
+    return build_conv_bn(e, L, pm, conv_key, bn_key, cout, cin, k, stride, cinPad, pixels, out_hw);
+}
+
+// every key the architecture defines, so that a checkpoint of a DIFFERENT architecture (extra / renamed keys: the
+// reference's UNet is an un-vendored submodule on an `experimental` branch) is rejected instead of half-loaded
+static Status reject_unknown_keys(const ParamMap& pm, const std::vector<std::string>& known, const char* model) {
+    for (const auto& kv : pm) {
+        bool ok = false;
+        for (const auto& k : known)
+            if (kv.first == k) { ok = true; break; }
+        if (!ok) return fail(1, std::string("state dict has key '") + kv.first + "' that " + model + " does not define");
+    }
+    return Status();
+}
+Status reject_unknown_keys_public(const ParamMap& pm, const std::vector<std::string>& known, const char* model) {
+    return reject_unknown_keys(pm, known, model);
+}
+static void bn_keys(std::vector<std::string>& out, const std::string& p) {
+    for (const char* leaf : {".weight", ".bias", ".running_mean", ".running_var"}) out.push_back(p + leaf);
+}
+static void double_conv_keys(std::vector<std::string>& out, const std::string& p) {
+    out.push_back(p + "0.weight"); bn_keys(out, p + "1");
+    out.push_back(p + "3.weight"); bn_keys(out, p + "4");
+}
+
+static Status unet_reserve(Engine& e, int n);
+static Status unet_chunk(Engine& e, const void* x, bool x_u8, int n, float* logits, uint8_t* mask, float thr, hipStream_t s);
+
+// Two deterministic calibration images, NCHW f32 in [0,1]: uniform noise, and a structured frame (dark noise, a bright
+// checkered quadrilateral, saturated white and black blocks) -- the extremes of what a photo can put into the network.
+static void calibration_images(std::vector<float>& x) {
+    x.assign((size_t)2 * 3 * 65536, 0.f);
+    uint32_t st = 0x9E3779B9u;
+    auto rnd = [&]() { st = st * 1664525u + 1013904223u; return (st >> 24) & 0xffu; };
+    for (size_t i = 0; i < (size_t)3 * 65536; ++i) x[i] = (float)rnd() / 255.f;
+    float* im = x.data() + (size_t)3 * 65536;
+    for (int y = 0; y < 256; ++y)
+        for (int xx = 0; xx < 256; ++xx) {
+            const bool board = xx > 40 + y / 16 && xx < 215 - y / 20 && y > 35 && y < 220;
+            for (int c = 0; c < 3; ++c) {
+                float v = (float)(rnd() % 40) / 255.f;
+                if (board) v = ((((xx - 40) / 22 + (y - 35) / 23) & 1) ? 230.f : 165.f) / 255.f;
+                if (xx < 32 && y < 32) v = 1.f;
+                if (xx >= 224 && y >= 224) v = 0.f;
+                im[((size_t)c * 256 + y) * 256 + xx] = v;
+            }
+        }
 }
 
 Status unet_load(Engine& e, const ParamMap& pm) {
     auto m = std::make_unique<Engine::UNet>();
     Engine::UNet& U = *m;
     const int dt = e.dt;
+    CV_TRY(e.guard_init());
     U.bilinear = pm.find("up1.up.weight") == pm.end();
     {   // CV_FUSE_HEAD=0 keeps OutConv a separate kernel (then the up4 output tensor can be read back)
         const char* v = std::getenv("CV_FUSE_HEAD");
         U.fuse_head = !(v && v[0] == '0');
     }
-    U.cap = e.unet_chunk;
-    const int S = U.cap;
+    U.max_cap = e.unet_chunk;
+    const int S = U.max_cap;                          // tile choices are made for full chunks
     const int f = U.bilinear ? 2 : 1;
     U.c5 = 1024 / f;
     const int enc_c[5] = {64, 128, 256, 512, U.c5};
     const int res[5] = {256, 128, 64, 32, 16};
     auto px = [&](int level) { return (int64_t)S * res[level] * res[level]; };
 
+    std::vector<std::string> known;
+    double_conv_keys(known, "inc.double_conv.");
     // encoder
-    CV_TRY(build_conv_bn(U.inc0, dt, pm, "inc.double_conv.0", "inc.double_conv.1", 64, 3, 3, 1, 8, px(0), 256));
-    CV_TRY(build_conv_bn(U.inc1, dt, pm, "inc.double_conv.3", "inc.double_conv.4", 64, 64, 3, 1, 64, px(0), 256));
+    CV_TRY(build_conv_bn(e, U.inc0, pm, "inc.double_conv.0", "inc.double_conv.1", 64, 3, 3, 1, 8, px(0), 256));
+    CV_TRY(build_conv_bn(e, U.inc1, pm, "inc.double_conv.3", "inc.double_conv.4", 64, 64, 3, 1, 64, px(0), 256));
     for (int i = 0; i < 4; ++i) {
         const std::string p = "down" + std::to_string(i + 1) + ".maxpool_conv.1.double_conv.";
-        CV_TRY(build_conv_bn(U.d[i][0], dt, pm, p + "0", p + "1", enc_c[i + 1], enc_c[i], 3, 1, enc_c[i], px(i + 1), res[i + 1]));
-        CV_TRY(build_conv_bn(U.d[i][1], dt, pm, p + "3", p + "4", enc_c[i + 1], enc_c[i + 1], 3, 1, enc_c[i + 1], px(i + 1), res[i + 1]));
+        double_conv_keys(known, p);
+        CV_TRY(build_conv_bn(e, U.d[i][0], pm, p + "0", p + "1", enc_c[i + 1], enc_c[i], 3, 1, enc_c[i], px(i + 1), res[i + 1]));
+        CV_TRY(build_conv_bn(e, U.d[i][1], pm, p + "3", p + "4", enc_c[i + 1], enc_c[i + 1], 3, 1, enc_c[i + 1], px(i + 1), res[i + 1]));
     }
     // decoder: up_i consumes the deeper tensor (channels deep_c) and skip level (3 - i)
     //   transposed: up: deep_c -> deep_c/2 ; conv: cat(skip, up) = deep_c -> out_c -> out_c
     //   bilinear  : up keeps deep_c (== skip channels) ; conv: 2*deep_c -> mid = deep_c -> out_c
     int deep_c = U.c5;
+    int up_c[4];                                      // channels of the up-sampled half of cat[lvl], by decoder stage
     for (int i = 0; i < 4; ++i) {
         const int lvl = 3 - i;                       // skip level, output resolution res[lvl]
         const int skip_c = enc_c[lvl];
@@ -100,46 +159,114 @@ Status unet_load(Engine& e, const ParamMap& pm) {
             const float *w, *b;
             CV_TRY(need(pm, p + ".up.weight", {deep_c, deep_c / 2, 2, 2}, &w));
             CV_TRY(need(pm, p + ".up.bias", {deep_c / 2}, &b));
+            known.push_back(p + ".up.weight"); known.push_back(p + ".up.bias");
             CV_TRY(U.upT[i].build_convT(p + ".up", dt, w, deep_c, deep_c / 2, b, px(lvl + 1)));
+            U.upT[i].layer_id = e.register_layer(p + ".up");
             cat_c = skip_c + deep_c / 2;
             out_c = skip_c;
             mid_c = out_c;
         } else {
+            U.up_id[i] = e.register_layer(p + ".up");
             cat_c = skip_c + deep_c;
             mid_c = cat_c / 2;
             out_c = (i == 3) ? 64 : skip_c / 2;
         }
+        up_c[i] = cat_c - skip_c;
         const std::string c = p + ".conv.double_conv.";
-        CV_TRY(build_conv_bn(U.u[i][0], dt, pm, c + "0", c + "1", mid_c, cat_c, 3, 1, cat_c, px(lvl), res[lvl]));
-        CV_TRY(build_conv_bn(U.u[i][1], dt, pm, c + "3", c + "4", out_c, mid_c, 3, 1, mid_c, px(lvl), res[lvl]));
+        double_conv_keys(known, c);
+        CV_TRY(build_conv_bn(e, U.u[i][0], pm, c + "0", c + "1", mid_c, cat_c, 3, 1, cat_c, px(lvl), res[lvl]));
+        CV_TRY(build_conv_bn(e, U.u[i][1], pm, c + "3", c + "4", out_c, mid_c, 3, 1, mid_c, px(lvl), res[lvl]));
         deep_c = out_c;
     }
     {
         const float *w, *b;
         CV_TRY(need(pm, "outc.conv.weight", {1, 64, 1, 1}, &w));
         CV_TRY(need(pm, "outc.conv.bias", {1}, &b));
+        known.push_back("outc.conv.weight"); known.push_back("outc.conv.bias");
+        for (int i = 0; i < 64; ++i)
+            if (!std::isfinite(w[i])) return fail(1, "outc.conv: non-finite weight in the state dict");
+        if (!std::isfinite(b[0])) return fail(1, "outc.conv: non-finite bias in the state dict");
         CV_TRY(U.outc_w.upload(w, 64 * sizeof(float)));
         CV_TRY(U.outc_b.upload(b, sizeof(float)));
+        U.outc_id = e.register_layer("outc.conv");
     }
+    CV_TRY(reject_unknown_keys(pm, known, U.bilinear ? "UNet(3,1,bilinear=True)" : "UNet(3,1)"));
 
-    // activations (dedicated buffers: borders are zeroed once and stay zero)
-    CV_TRY(U.in8.create(S, 256, 256, 8, dt));
-    CV_TRY(U.a_inc0.create(S, 256, 256, 64, dt));
+    // activation shapes (dedicated buffers: borders are zeroed once and stay zero); memory comes with unet_reserve
+    U.in8.shape(256, 256, 8, dt);
+    U.in8.fixed_exp = true;
+    U.in8.exp = dt == kF32 ? 0 : kInputExp;
+    U.a_inc0.shape(256, 256, 64, dt);
+    U.acts = {&U.in8, &U.a_inc0};
     for (int lvl = 0; lvl < 4; ++lvl) {
         const int skip_c = enc_c[lvl];
-        const int up_c = U.u[3 - lvl][0].cin - skip_c;
-        CV_TRY(U.cat[lvl].create(S, res[lvl], res[lvl], skip_c + up_c, dt));
-        CV_TRY(U.pool[lvl].create(S, res[lvl + 1], res[lvl + 1], skip_c, dt));
-        if (lvl < 3) CV_TRY(U.dmid[lvl].create(S, res[lvl + 1], res[lvl + 1], enc_c[lvl + 1], dt));
+        U.cat[lvl].shape(res[lvl], res[lvl], skip_c + up_c[3 - lvl], dt);
+        U.pool[lvl].shape(res[lvl + 1], res[lvl + 1], skip_c, dt);
+        U.pool[lvl].tie = &U.cat[lvl];               // max-pool of the skip half: same scale
+        U.dmid[lvl].shape(res[lvl + 1], res[lvl + 1], enc_c[lvl + 1], dt);
+        U.acts.push_back(&U.cat[lvl]); U.acts.push_back(&U.pool[lvl]); U.acts.push_back(&U.dmid[lvl]);
     }
-    CV_TRY(U.dmid[3].create(S, 16, 16, U.c5, dt));
-    CV_TRY(U.bott.create(S, 16, 16, U.c5, dt));
+    U.bott.shape(16, 16, U.c5, dt);
+    U.acts.push_back(&U.bott);
     for (int i = 0; i < 4; ++i) {
         const int lvl = 3 - i;
-        CV_TRY(U.umid[i].create(S, res[lvl], res[lvl], U.u[i][0].cout, dt));
-        CV_TRY(U.uout[i].create(S, res[lvl], res[lvl], U.u[i][1].cout, dt));
+        U.umid[i].shape(res[lvl], res[lvl], U.u[i][0].cout, dt);
+        U.uout[i].shape(res[lvl], res[lvl], U.u[i][1].cout, dt);
+        U.acts.push_back(&U.umid[i]);
+        if (!(i == 3 && U.fuse_head)) U.acts.push_back(&U.uout[i]);   // with the fused head the up4 output never reaches memory
     }
 
+    // algorithmic multiply-accumulates per image (conv / conv-transpose / outc), true channel counts
+    int64_t macs = 0;
+    auto add = [&](const ConvLayer& L, int64_t out_pixels) { macs += L.macs_per_out_pixel() * out_pixels; };
+    add(U.inc0, 65536); add(U.inc1, 65536);
+    for (int i = 0; i < 4; ++i) { add(U.d[i][0], (int64_t)res[i + 1] * res[i + 1]); add(U.d[i][1], (int64_t)res[i + 1] * res[i + 1]); }
+    for (int i = 0; i < 4; ++i) {
+        const int lvl = 3 - i;
+        if (!U.bilinear) add(U.upT[i], (int64_t)res[lvl + 1] * res[lvl + 1]);
+        add(U.u[i][0], (int64_t)res[lvl] * res[lvl]); add(U.u[i][1], (int64_t)res[lvl] * res[lvl]);
+    }
+    macs += 64LL * 65536;
+    U.macs = macs;
+
+    e.unet = std::move(m);
+    // range calibration of the f16-based engines on two images (Activation, Engine::calibrate)
+    Status st = unet_reserve(e, 2);
+    if (st.ok() && dt != kF32 && calibration_enabled()) {
+        std::vector<float> host;
+        calibration_images(host);
+        DeviceBuffer xin, lout;
+        st = xin.upload(host.data(), host.size() * sizeof(float));
+        if (st.ok()) st = lout.alloc((size_t)2 * 65536 * sizeof(float), false);
+        if (st.ok())
+            st = e.calibrate(e.unet->acts, [&]() -> Status {                   // the statistics accumulate over the chunks
+                for (int off = 0; off < 2; off += e.unet->cap) {
+                    const int c = std::min(e.unet->cap, 2 - off);
+                    CV_TRY(unet_chunk(e, (const float*)xin.ptr + (size_t)off * 3 * 65536, false, c, (float*)lout.ptr + (size_t)off * 65536,
+                                      nullptr, 0.5f, nullptr));
+                }
+                return Status();
+            }, nullptr, "UNet");
+        if (st.ok()) {
+            hipError_t he = hipDeviceSynchronize();
+            if (he != hipSuccess) st = hip_fail(he, "UNet calibration");
+        }
+    }
+    if (!st.ok()) e.unet.reset();
+    return st;
+}
+
+// (re)allocate the workspace for min(n, chunk) images; exponents survive, module taps are rebuilt
+static Status unet_reserve(Engine& e, int n) {
+    Engine::UNet& U = *e.unet;
+    const int want = std::min(U.max_cap, std::max(n, 1));
+    if (want <= U.cap) return Status();
+    CV_HIP(hipDeviceSynchronize());                  // nothing may still read the buffers about to be replaced
+    for (Activation* a : U.acts) CV_TRY(a->reserve(want));
+    U.cap = want;
+    const int S = want;
+    const int enc_c[5] = {64, 128, 256, 512, U.c5};
+    U.taps.clear();
     // module-name taps for cv_get_activation (names follow the reference state-dict prefixes)
     U.taps["input"] = U.in8.ref(S, 0, 8);
     U.taps["inc.double_conv.2"] = U.a_inc0.ref(S);
@@ -158,26 +285,11 @@ Status unet_load(Engine& e, const ParamMap& pm) {
         const std::string p = "up" + std::to_string(i + 1);
         U.taps[p + ".up"] = U.cat[lvl].ref(S, enc_c[lvl], U.cat[lvl].C - enc_c[lvl]);
         U.taps[p + ".conv.double_conv.2"] = U.umid[i].ref(S);
-        if (!(i == 3 && U.fuse_head)) {                  // with the fused head the up4 output never reaches memory
+        if (!(i == 3 && U.fuse_head)) {
             U.taps[p + ".conv.double_conv.5"] = U.uout[i].ref(S);
             U.taps[p] = U.uout[i].ref(S);
         }
     }
-
-    // algorithmic multiply-accumulates per image (conv / conv-transpose / outc), true channel counts
-    int64_t macs = 0;
-    auto add = [&](const ConvLayer& L, int64_t out_pixels) { macs += L.macs_per_out_pixel() * out_pixels; };
-    add(U.inc0, 65536); add(U.inc1, 65536);
-    for (int i = 0; i < 4; ++i) { add(U.d[i][0], (int64_t)res[i + 1] * res[i + 1]); add(U.d[i][1], (int64_t)res[i + 1] * res[i + 1]); }
-    for (int i = 0; i < 4; ++i) {
-        const int lvl = 3 - i;
-        if (!U.bilinear) add(U.upT[i], (int64_t)res[lvl + 1] * res[lvl + 1]);
-        add(U.u[i][0], (int64_t)res[lvl] * res[lvl]); add(U.u[i][1], (int64_t)res[lvl] * res[lvl]);
-    }
-    macs += 64LL * 65536;
-    U.macs = macs;
-
-    e.unet = std::move(m);
     return Status();
 }
 
@@ -188,6 +300,7 @@ Status unet_activation(Engine& e, const std::string& name, TensorRef* out) {
     auto it = e.unet->taps.find(name);
     if (it == e.unet->taps.end()) return fail(1, "unknown UNet activation '" + name + "'");
     *out = it->second;
+    out->exp = static_cast<Activation*>(out->owner)->exp;
     out->N = e.unet->last_n;
     return Status();
 }
@@ -203,11 +316,12 @@ static Status unet_chunk(Engine& e, const void* x, bool x_u8, int n, float* logi
         if (err != hipSuccess) return hip_fail(err, name);
         return Status();
     };
-    auto begin = [&](const char* name) { if (e.profiling) e.prof_begin(name, false, 0, s); };
+    auto begin = [&](const char* name, double bytes = 0) { if (e.profiling) e.prof_begin(name, false, 0, s, bytes); };
+    const double esz = dtype_size(dt);
 
-    begin("pack_input");
+    begin("pack_input", (double)n * 65536 * ((x_u8 ? 3 : 12) + 8 * esz));
     if (x_u8) CV_TRY(timed("pack_hwc3_u8", pack_hwc3_u8(dt, (const uint8_t*)x, U.in8.ref(n, 0, 8), s)));
-    else      CV_TRY(timed("pack_nchw_f32", pack_nchw_f32(dt, (const float*)x, 3, U.in8.ref(n, 0, 8), s)));
+    else      CV_TRY(timed("pack_nchw_f32", pack_nchw_f32(dt, (const float*)x, 3, U.in8.ref(n, 0, 8), e.guard_ptr(), s)));
 
     CV_TRY(e.run_conv(U.inc0, U.in8.ref(n, 0, 8), U.a_inc0.ref(n), nullptr, true, s));
     // every encoder level's second conv also emits its 2x2 max-pool (fused into the epilogue where the halo kernel runs)
@@ -226,8 +340,9 @@ static Status unet_chunk(Engine& e, const void* x, bool x_u8, int n, float* logi
         if (!U.bilinear) {
             CV_TRY(e.run_conv(U.upT[i], deep, up, nullptr, false, s));
         } else {
-            begin("upsample_bilinear2x");
-            CV_TRY(timed("upsample_bilinear2x", upsample_bilinear2x(dt, deep, up, s)));
+            begin("upsample_bilinear2x", (double)n * deep.H * deep.W * deep.C * esz * 5.0);     // 1 read + 4 written elements
+            CV_TRY(timed("upsample_bilinear2x", upsample_bilinear2x(dt, deep, up, e.guard_ptr(), U.up_id[i], s)));
+            if (e.calibrating) CV_TRY(e.measure(up, s));
         }
         CV_TRY(e.run_conv(U.u[i][0], U.cat[lvl].ref(n), U.umid[i].ref(n), nullptr, true, s));
         if (i == 3 && U.fuse_head) {
@@ -240,9 +355,9 @@ static Status unet_chunk(Engine& e, const void* x, bool x_u8, int n, float* logi
         CV_TRY(e.run_conv(U.u[i][1], U.umid[i].ref(n), U.uout[i].ref(n), nullptr, true, s));
         deep = U.uout[i].ref(n);
     }
-    begin("outc_1x1");
+    begin("outc_1x1", (double)n * 65536 * (64 * esz + 4 + (mask ? 1 : 0)));
     CV_TRY(timed("outc_1x1", outc_1x1(dt, deep, (const float*)U.outc_w.ptr, (const float*)U.outc_b.ptr, logits,
-                                      mask, thr, s)));
+                                      mask, thr, e.guard_ptr(), U.outc_id, s)));
     return Status();
 }
 
@@ -250,6 +365,8 @@ Status unet_forward(Engine& e, const void* x, bool x_u8, int batch, float* logit
                     hipStream_t s) {
     if (!e.unet) return fail(3, "UNet weights not loaded (call cv_load_unet first)");
     if (batch < 0 || (batch > 0 && (!x || !logits))) return fail(1, "cv_unet_forward: null tensor or negative batch");
+    if (batch == 0) return Status();
+    CV_TRY(unet_reserve(e, batch));
     const size_t in_stride = (size_t)3 * 256 * 256 * (x_u8 ? 1 : 4);
     for (int off = 0; off < batch; off += e.unet->cap) {
         const int n = std::min(e.unet->cap, batch - off);

@@ -19,7 +19,8 @@
  *
  * Conventions
  *   - every function returns CV_OK (0) or a CV_ERR_* code; cv_last_error() returns a thread-local,
- *     NUL-terminated description of the most recent failure on the calling thread.  Nothing aborts.
+ *     NUL-terminated description of the most recent failure on the calling thread.  Nothing aborts and no C++
+ *     exception crosses the boundary (host allocation failures come back as CV_ERR_NOMEM).
  *   - all tensor arguments of the *_forward* functions are DEVICE pointers on the engine's device;
  *     `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are asynchronous
  *     with respect to the host and ordered on `stream`.
@@ -45,7 +46,8 @@ enum cv_status {
     CV_ERR_INVALID = 1,   /* bad argument / shape / missing or mis-shaped parameter            */
     CV_ERR_HIP = 2,       /* a HIP runtime call failed (message carries hipGetErrorString)     */
     CV_ERR_STATE = 3,     /* model not loaded, wrong device, ...                               */
-    CV_ERR_NOMEM = 4
+    CV_ERR_NOMEM = 4,
+    CV_ERR_NUMERIC = 5    /* a layer produced a non-finite value (f16 range exceeded / NaN input): results invalid */
 };
 
 /* arithmetic type of the convolution path */
@@ -88,8 +90,21 @@ int cv_load_unet(cv_engine_t* eng, const cv_param_t* params, int n_params);
 int cv_load_resnet18(cv_engine_t* eng, const cv_param_t* params, int n_params);
 
 /* Largest number of images (UNet) / squares (ResNet) processed per internal pass; larger batches are
- * looped inside the forward call.  0 = keep default (64 images / 16384 squares).  Must be called before the first forward. */
+ * looped inside the forward call.  0 = keep default (64 images / 16384 squares).  Must be called before cv_load_*.
+ * The activation workspace is elastic: it is sized for the largest batch seen so far (at most one chunk) and grows
+ * on demand, so an engine that only ever serves single images (the reference's Flask endpoint,
+ * app/computeroot/cv_endpoint.py:131-133) stays well under 1 GB while a throughput job grows once to its chunk. */
 int cv_engine_set_chunk(cv_engine_t* eng, int unet_images, int resnet_squares);
+
+/* Bytes of activation workspace currently allocated by the engine (both models). */
+int cv_engine_workspace_bytes(cv_engine_t* eng, size_t* bytes);
+
+/* Numeric guard.  The f16-based precisions hold every tensor as value * 2^-exp with a per-tensor exponent calibrated at
+ * load time (2^11 head-room over the calibration maximum); a layer that nevertheless produces a non-finite value
+ * (range exceeded, NaN/inf in the input) records itself on the device.  This call synchronises `stream`, returns
+ * CV_ERR_NUMERIC with the name of the first such layer in cv_last_error() and re-arms the guard; CV_OK when every
+ * forward since the previous check was clean.  The forward calls themselves stay asynchronous. */
+int cv_engine_numeric_status(cv_engine_t* eng, void* stream);
 
 /* ---- forward (the hot path) ---------------------------------------------------------------------- */
 /* x: (batch,3,256,256) float32 NCHW in [0,1]  ->  logits: (batch,1,256,256) float32.
@@ -120,6 +135,9 @@ int cv_softmax13(cv_engine_t* eng, const float* logits, int n, float* probs, voi
 int cv_get_activation(cv_engine_t* eng, const char* model, const char* name, float* out_host,
                       size_t out_capacity, int64_t dims[4]);
 
+/* Power-of-two exponent the named activation is currently stored with (stored = value * 2^-exponent; 0 for f32). */
+int cv_get_activation_exponent(cv_engine_t* eng, const char* model, const char* name, int* exponent);
+
 /* Algorithmic work of one forward: multiply-accumulates per image (UNet) / per square (ResNet). */
 int cv_model_macs(cv_engine_t* eng, const char* model, int64_t* macs);
 
@@ -133,6 +151,9 @@ int cv_profile_convs(cv_engine_t* eng, const char* model, const void* x, int bat
  * name = producing module, ms = event-timed duration, macs = algorithmic multiply-accumulates. */
 int cv_profile_entry(cv_engine_t* eng, int index, char* name, int name_cap, float* ms, double* macs,
                      int* is_conv);
+
+/* Algorithmic HBM bytes (inputs + outputs + weights, once each, at the engine's storage width) of record `index`. */
+int cv_profile_entry_bytes(cv_engine_t* eng, int index, double* bytes);
 
 /* Stand-alone single-layer entry points used by the parity tests (float32 NCHW device tensors in,
  * float32 NCHW out; packing to the internal layout happens inside, on `stream`).
@@ -172,6 +193,21 @@ int cv_resize_area_u8(cv_engine_t* eng, const uint8_t* src, int n, int h, int w,
  * Synchronises `stream` before returning. */
 int cv_extract_squares_u8(cv_engine_t* eng, const uint8_t* images, int n, int h, int w, const double* inv_host,
                           uint8_t* squares, uint8_t* boards, void* stream);
+
+/* The same with the n x 9 matrices already on the DEVICE (inv_dev): fully asynchronous, nothing is staged or
+ * synchronised -- the form the batched pipeline uses so that consecutive jobs overlap on the stream. */
+int cv_extract_squares_u8_dev(cv_engine_t* eng, const uint8_t* images, int n, int h, int w, const double* inv_dev,
+                              uint8_t* squares, uint8_t* boards, void* stream);
+
+/* (n_boards,64,13) class probabilities (HOST, classifier order a8..h1, or h1..a8 when flip != 0) -> per board the
+ * arg-max labels, the FEN piece placement before and after the reference's only live rule ("no_pawns_on_ends": a pawn on
+ * rank 1 or 8 becomes the most probable non-pawn class).  Replaces, for a whole job, process_position_probabilities /
+ * validate_position / board_fen (core.py:309-355, 441-469).  fen, original_fen: n_boards x 72 chars (NUL-terminated);
+ * labels: n_boards x 64 validated class indices (order of constants.LABEL_NAMES = "BKNPQRbknpqrf"); fixes: capacity
+ * n_boards x 16 records of {board, square index, original class, corrected class}; *n_fixes = records written.
+ * Needs no GPU and no engine. */
+int cv_decode_positions(const float* probs, int n_boards, int flip, char* fen, char* original_fen, int8_t* labels,
+                        int32_t* fixes, int32_t* n_fixes);
 
 /* MFMA lane-map self test: computes D = A(16xK) * B(Kx16) with the kernels' fragment loaders for both
  * precisions and returns the max abs error against a host reference (used by tests; 0 expected). */

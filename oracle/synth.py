@@ -80,3 +80,74 @@ def squares_input(seed: int, n: int, hw: int = 64) -> torch.Tensor:
     t = torch.from_numpy(u8).to(torch.float32).permute(0, 3, 1, 2).contiguous()
     t /= 255.0
     return t
+
+
+# ---- range-stress variants (tests of the f16-based engines outside the benign O(1) regime) -------------------------------
+# Both rewrites are mathematically the identity on the network function, so the stressed oracle must agree with the plain
+# one (checked in tests/test_oracle_structure.py) while its weights, BatchNorm statistics and activations span decades:
+#   rescale_conv_bn: conv weight * a, BN running_mean * a, running_var -> a^2 (var + eps) - eps    (BN output unchanged);
+#                    a in [1e-2, 1e2] puts running_var anywhere in ~[1e-4, 1e4] and weights in ~[1e-4, 1e1]
+#   push_activation: BN gamma, beta * g (post-ReLU activations * g: ReLU is positively homogeneous) and the weights of the
+#                    consuming conv / g -- the tensor in between carries magnitudes of 1e3..1e5 (> 65504 = f16 max).
+_EPS = 1e-5
+
+
+def rescale_conv_bn(sd: dict, conv_key: str, bn_key: str, a: float) -> None:
+    sd[conv_key + ".weight"] = sd[conv_key + ".weight"] * a
+    sd[bn_key + ".running_mean"] = sd[bn_key + ".running_mean"] * a
+    sd[bn_key + ".running_var"] = (sd[bn_key + ".running_var"] + _EPS) * (a * a) - _EPS
+
+
+def push_activation(sd: dict, bn_key: str, consumers: list, g: float) -> None:
+    """consumers: [(conv_key, first input channel, number of input channels)] reading the scaled tensor."""
+    sd[bn_key + ".weight"] = sd[bn_key + ".weight"] * g
+    sd[bn_key + ".bias"] = sd[bn_key + ".bias"] * g
+    for conv_key, c0, n in consumers:
+        w = sd[conv_key + ".weight"].clone()
+        w[:, c0:c0 + n] = w[:, c0:c0 + n] / g
+        sd[conv_key + ".weight"] = w
+
+
+def _log_uniform(seed: int, name: str, lo: float, hi: float) -> float:
+    u = float(prng.uniform(seed, name, (1,), 0.0, 1.0)[0])
+    return float(lo * (hi / lo) ** u)
+
+
+def stress_unet_state_dict(seed: int = 1, bilinear: bool = False, push: float = 3.0e4) -> dict:
+    net = UNet(3, 1, bilinear)
+    sd = synth_state_dict(net, seed)
+    pairs = [("inc.double_conv.0", "inc.double_conv.1"), ("inc.double_conv.3", "inc.double_conv.4")]
+    for i in range(1, 5):
+        p = f"down{i}.maxpool_conv.1.double_conv."
+        pairs += [(p + "0", p + "1"), (p + "3", p + "4")]
+        p = f"up{i}.conv.double_conv."
+        pairs += [(p + "0", p + "1"), (p + "3", p + "4")]
+    for conv, bn in pairs:
+        rescale_conv_bn(sd, conv, bn, _log_uniform(seed + 77, conv, 1e-2, 1e2))
+    # activations of 1e3..1e5 inside three DoubleConvs (first BN -> second conv) at different depths
+    push_activation(sd, "inc.double_conv.1", [("inc.double_conv.3", 0, 64)], push / 10)
+    push_activation(sd, "down3.maxpool_conv.1.double_conv.1", [("down3.maxpool_conv.1.double_conv.3", 0, 512)], push)
+    mid = sd["up2.conv.double_conv.3.weight"].shape[1]
+    push_activation(sd, "up2.conv.double_conv.1", [("up2.conv.double_conv.3", 0, mid)], push / 3)
+    return sd
+
+
+def stress_resnet_state_dict(seed: int = 2, push: float = 3.0e4) -> dict:
+    net = ResNet18()
+    sd = synth_state_dict(net, seed, residual_gamma=0.5)
+    for layer in range(1, 5):
+        for block in range(2):
+            p = f"layer{layer}.{block}"
+            rescale_conv_bn(sd, p + ".conv1", p + ".bn1", _log_uniform(seed + 77, p + ".conv1", 1e-2, 1e2))
+            rescale_conv_bn(sd, p + ".conv2", p + ".bn2", _log_uniform(seed + 77, p + ".conv2", 1e-2, 1e2))
+            if block == 0 and layer > 1:
+                rescale_conv_bn(sd, p + ".downsample.0", p + ".downsample.1", _log_uniform(seed + 77, p + ".ds", 1e-2, 1e2))
+    rescale_conv_bn(sd, "conv1", "bn1", 20.0)
+    push_activation(sd, "layer1.1.bn1", [("layer1.1.conv2", 0, 64)], push / 10)
+    push_activation(sd, "layer3.0.bn1", [("layer3.0.conv2", 0, 256)], push)
+    return sd
+
+
+def load(net: torch.nn.Module, sd: dict) -> torch.nn.Module:
+    net.load_state_dict(sd)
+    return net.eval()

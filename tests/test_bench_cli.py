@@ -1,0 +1,75 @@
+"""bench.py command line: the multi-GPU self-launch and the JSON contract.
+
+CPU: `python bench.py --gpus 2` from a bare shell must neither hang nor exec -- without two devices it exits with a clear
+message before any launcher starts.  GPU (one device): the RCCL code path (process-group init, the weight broadcast, an
+all-reduce, the barriers) runs with world size 1 under CV_FORCE_DIST=1, and the line carries every block the contract names."""
+from __future__ import annotations
+
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_gpus_gt_visible_devices_is_a_clean_exit():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    want = torch.cuda.device_count() + 2
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", str(want)], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 2
+    assert f"--gpus {want}" in out.stderr and "device(s) visible" in out.stderr
+    assert out.stdout.strip() == ""
+
+
+def test_relaunch_command_is_torchrun_on_localhost(monkeypatch):
+    """The child command line (no GPU needed): one rank per GPU, rendezvous on 127.0.0.1, the original arguments passed on."""
+    sys.path.insert(0, str(ROOT))
+    import bench
+
+    seen = {}
+
+    class _Done:
+        returncode = 7
+
+    def fake_run(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return _Done()
+
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 8)
+
+    class _Args:
+        gpus = 4
+
+    rc = bench.relaunch_under_torchrun(_Args(), ["--gpus", "4", "--steps", "3"])
+    assert rc == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+@pytest.mark.gpu
+def test_bench_line_contract_with_rccl_world_of_one():
+    env = dict(os.environ, CV_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29517")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--boards", "64", "--steps", "1", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["rccl_ranks_seen"] == 1 and line["value"] > 0
+    assert line["unit"] == "boards/sec" and line["scaling"] == "weak" and line["vs_baseline"] is None and line["dtype"] == "f16x3"
+    roof = line["roofline"]
+    assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    assert roof["launches_per_step"] == 41 and "traffic" in roof and "traffic_source" in roof
+    hbm = line["roofline_hbm"]
+    assert {"pack_input", "stem7x7+maxpool (mfma)", "head_avgpool_fc"} <= set(hbm)
+    for blk in hbm.values():
+        assert blk["bound"] == "hbm" and blk["peak"] == 8000.0 and 0 < blk["frac"] < 1

@@ -23,10 +23,9 @@ def test_product_and_tools_never_import_the_oracle():
 def test_bench_touches_the_oracle_only_in_the_cpu_baseline_leg():
     src = (ROOT / "bench.py").read_text()
     hits = [m.start() for m in ORACLE_IMPORT.finditer(src)]
-    assert len(hits) == 1
     body_start = src.index("def cpu_baseline(")
     body_end = src.index("\ndef ", body_start + 1)
-    assert body_start < hits[0] < body_end
+    assert hits and all(body_start < h < body_end for h in hits), hits
 
 
 def test_nothing_that_runs_on_the_gpu_box_reads_the_reference_checkout():

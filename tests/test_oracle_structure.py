@@ -80,3 +80,29 @@ def test_resnet18_layer_shapes_match_reference_notebook():
                       "layer2": (1, 128, 8, 8), "layer3": (1, 256, 4, 4), "layer4": (1, 512, 2, 2), "fc": (1, 13)}
     # 141.64 M mult-adds in the notebook (torchinfo rounds); exact count of the restated tree:
     assert resnet_ref.resnet18_macs() == 141_629_952
+
+
+def test_range_stressed_networks_compute_the_same_function():
+    """oracle/synth.py: stress_*_state_dict rescale weights / BatchNorm statistics by up to 1e+-2 per layer and push three
+    activations to 1e3..1e5 while leaving the network function unchanged -- the premise of tests/test_gpu_numerics.py."""
+    from oracle import synth
+
+    x, sq = synth.unet_input(3, 1), synth.squares_input(4, 64)
+    with torch.no_grad():
+        a = synth.make_unet(1)(x)
+        sd = synth.stress_unet_state_dict(1)
+        b = synth.load(unet_ref.UNet(3, 1, False), sd)(x)
+        c = synth.make_resnet(2)(sq)
+        d = synth.load(resnet_ref.ResNet18(), synth.stress_resnet_state_dict(2))(sq)
+    assert float((a - b).abs().max()) <= 2e-4 and float((c - d).abs().max()) <= 5e-5
+    var = torch.cat([v.flatten() for k, v in sd.items() if k.endswith("running_var")])
+    assert float(var.min()) < 1e-3 and float(var.max()) > 1e3                   # BatchNorm scales from ~0.01x to ~100x
+    seen = {}
+    net = synth.load(unet_ref.UNet(3, 1, False), sd)
+    hooks = [m.register_forward_hook(lambda m, i, o, n=n: seen.__setitem__(n, float(o.abs().max())))
+             for n, m in net.named_modules() if isinstance(m, torch.nn.ReLU)]
+    with torch.no_grad():
+        net(x)
+    for h in hooks:
+        h.remove()
+    assert seen["down3.maxpool_conv.1.double_conv.2"] > 65504 < seen["up2.conv.double_conv.2"]   # beyond the f16 range

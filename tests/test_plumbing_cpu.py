@@ -13,18 +13,15 @@ from chessvision.cv_types import BoardExtractionResult, ChessVisionResult, Posit
 from oracle import synth
 
 
-class _BrightnessExtractor:
-    """Stand-in segmenter with the extractor's tensor contract: logits = +-12 from the mean brightness of the pixel."""
+def _oracle_extractor():
+    """The oracle's UNet(3,1) with the "segmenting" random-init weights (chessvision/synthetic.py: make_segmenting): the real
+    module tree at the model seam, whose logits follow the brightness of the photo closely enough to yield real contours."""
+    from chessvision import synthetic
+    from oracle.unet_ref import UNet
 
-    def __call__(self, x: torch.Tensor) -> torch.Tensor:
-        assert tuple(x.shape[1:]) == (3, 256, 256) and x.dtype == torch.float32
-        return (x.mean(dim=1, keepdim=True) > 0.5).float() * 24.0 - 12.0
-
-    def eval(self):
-        return self
-
-    def to(self, device):
-        return self
+    net = UNet(3, 1, False)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.unet_state_dict(1, segmenting=True).items()}, strict=False)
+    return net.eval()
 
 
 def _photo_with_board():
@@ -40,7 +37,7 @@ def _photo_with_board():
 def test_process_image_contract_on_cpu():
     cv = ChessVision()
     assert cv.device.type == "cpu"
-    cv._board_extractor = _BrightnessExtractor()
+    cv._board_extractor = _oracle_extractor()
     cv._classifier = synth.make_resnet(seed=2).eval()
     result = cv.process_image(_photo_with_board())
     assert isinstance(result, ChessVisionResult) and isinstance(result.board_extraction, BoardExtractionResult)
@@ -67,8 +64,23 @@ def test_process_image_contract_on_cpu():
 
 def test_no_board_gives_no_position_on_cpu():
     cv = ChessVision()
-    cv._board_extractor = _BrightnessExtractor()
+    cv._board_extractor = _oracle_extractor()
     cv._classifier = synth.make_resnet(seed=2).eval()
     result = cv.process_image(np.full((512, 512, 3), 10, np.uint8))
     assert result.board_extraction.board_image is None and result.board_extraction.quadrangle is None
     assert result.position is None
+
+
+def test_oracle_pipeline_with_fallback_quadrangle_on_cpu():
+    """oracle/pipeline_ref.py (the checker of tests/test_gpu_e2e.py): a frame without a board is classified through the
+    whole-image quadrangle when fallback_quad is set, and a synthetic board photo is found for real."""
+    from chessvision import synthetic
+    from oracle import pipeline_ref
+
+    unet, resnet = _oracle_extractor(), synth.make_resnet(seed=2)
+    dark = np.full((512, 512, 3), 10, np.uint8)
+    res = pipeline_ref.process_images(unet, resnet, [dark, synthetic.board_photo(3)], fallback_quad=True)
+    assert res[0].position is not None and res[0].board_extraction.quadrangle.tolist() == [[[510.0, 0.0]], [[0.0, 0.0]], [[0.0, 510.0]], [[510.0, 510.0]]]
+    q = res[1].board_extraction.quadrangle.reshape(4, 2)
+    assert res[1].position is not None and 250 < float(np.ptp(q[:, 0])) < 420 and 250 < float(np.ptp(q[:, 1])) < 420
+    assert pipeline_ref.process_images(unet, resnet, [dark])[0].position is None
