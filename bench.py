@@ -266,6 +266,13 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(relaunch_under_torchrun(args, sys.argv[1:]))
 
+    # Only the JSON line may reach stdout: native libraries (RCCL prints "Librccl path : ..." through C stdio, flushed at exit)
+    # write to file descriptor 1 behind Python's back, so fd 1 is pointed at stderr for the whole run and the line goes to a
+    # private duplicate of the real stdout.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     from chessvision import distributed as cvd
     from chessvision import synthetic
     from chessvision.hip_backend import HipEngine
@@ -397,7 +404,7 @@ def main():
                 e3.close()
             except Exception as exc:
                 result["by_variant"] = {"bilinear": {"error": repr(exc)}}
-    print(json.dumps(result), flush=True)
+    print(json.dumps(result), file=json_out, flush=True)
     cvd.barrier(device)
     cvd.shutdown()
 

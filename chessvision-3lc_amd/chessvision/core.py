@@ -209,6 +209,9 @@ class ChessVision:
             groups.setdefault(im.shape, []).append(i)
         step = max(1, int(pipeline_chunk))
         jobs = [ids[k:k + step] for ids in groups.values() for k in range(0, len(ids), step)]
+        if len(jobs) > 1 and len(jobs[0]) > 16:
+            # pipeline fill: nothing overlaps the staging + upload of the very first job, so it is kept short
+            jobs = [jobs[0][:16], jobs[0][16:]] + jobs[1:]
         tm = timings if timings is not None else {}
         for key in ("stage_s", "wait_masks_s", "contours_s", "homography_s", "wait_probs_s", "decode_s", "assemble_s"):
             tm.setdefault(key, 0.0)
@@ -234,7 +237,7 @@ class ChessVision:
         up, down = self._pipeline_streams()
         pool = self._copy_pool
         if pool is None:
-            pool = self._copy_pool = ThreadPoolExecutor(max_workers=4, thread_name_prefix="cv-stage")
+            pool = self._copy_pool = ThreadPoolExecutor(max_workers=8, thread_name_prefix="cv-stage")
 
         def segment(ids):                                   # host -> device (own stream), resize, UNet; masks start back
             t0 = time.perf_counter()
