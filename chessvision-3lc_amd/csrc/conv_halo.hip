@@ -32,9 +32,13 @@ namespace cv {
 // PERSIST: the grid is one workgroup per CU slot and every workgroup walks tiles lid, lid + grid, ...; the first DMAs of the
 // next tile (its halo and three weight stages) are issued before the current tile's epilogue, so their latency, the
 // store drain and the workgroup relaunch disappear behind it (r01_tuning.md step 22).
-template <typename T, int CT, int TH, int WGC, int NW, int TPS, int NSW, int IMG, bool PERSIST>
+// DBH: halo double buffered (the next channel block's halo lands while the current one is computed).  DBH = false keeps ONE
+// halo buffer: at every channel-block boundary the workgroup drains, DMAs the next halo and waits for it -- a bubble that the
+// second workgroup resident on the CU fills; what it buys is LDS: a 64-channel tile over a 16 x 16 patch (four patch rows per
+// wave = twice the MFMAs per weight byte and per fragment read of the 8 x 16 tile) then fits twice per CU.
+template <typename T, int CT, int TH, int WGC, int NW, int TPS, int NSW, int IMG, bool PERSIST, bool DBH = true>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_halo_kernel(const ConvParams p) {
-    static_assert((TPS == 1 || TPS == 3) && (NSW == 2 || NSW == 3), "stage shape");
+    static_assert(TPS == 1 && (NSW == 3 || NSW == 4), "stage shape");
     constexpr int SPC = 9 / TPS;                        // stages per channel block
     constexpr int WGP = NW / WGC;                       // wave groups along the patch rows
     static_assert(CT / WGC == 64, "every wave owns a 64-channel slab");
@@ -69,6 +73,20 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // experiments (CV_TUNE): static priority that differs between the two waves sharing a SIMD, so that they stop running in
+    // lockstep (both in their MFMA phase, then both in their DMA / barrier phase)
+    if (NW == 4 && (p.tune & 1)) {                       // 4-wave tile, two workgroups per CU: by wave slot parity
+        if (__builtin_amdgcn_s_getreg(6148) & 1u) __builtin_amdgcn_s_setprio(2);     // HW_REG_HW_ID[3:0] = wave slot of the SIMD
+    }
+    if (NW == 4 && (p.tune & 2)) {                       // ... by dispatch generation of the workgroup
+        if ((blockIdx.x >> 8) & 1u) __builtin_amdgcn_s_setprio(2);
+    }
+    if (NW == 8 && (p.tune & 4)) {                       // 8-wave tile: the younger half (waves 4..7) wins arbitration
+        if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+    }
+    if (NW == 8 && (p.tune & 8)) {
+        if (wave < 4) __builtin_amdgcn_s_setprio(1);
+    }
     const unsigned nwg = gridDim.x, bid = blockIdx.x;   // XCD-aware remap, as in conv_igemm.hip
     const unsigned xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
     const unsigned lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
@@ -89,7 +107,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const bool is_w = !kRoles || wave < NWI;            // this wave moves weight stages / halo pieces
     const bool is_h = !kRoles || wave >= NWI;
     const int wi = kRoles && wave >= NWI ? wave - NWI : wave;     // index among the waves of its role
-    auto decode = [&](unsigned tile) {
+    auto decode = [&](unsigned tile) __attribute__((always_inline)) {
         ctTile = tile % p.nCt;
         int pt = tile / p.nCt;
         tx = pt % tilesX; pt /= tilesX;
@@ -99,12 +117,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         wsrc = p.w + (size_t)ctTile * p.nStages * WTAP + wi * 1024 + lane * 16;
     };
 
-    auto issue_w = [&](int s, int slot) {
+    auto issue_w = [&](int s, int slot) __attribute__((always_inline)) {
         char* sW = smem + slot * WSTAGE;
 #pragma unroll
         for (int i = 0; i < LW; ++i) glds16(wsrc + (size_t)s * WSTAGE + i * (NWI * 1024), sW + (i * NWI + wi) * 1024);   // stage s = TPS consecutive taps
     };
-    auto issue_halo = [&](int cb, int hb, auto i0_tag, auto n_tag) {          // pieces [I0, I0 + N) of this wave's H
+    auto issue_halo = [&](int cb, int hb, auto i0_tag, auto n_tag) __attribute__((always_inline)) {          // pieces [I0, I0 + N) of this wave's H
         constexpr int I0 = decltype(i0_tag)::value, N = decltype(n_tag)::value;
         char* sH = halo + hb * HBYTES;
         int ln = lane;
@@ -160,14 +178,21 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         boff[0][kx] = NSW * WSTAGE + row * 128 + ((c0 ^ (col & 7)) << 4);
         boff[1][kx] = NSW * WSTAGE + row * 128 + ((c1 ^ (col & 7)) << 4);
     }
-    auto load_a = [&](Frags& F, auto slot_tag) {        // weights: published by the barrier of the previous stage
+    // Weight ring slot of a stage: NSW == 3 divides the nine taps of a channel block, so slot = tap % 3 is an immediate;
+    // NSW == 4 (one more stage of L2 -> LDS latency hidden) tracks the slot at run time: `wslot` = byte offset of the slot
+    // of the stage being computed, two VALU adds per stage.
+    int wslot = 0;
+    auto next_slot = [&](int off) __attribute__((always_inline)) { return off + WSTAGE == NSW * WSTAGE ? 0 : off + WSTAGE; };
+    auto load_a = [&](Frags& F, auto slot_tag, int roff) __attribute__((always_inline)) {        // weights: published by the barrier of the previous stage
         constexpr int SLOT = decltype(slot_tag)::value;
+        const int so = NSW == 3 ? SLOT * WSTAGE : roff;
+        const int a0 = aoff[0] + so, a1 = aoff[1] + so;
 #pragma unroll
-        for (int f = 0; f < FC; ++f) F.a[0][f] = *reinterpret_cast<const V*>(smem + aoff[0] + (SLOT * WSTAGE + f * 2048));
+        for (int f = 0; f < FC; ++f) F.a[0][f] = *reinterpret_cast<const V*>(smem + a0 + f * 2048);
 #pragma unroll
-        for (int f = 0; f < FC; ++f) F.a[1][f] = *reinterpret_cast<const V*>(smem + aoff[1] + (SLOT * WSTAGE + f * 2048));
+        for (int f = 0; f < FC; ++f) F.a[1][f] = *reinterpret_cast<const V*>(smem + a1 + f * 2048);
     };
-    auto load_b = [&](Frags& F, auto tap_tag, auto hb_tag) {      // pixels: nine shifted views of the resident halo
+    auto load_b = [&](Frags& F, auto tap_tag, auto hb_tag) __attribute__((always_inline)) {      // pixels: nine shifted views of the resident halo
         constexpr int TAP = decltype(tap_tag)::value;
         constexpr int KY = TAP / 3, KX = TAP % 3;
         constexpr int BUF = decltype(hb_tag)::value * HBYTES;
@@ -177,13 +202,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         for (int g = 0; g < FP; ++g) F.b[1][g] = *reinterpret_cast<const V*>(smem + boff[1][KX] + (BUF + (g + KY) * (HLW * 128)));
     };
     // first third (split) / half of the stage's MFMAs: needs set 0 only
-    auto mma_head = [&](const Frags& F) {
+    auto mma_head = [&](const Frags& F) __attribute__((always_inline)) {
 #pragma unroll
         for (int f = 0; f < FC; ++f)
 #pragma unroll
             for (int g = 0; g < FP; ++g) mma16(acc[f][g], F.a[0][f], F.b[0][g]);
     };
-    auto mma_tail = [&](const Frags& F) {               // passes over all accumulators: dependent MFMAs stay FC*FP apart
+    auto mma_tail = [&](const Frags& F) __attribute__((always_inline)) {               // passes over all accumulators: dependent MFMAs stay FC*FP apart
         if constexpr (kSplit16) {
 #pragma unroll
             for (int f = 0; f < FC; ++f)
@@ -216,24 +241,34 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     unsigned long long st_wait = 0, st_head = 0, st_tail = 0;
     const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    static_assert(NSW == 3 && TPS == 1, "the pipelined loop is written for one tap per stage and a 3-deep weight ring");
+
     Frags F0, F1;
     int s = 0;
-    auto issue_prologue = [&]() {                        // first DMAs of the tile `decode` was last called for
+    auto issue_prologue = [&]() __attribute__((always_inline)) {                        // first DMAs of the tile `decode` was last called for
         if (is_h) issue_halo(0, 0, std::integral_constant<int, 0>{}, std::integral_constant<int, H>{});
-        if (is_w) { issue_w(0, 0); issue_w(1, 1); issue_w(2, 2); }
+        if (is_w) {
+            issue_w(0, 0); issue_w(1, 1); issue_w(2, 2);
+            if (NSW == 4) issue_w(3 < nS ? 3 : nS - 1, 3);
+        }
     };
-    auto stage = [&](Frags& cur, Frags& nxt, auto j_tag, auto hb_tag, int cb) {
+    auto stage = [&](Frags& cur, Frags& nxt, auto j_tag, auto hb_tag, int cb) __attribute__((always_inline)) {
         constexpr int J = decltype(j_tag)::value;
         constexpr int HB = decltype(hb_tag)::value;
         const bool more_cb = cb + 1 < nCb;
+        // Single halo buffer: the fragments of tap 8 are read during tap 7's head, and every wave drains those reads
+        // (lgkmcnt(0)) before tap 7's barrier -- past that barrier nobody reads the halo any more.  The next
+        // block's halo is therefore issued in tap 7's DMA slot, flies during the rest of taps 7 and 8, and is waited for at
+        // the end of tap 8, where the first fragments of the new block are read (they cannot be prefetched earlier).
+        constexpr bool kRefill = !DBH && J == 8;
+        constexpr bool kRefillIssue = !DBH && J == 7;
 #if CV_STAMP
         const unsigned long long st_0 = __builtin_amdgcn_s_memtime();
 #endif
         __builtin_amdgcn_sched_barrier(0);              // head MFMAs (they wait for this stage's reads) stay behind the previous tail
         // the next tap's pixel fragments come from the resident halo: no need to wait for the barrier to read them
 #if CV_ABLATE != 3
-        load_b(nxt, std::integral_constant<int, (J + 1) % 9>{}, std::integral_constant<int, (J == 8 ? HB ^ 1 : HB)>{});
+        if constexpr (!kRefill)
+            load_b(nxt, std::integral_constant<int, (J + 1) % 9>{}, std::integral_constant<int, (DBH && J == 8 ? HB ^ 1 : HB)>{});
 #endif
         mma_head(cur);
 #if CV_SCHED_HINTS
@@ -250,16 +285,19 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         // issued at every barrier, clamped at the end) may fly.  Symmetric duties: plus the next halo when it was issued
         // one or two stages ago.  Roles: the halo waves drain theirs at tap 7 (its last pieces leave at tap 5; the
         // next block's pixel reads start in the head of tap 8).
-        const bool halo_young = !kRoles && (J == 1 || J == 2) && more_cb;
+        // the next halo is younger than W(s+1): double buffered, issued at tap 0; single buffer, issued at tap 7
+        const bool halo_young = !kRoles && more_cb && (DBH ? (J >= 1 && J <= NSW - 1) : J == 8);
 #if CV_STAMP
         const unsigned long long st_a = __builtin_amdgcn_s_memtime();
 #endif
         __builtin_amdgcn_sched_barrier(0);              // the head MFMAs stay in front of the rendezvous, the tail behind it
+        constexpr int FLY = (NSW - 2) * LW;             // weight pieces of the stages after W(s+1), still allowed in flight
+        static_assert(FLY + H <= 63, "vmcnt range");
         if (kRoles && !is_w) {
             if (J == 7) wait_vm_barrier<0>();
             else wait_vm_barrier<63>();
-        } else if (halo_young) wait_vm_barrier<LW + H>();
-        else wait_vm_barrier<LW>();
+        } else if (halo_young) wait_vm_barrier<FLY + H>();
+        else wait_vm_barrier<FLY>();
         __builtin_amdgcn_sched_barrier(0);
 #if CV_STAMP
         const unsigned long long st_b = __builtin_amdgcn_s_memtime();
@@ -271,15 +309,17 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #if CV_ABLATE != 1 && CV_ABLATE != 3
         if constexpr (kRoles) {
             // un-interleaved on purpose: the other wave of this SIMD covers the matrix pipe meanwhile
-            if (is_w) issue_w(s + 3 < nS ? s + 3 : nS - 1, J % 3);
-            else if (J < 6 && more_cb) issue_halo(cb + 1, HB ^ 1, std::integral_constant<int, J * HPS>{}, std::integral_constant<int, HPS>{});
+            if (is_w) issue_w(s + NSW < nS ? s + NSW : nS - 1, NSW == 3 ? J % 3 : wslot / WSTAGE);
+            else if (DBH && J < 6 && more_cb) issue_halo(cb + 1, HB ^ 1, std::integral_constant<int, J * HPS>{}, std::integral_constant<int, HPS>{});
         } else {
-            issue_w(s + 3 < nS ? s + 3 : nS - 1, J % 3);
-            if (J == 0 && more_cb) issue_halo(cb + 1, HB ^ 1, std::integral_constant<int, 0>{}, std::integral_constant<int, H>{});
+            issue_w(s + NSW < nS ? s + NSW : nS - 1, NSW == 3 ? J % 3 : wslot / WSTAGE);
+            if (kRefillIssue && more_cb) issue_halo(cb + 1, 0, std::integral_constant<int, 0>{}, std::integral_constant<int, H>{});
+            if (DBH && J == 0 && more_cb) issue_halo(cb + 1, HB ^ 1, std::integral_constant<int, 0>{}, std::integral_constant<int, H>{});
         }
 #endif
 #if CV_ABLATE != 3
-        load_a(nxt, std::integral_constant<int, (J + 1) % 3>{});
+        wslot = next_slot(wslot);                         // now the slot of stage s + 1
+        load_a(nxt, std::integral_constant<int, (J + 1) % 3>{}, wslot);
 #endif
 #if CV_STAMP
         const unsigned long long st_c = __builtin_amdgcn_s_memtime();
@@ -288,7 +328,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #if CV_SCHED_HINTS
         if constexpr (!kRoles) {
 #pragma unroll
-            for (int i = 0; i < LW; ++i) {
+            for (int i = 0; i < LW + (kRefillIssue ? H : 0); ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);           // one LDS-DMA (VMEM read)
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           // one MFMA
             }
@@ -299,15 +339,24 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             __builtin_amdgcn_sched_group_barrier(0x008, MPL, 0);
         }
 #endif
+        if constexpr (kRefill) {
+            if (more_cb) {                               // wave-uniform
+                __builtin_amdgcn_sched_barrier(0);
+                // everybody's pieces of the next halo have landed (only the weight stage issued after them may still fly)
+                asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LW) : "memory");
+                load_b(nxt, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
 #if CV_STAMP
         const unsigned long long st_d = __builtin_amdgcn_s_memtime();
         st_head += st_a - st_0; st_wait += st_b - st_a; st_tail += st_d - st_b; (void)st_c;
 #endif
         ++s;
     };
-    auto run_cb = [&](auto pb_tag, int cb) {             // PB = parity of the channel block = halo buffer = parity of its tap 0
+    auto run_cb = [&](auto pb_tag, int cb) __attribute__((always_inline)) {             // PB = parity of the channel block = halo buffer = parity of its tap 0
         constexpr int PB = decltype(pb_tag)::value;
-        typedef std::integral_constant<int, PB> HBt;
+        typedef std::integral_constant<int, DBH ? PB : 0> HBt;
         Frags& E = PB ? F1 : F0;                         // fragments of even taps
         Frags& O = PB ? F0 : F1;
         stage(E, O, std::integral_constant<int, 0>{}, HBt{}, cb); stage(O, E, std::integral_constant<int, 1>{}, HBt{}, cb);
@@ -325,12 +374,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
         for (int g = 0; g < FP; ++g) acc[f][g] = f4{0.f, 0.f, 0.f, 0.f};
     if (first) {
-        if (is_w) wait_vm_barrier<2 * LW>();            // halo(0) and W(0) landed; W(1), W(2) may still fly
+        if (is_w) wait_vm_barrier<(NSW - 1) * LW>();    // halo(0) and W(0) landed; the later weight stages may still fly
         else wait_vm_barrier<0>();
     } else {
         wait_vm_barrier<0>();                            // issued a whole epilogue ago; also drains that epilogue's stores
     }
-    load_a(F0, std::integral_constant<int, 0>{});
+    wslot = 0;
+    load_a(F0, std::integral_constant<int, 0>{}, 0);
     load_b(F0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
     s = 0;
     for (int cb = 0; cb < nCb; cb += 2) {
@@ -416,13 +466,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     // bytes; output addresses are derived from the pixel index.  A persistent workgroup stages in halo buffer 1, the
     // only region the next tile's first DMAs do not write, which has room for one row per wave.
     constexpr int RG = PERSIST ? 1 : 2;
-    static_assert(FP % 2 == 0 && NW * RG * 16 * SROW <= (PERSIST ? HBYTES : NSW * WSTAGE + 2 * HBYTES), "staging must fit in LDS");
+    static_assert(DBH || !PERSIST, "the persistent epilogue stages in the second halo buffer");
+    static_assert(FP % 2 == 0 && NW * RG * 16 * SROW <= (PERSIST ? HBYTES : NSW * WSTAGE + (DBH ? 2 : 1) * HBYTES), "staging must fit in LDS");
     char* const stg = (PERSIST ? halo + HBYTES : smem) + wave * (RG * 16 * SROW);
     const int slab0 = eCt * CT + wci * 64;
     T* const pbase = reinterpret_cast<T*>(p.pool_y);
     const bool relu_early = p.relu && !rbase;
     // output pixel index (in padded-plane pixels) of (patch row oy0 + g, pixel px of the 16-lane row)
-    auto out_pixel = [&](int g, int px, bool* live) -> unsigned {
+    auto out_pixel = [&](int g, int px, bool* live) __attribute__((always_inline)) -> unsigned {
         if constexpr (IMG == 0) {
             *live = true;
             return (unsigned)((eN * p.yHp + oy0 + g + 1) * p.yWp + eTx * 16 + px + 1);
@@ -541,12 +592,15 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 }
 
 // ---- host-side launch -------------------------------------------------------------------------------------
+// the 64-channel tile over a 16 x 16 patch keeps a single halo buffer (see the kernel: DBH)
+template <int CT, int TH> static constexpr bool halo_double() { return !(CT == 64 && TH == 16); }
+
 template <int CT, int TH, int NW, int TPS, int NSW, int IMG>
 static constexpr size_t halo_lds() {
     constexpr int HR = IMG ? 4 * (IMG + 2) * (IMG + 2) : 18 * (TH + 2);
     constexpr int NWI = NW == 8 ? NW / 2 : NW;          // as in the kernel: waves per DMA role
     constexpr int H = ((HR + 7) / 8 + NWI - 1) / NWI;
-    return (size_t)NSW * TPS * CT * 128 + (size_t)2 * H * NWI * 1024;
+    return (size_t)NSW * TPS * CT * 128 + (size_t)(halo_double<CT, TH>() ? 2 : 1) * H * NWI * 1024;
 }
 
 static int g_halo_cus = 256;                            // CUs of the device (set by conv_halo_prepare)
@@ -566,11 +620,11 @@ static hipError_t launch_halo(const ConvParams& p, int n_images, hipStream_t str
     // for the hidden prologue to matter; long loops lose ~1 % to the single-row staging
     static const int max_k = [] { const char* v = std::getenv("CV_HALO_PERSIST_MAXK"); return v && *v ? std::atoi(v) : 72; }();
     if (NW == 8 && halo_persistent<NW>() && tiles >= 4 * g_halo_cus && p.nStages <= max_k) {
-        auto kern = conv3x3_halo_kernel<T, CT, TH, WGC, NW, TPS, NSW, IMG, NW == 8>;
+        auto kern = conv3x3_halo_kernel<T, CT, TH, WGC, NW, TPS, NSW, IMG, NW == 8, true>;
         const int grid = tiles < g_halo_cus ? tiles : g_halo_cus;
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * NW), lds, stream, p);
     } else {
-        auto kern = conv3x3_halo_kernel<T, CT, TH, WGC, NW, TPS, NSW, IMG, false>;
+        auto kern = conv3x3_halo_kernel<T, CT, TH, WGC, NW, TPS, NSW, IMG, false, halo_double<CT, TH>()>;
         hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(64 * NW), lds, stream, p);
     }
     return hipGetLastError();
@@ -578,21 +632,33 @@ static hipError_t launch_halo(const ConvParams& p, int n_images, hipStream_t str
 
 template <typename T, int CT, int TH, int WGC, int NW, int TPS, int NSW, int IMG>
 static hipError_t prepare_halo() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<T, CT, TH, WGC, NW, TPS, NSW, IMG, false>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<T, CT, TH, WGC, NW, TPS, NSW, IMG, false, halo_double<CT, TH>()>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess || NW != 8) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<T, CT, TH, WGC, NW, TPS, NSW, IMG, NW == 8>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<T, CT, TH, WGC, NW, TPS, NSW, IMG, NW == 8, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
-// configurations: 64 channels x 8x16 patch (4 waves, two patch rows each), one tap per stage, ring 3: 72 KB, so two
-//                 workgroups share a CU and fill each other's barrier stalls;
+// configurations: 64 channels x 16x16 patch (4 waves, four patch rows each), one tap per stage, ring 3, ONE halo buffer: 68 KB,
+//                 so two workgroups share a CU; each fills the other's barrier stalls and its halo refill at the channel-block
+//                 boundaries (r02_tuning.md: +8-16 % over the double-buffered 8x16 patch of round 1, which did half the MFMAs per
+//                 weight byte and per fragment read; -DCV_HALO_TH64=8 builds that tile);
 //                 128 channels x 16x16 patch (8 waves as 2 x 4, four patch rows each), one tap per stage, ring 3;
 //                 the same 128-channel tile over four packed 8x8 images (ResNet-18 layer2).
-// (An 8-wave 64 x 16x16 variant of the pipelined loop measured 10 % slower than the 4-wave tile, r01_tuning.md step 17.)
-#define CV_FOR_EACH_HALO(X, T)   \
-    X(T, 64, 8, 1, 4, 1, 3, 0)   \
-    X(T, 128, 16, 2, 8, 1, 3, 0) \
+// (Measured and dropped: an 8-wave 64 x 16x16 variant, -10 % (r01_tuning.md step 17); the 16x16 patch with a double-buffered halo
+//  and therefore one workgroup per CU, -8..-17 %; a 4-deep weight ring, +-1 % (r02_tuning.md).)
+#ifndef CV_HALO_NSW64
+#define CV_HALO_NSW64 3
+#endif
+#ifndef CV_HALO_NSW128
+#define CV_HALO_NSW128 3
+#endif
+#ifndef CV_HALO_TH64
+#define CV_HALO_TH64 16                       // patch rows of the 64-channel tile: 16 (single halo buffer, 68 KB) | 8 (double buffered, 72 KB)
+#endif
+#define CV_FOR_EACH_HALO(X, T)                \
+    X(T, 64, CV_HALO_TH64, 1, 4, 1, CV_HALO_NSW64, 0)    \
+    X(T, 128, 16, 2, 8, 1, CV_HALO_NSW128, 0) \
     X(T, 128, 16, 2, 8, 1, 3, 8)
 
 hipError_t conv_halo_prepare() {
@@ -609,8 +675,8 @@ hipError_t conv_halo_prepare() {
     return hipSuccess;
 }
 
-// The 64-row tile (4 waves, 72 KB: two workgroups per CU) beats conv_igemm's 64x256 tile by 5-10 % on the 64-channel
-// layers (r01_tuning.md step 16); CV_HALO64=0 switches it off for A/B runs, CV_HALO_IMG8=0 the packed-image mode.
+// The 64-row tile (4 waves, two workgroups per CU) beats conv_igemm's 64x256 tile on the 64-channel layers (r01_tuning.md step
+// 16, r02_tuning.md); CV_HALO64=0 switches it off for A/B runs, CV_HALO_IMG8=0 the packed-image mode.
 bool conv_halo_supported(int ct, int Ho, int Wo) {
     static const bool allow64 = [] { const char* v = std::getenv("CV_HALO64"); return !(v && v[0] == '0'); }();
     static const bool allow_img8 = [] { const char* v = std::getenv("CV_HALO_IMG8"); return !(v && v[0] == '0'); }();

@@ -86,6 +86,7 @@ struct ConvParams {
     // with atomicMin; the host turns it into CV_ERR_NUMERIC naming the layer (cv_engine_numeric_status).  Null = off.
     unsigned* flag;
     unsigned layer_id;
+    int tune;                 // experiment bits (CV_TUNE), 0 in production
     unsigned long long* stamp;   // diagnostic builds (-DCV_STAMP=1) only: per-workgroup cycle stamps, else null
 };
 

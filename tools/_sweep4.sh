@@ -1,0 +1,9 @@
+set -u
+O=gpurun_out/r2_sweep4; mkdir -p $O
+run() { tag=$1; shift; env "$@" python3 tools/layer_profile.py --prec f16x3 --unet-batch 128 --squares 16384 > $O/$tag.txt 2>&1; grep -E "unet \[|resnet18 \[|inc.double_conv.3|up4.conv|layer1" $O/$tag.txt | sed "s/^/$tag: /"; }
+run base A=1
+run th16 CHESSVISION_HIP_LIB=$PWD/chessvision-3lc_amd/lib/ab/libcv_th16.so
+run base2 A=1
+run th16b CHESSVISION_HIP_LIB=$PWD/chessvision-3lc_amd/lib/ab/libcv_th16.so
+python -m pytest tests/test_gpu_ops.py -m gpu -q -x 2>&1 | tail -3
+CHESSVISION_HIP_LIB=$PWD/chessvision-3lc_amd/lib/ab/libcv_th16.so python -m pytest tests/test_gpu_ops.py tests/test_gpu_models.py -m gpu -q -x 2>&1 | tail -3
