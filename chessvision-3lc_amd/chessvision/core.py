@@ -172,7 +172,7 @@ class ChessVision:
 
     def process_images(self, images: Sequence[NDArray[np.uint8]], threshold: float = 0.5, flip: bool = False,
                        fallback_quad: bool = False, pipeline_chunk: int = 64, return_crops: bool = False,
-                       timings: dict | None = None) -> list[ChessVisionResult]:
+                       timings: dict | None = None, first_job: int | None = None) -> list[ChessVisionResult]:
         """Batched pipeline (new; the reference processes one image per call, core.py:152-195).
 
         Images stay on the device between the two CNNs: INTER_AREA resize -> UNet (u8 in, logits + thresholded mask out);
@@ -209,9 +209,11 @@ class ChessVision:
             groups.setdefault(im.shape, []).append(i)
         step = max(1, int(pipeline_chunk))
         jobs = [ids[k:k + step] for ids in groups.values() for k in range(0, len(ids), step)]
-        if len(jobs) > 1 and len(jobs[0]) > 16:
-            # pipeline fill: nothing overlaps the staging + upload of the very first job, so it is kept short
-            jobs = [jobs[0][:16], jobs[0][16:]] + jobs[1:]
+        first = int(os.environ.get("CHESSVISION_PIPE_FIRST_JOB", "0")) if first_job is None else int(first_job)
+        if len(jobs) > 1 and 0 < first < len(jobs[0]):
+            # optional short first job (nothing overlaps its staging + upload); measured on MI355X: the UNet runs ~5 % slower on
+            # 16- or 32-board jobs than on full 64-board chunks, which costs more than the shorter pipeline fill saves
+            jobs = [jobs[0][:first], jobs[0][first:]] + jobs[1:]
         tm = timings if timings is not None else {}
         for key in ("stage_s", "wait_masks_s", "contours_s", "homography_s", "wait_probs_s", "decode_s", "assemble_s"):
             tm.setdefault(key, 0.0)
@@ -237,7 +239,7 @@ class ChessVision:
         up, down = self._pipeline_streams()
         pool = self._copy_pool
         if pool is None:
-            pool = self._copy_pool = ThreadPoolExecutor(max_workers=8, thread_name_prefix="cv-stage")
+            pool = self._copy_pool = ThreadPoolExecutor(max_workers=16, thread_name_prefix="cv-stage")
 
         def segment(ids):                                   # host -> device (own stream), resize, UNet; masks start back
             t0 = time.perf_counter()

@@ -18,6 +18,8 @@ struct Engine::UNet {
     ConvLayer inc0, inc1, d[4][2], upT[4], u[4][2];
     unsigned up_id[4] = {0, 0, 0, 0}, outc_id = 0;  // numeric-guard ids of the non-conv producers
     DeviceBuffer outc_w, outc_b;
+    DeviceBuffer inc0_wpk;                          // f16-based engines: MFMA image of inc.double_conv.0 for the fused first-layer kernel
+    bool fused_inc0 = false;
     // activations
     Activation in8, a_inc0, cat[4], pool[4], dmid[4], bott, umid[4], uout[4];
     std::vector<Activation*> acts;                  // every tensor above that exists in this variant

@@ -37,6 +37,12 @@ hipError_t stem_pool_mfma(int dt, const void* x, bool x_is_u8, int n, const void
                           const float* shift, int in_exp, const TensorRef& dst, unsigned* flag, unsigned layer_id,
                           hipStream_t s);
 
+// UNet first layer for the f16 / split-f16 engines, fused with the input packing: conv 3x3 p1 (3 -> 64) + BN + ReLU straight from
+// the caller's image (x: (n,3,256,256) f32 or (n,256,256,3) u8, scaled by /255).  wpk: [hi|lo][fragment 4][lane 64] x half8
+// (unet.cpp: pack_inc0_mfma), k = (ky*3 + kx)*3 + c.  dst: 64 ch @ 256x256, whole buffer (Cs == 64).
+hipError_t inc0_mfma(int dt, const void* x, bool x_is_u8, int n, const void* wpk, const float* scale, const float* shift,
+                     int in_exp, const TensorRef& dst, unsigned* flag, unsigned layer_id, hipStream_t s);
+
 // global average pool + Linear(C -> 13) (+ optional softmax).  w: [13][C] f32, b: [13]
 hipError_t head_avgpool_fc(int dt, const TensorRef& src, const float* w, const float* b, float* out,
                            int softmax, unsigned* flag, unsigned layer_id, hipStream_t s);

@@ -462,6 +462,116 @@ __global__ __launch_bounds__(256) void stem_pool_mfma_kernel(const XT* __restric
     report_bad(flag, layer_id, bad);
 }
 
+
+// ---- UNet first layer on the matrix cores, straight from the caller's image ---------------------------------------
+// inc.double_conv.0: conv 3x3 p1 (3 -> 64) + BN + ReLU, fused with the input packing (u8 HWC / 255 or f32 NCHW -> internal
+// layout).  The layer is 0.2 % of the network's MACs but writes 16.8 MB per image: it is bound by that store stream, and the
+// generic implicit-GEMM kernel (three 128-byte K stages over an 8-channel padded copy of the image, one 128-pixel tile per
+// workgroup) spent its time in per-workgroup prologues instead.  Here K = 3 x 3 x 3 = 27 -> 32 = ONE 16x16x32 MFMA k-step
+// (x3 products for split-f16); a workgroup owns an 8-row band of one image, keeps the 10 x 258 x 3 input patch in LDS as
+// f32, and every wave walks 2 rows x 16 fragments: eight ds_read_b32 build the B fragment (lane group q holds k = 8q..8q+7,
+// k = (ky*3 + kx)*3 + c), 4 x (1 | 3) MFMAs give the lane 16 consecutive channels of its pixel, and the wave-private LDS
+// transpose of conv_igemm.hip turns them into 2 KB-contiguous stores.  The 8-channel padded input tensor and its packing
+// kernel disappear.
+template <typename T, typename XT>
+__global__ __launch_bounds__(256) void inc0_mfma_kernel(const XT* __restrict__ x, const half8* __restrict__ wpk,
+                                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                                        float in_mul, TensorRef dst, unsigned* flag, unsigned layer_id) {
+    constexpr bool SPLIT = sizeof(T) == 4;
+    constexpr int W = 256, BAND = 8, PR = BAND + 2, PW = 260;      // patch rows / row pitch (floats): cols -1..256 + pad
+    constexpr int SROW = 272;                                        // staging row pitch (bytes), as conv_igemm.hip
+    __shared__ __attribute__((aligned(16))) float patch[3 * PR * PW + 4];
+    __shared__ __attribute__((aligned(16))) char stage_mem[4 * 16 * SROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, l15 = lane & 15;
+    const int n = blockIdx.x / (W / BAND), band = blockIdx.x % (W / BAND);
+    const int y0 = band * BAND;
+
+    // ---- input patch: rows y0-1 .. y0+8, all 256 columns, 3 channels; zero outside the image -------------------------
+    float bad = 0.f;
+    if (tid < 4) patch[3 * PR * PW + tid] = 0.f;                      // the zero slot the padded k indices read
+    for (int i = tid; i < 3 * PR; i += 256) { patch[i * PW] = 0.f; patch[i * PW + W + 1] = 0.f; }
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        for (int r = 0; r < PR; ++r) {
+            const int gy = y0 - 1 + r;
+            float v = 0.f;
+            if (gy >= 0 && gy < W) {
+                if (sizeof(XT) == 1) v = (float)x[((size_t)(n * W + gy) * W + tid) * 3 + c] / 255.f;
+                else v = (float)x[((size_t)(n * 3 + c) * W + gy) * W + tid];
+            }
+            bad = __builtin_fmaf(v, 0.f, bad);
+            patch[(c * PR + r) * PW + tid + 1] = v * in_mul;
+        }
+    report_bad(flag, 0u, bad);                                       // layer id 0 = the caller's input tensor
+
+    // ---- per-lane constants ---------------------------------------------------------------------------------------------
+    half8 ah[4], al[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        ah[f] = wpk[(0 * 4 + f) * 64 + lane];
+        al[f] = SPLIT ? wpk[(1 * 4 + f) * 64 + lane] : ah[f];
+    }
+    float sc[16], sh[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { sc[i] = scale[q * 16 + i]; sh[i] = shift[q * 16 + i]; }
+    int koff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = q * 8 + j;
+        const int tap = k / 3, c = k - tap * 3, ky = tap / 3, kx = tap - ky * 3;
+        koff[j] = k < 27 ? (c * PR + ky) * PW + kx : 3 * PR * PW;   // (float index relative to the pixel's patch origin) | zero slot
+    }
+    __syncthreads();
+
+    char* const stg = stage_mem + wave * (16 * SROW);
+    float out_bad = 0.f;
+    for (int it = 0; it < 2 * (W / 16); ++it) {
+        const int r = wave * 2 + it / (W / 16), cb = it % (W / 16);   // row of the band, 16-pixel block of the row
+        const int pbase = r * PW + cb * 16 + l15;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = patch[(q * 8 + j < 27 ? pbase : 0) + koff[j]];
+        half8 bh, bl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { bh[j] = (half_t)v[j]; bl[j] = (half_t)(v[j] - (float)bh[j]); }
+        f4 acc[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[f], bh, f4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            if (SPLIT) {
+                acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[f], bh, acc[f], 0, 0, 0);
+                acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[f], bl, acc[f], 0, 0, 0);
+            }
+        }
+        // BN + ReLU, then the wave-private transpose: lane (pixel l15, group q) holds 16 consecutive channels
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            f4 t;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[k] = __builtin_fmaxf(acc[f][k] * sc[f * 4 + k] + sh[f * 4 + k], 0.f);
+            *reinterpret_cast<f4*>(stg + l15 * SROW + (q * 16 + f * 4) * 4) = t;
+        }
+        asm volatile("" ::: "memory");
+        const size_t row_pix = pix_index(dst, n, y0 + r, cb * 16);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {                                  // 16 px x 8 groups of 8 channels = 128 units
+            const int unit = lane + 64 * i, px = unit >> 3, g = unit & 7;
+            float w[8];
+#pragma unroll
+            for (int j = 0; j < 8; j += 4) {
+                const f4 t = *reinterpret_cast<const f4*>(stg + px * SROW + (g * 8 + j) * 4);
+                w[j] = t[0]; w[j + 1] = t[1]; w[j + 2] = t[2]; w[j + 3] = t[3];
+            }
+            int par;
+            char* d = grp_ptr<T>(dst, row_pix + px, g, &par);
+            Grp<T>::store(d, par, w, out_bad);
+        }
+        asm volatile("" ::: "memory");
+    }
+    report_bad(flag, layer_id, out_bad);
+}
+
 // ---- head: adaptive_avg_pool2d(1) + Linear(C -> 13) (+ softmax) ------------------------------------
 // One wave per square; lane owns channel groups lane, lane+64, ...; 13 wave-wide xor-butterfly reductions.
 template <typename T>
@@ -640,6 +750,21 @@ hipError_t stem_pool_mfma(int dt, const void* x, bool x_is_u8, int n, const void
     } else {
         if (x_is_u8) hipLaunchKernelGGL((stem_pool_mfma_kernel<split_t, uint8_t>), g, b, 0, s, (const uint8_t*)x, n, w, scale, shift, im, dst, flag, layer_id);
         else hipLaunchKernelGGL((stem_pool_mfma_kernel<split_t, float>), g, b, 0, s, (const float*)x, n, w, scale, shift, im, dst, flag, layer_id);
+    }
+    return hipGetLastError();
+}
+hipError_t inc0_mfma(int dt, const void* x, bool x_is_u8, int n, const void* wpk, const float* scale, const float* shift,
+                     int in_exp, const TensorRef& dst, unsigned* flag, unsigned layer_id, hipStream_t s) {
+    if (dt == kF32 || dst.C != 64 || dst.H != 256 || dst.W != 256 || dst.Coff != 0 || dst.Cs != 64) return hipErrorInvalidValue;
+    const dim3 g((unsigned)(n * 32)), b(256);
+    const half8* w = reinterpret_cast<const half8*>(wpk);
+    const float im = pow2f(-in_exp);
+    if (dt == kF16) {
+        if (x_is_u8) hipLaunchKernelGGL((inc0_mfma_kernel<half_t, uint8_t>), g, b, 0, s, (const uint8_t*)x, w, scale, shift, im, dst, flag, layer_id);
+        else hipLaunchKernelGGL((inc0_mfma_kernel<half_t, float>), g, b, 0, s, (const float*)x, w, scale, shift, im, dst, flag, layer_id);
+    } else {
+        if (x_is_u8) hipLaunchKernelGGL((inc0_mfma_kernel<split_t, uint8_t>), g, b, 0, s, (const uint8_t*)x, w, scale, shift, im, dst, flag, layer_id);
+        else hipLaunchKernelGGL((inc0_mfma_kernel<split_t, float>), g, b, 0, s, (const float*)x, w, scale, shift, im, dst, flag, layer_id);
     }
     return hipGetLastError();
 }

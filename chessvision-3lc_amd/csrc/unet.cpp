@@ -139,6 +139,32 @@ Status unet_load(Engine& e, const ParamMap& pm) {
     // encoder
     CV_TRY(build_conv_bn(e, U.inc0, pm, "inc.double_conv.0", "inc.double_conv.1", 64, 3, 3, 1, 8, px(0), 256));
     CV_TRY(build_conv_bn(e, U.inc1, pm, "inc.double_conv.3", "inc.double_conv.4", 64, 64, 3, 1, 64, px(0), 256));
+    if (dt != kF32) {
+        // the same layer for the fused first-layer kernel (pointwise.hip: inc0_mfma): rows normalised exactly as finish_layer
+        // does (the epilogue constants of U.inc0 carry the row exponents), k = (ky*3 + kx)*3 + c, padded 27 -> 32
+        const char* v = std::getenv("CV_INC0");
+        U.fused_inc0 = !(v && v[0] == '0');
+        const float* w;
+        CV_TRY(need(pm, "inc.double_conv.0.weight", {64, 3, 3, 3}, &w));
+        std::vector<_Float16> pk((size_t)2 * 4 * 64 * 8);
+        for (int hl = 0; hl < 2; ++hl)
+            for (int f = 0; f < 4; ++f)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int i = lane & 15, q = lane >> 4;
+                    const int ch = 16 * (i / 4) + 4 * f + (i % 4);
+                    float mx = 0.f;
+                    for (int t = 0; t < 27; ++t) mx = std::max(mx, std::fabs(w[ch * 27 + t]));
+                    int ex = 0;
+                    if (mx > 0.f) (void)std::frexp(mx, &ex);
+                    for (int j = 0; j < 8; ++j) {
+                        const int k = q * 8 + j, tap = k / 3, c = k % 3;
+                        const float val = k < 27 ? std::ldexp(w[(ch * 3 + c) * 9 + tap], -ex) : 0.f;
+                        const _Float16 hi = (_Float16)val;
+                        pk[(((size_t)hl * 4 + f) * 64 + lane) * 8 + j] = hl ? (_Float16)(val - (float)hi) : hi;
+                    }
+                }
+        CV_TRY(U.inc0_wpk.upload(pk.data(), pk.size() * sizeof(_Float16)));
+    }
     for (int i = 0; i < 4; ++i) {
         const std::string p = "down" + std::to_string(i + 1) + ".maxpool_conv.1.double_conv.";
         double_conv_keys(known, p);
@@ -197,7 +223,8 @@ Status unet_load(Engine& e, const ParamMap& pm) {
     U.in8.fixed_exp = true;
     U.in8.exp = dt == kF32 ? 0 : kInputExp;
     U.a_inc0.shape(256, 256, 64, dt);
-    U.acts = {&U.in8, &U.a_inc0};
+    U.acts = {&U.a_inc0};
+    if (!U.fused_inc0) U.acts.push_back(&U.in8);     // the packed 8-channel copy of the input exists on the generic path only
     for (int lvl = 0; lvl < 4; ++lvl) {
         const int skip_c = enc_c[lvl];
         U.cat[lvl].shape(res[lvl], res[lvl], skip_c + up_c[3 - lvl], dt);
@@ -268,7 +295,7 @@ static Status unet_reserve(Engine& e, int n) {
     const int enc_c[5] = {64, 128, 256, 512, U.c5};
     U.taps.clear();
     // module-name taps for cv_get_activation (names follow the reference state-dict prefixes)
-    U.taps["input"] = U.in8.ref(S, 0, 8);
+    if (!U.fused_inc0) U.taps["input"] = U.in8.ref(S, 0, 8);
     U.taps["inc.double_conv.2"] = U.a_inc0.ref(S);
     U.taps["inc.double_conv.5"] = U.cat[0].ref(S, 0, 64);
     U.taps["inc"] = U.taps["inc.double_conv.5"];
@@ -319,11 +346,19 @@ static Status unet_chunk(Engine& e, const void* x, bool x_u8, int n, float* logi
     auto begin = [&](const char* name, double bytes = 0) { if (e.profiling) e.prof_begin(name, false, 0, s, bytes); };
     const double esz = dtype_size(dt);
 
-    begin("pack_input", (double)n * 65536 * ((x_u8 ? 3 : 12) + 8 * esz));
-    if (x_u8) CV_TRY(timed("pack_hwc3_u8", pack_hwc3_u8(dt, (const uint8_t*)x, U.in8.ref(n, 0, 8), s)));
-    else      CV_TRY(timed("pack_nchw_f32", pack_nchw_f32(dt, (const float*)x, 3, U.in8.ref(n, 0, 8), e.guard_ptr(), s)));
-
-    CV_TRY(e.run_conv(U.inc0, U.in8.ref(n, 0, 8), U.a_inc0.ref(n), nullptr, true, s));
+    if (U.fused_inc0) {
+        // first layer straight from the caller's image: no packed copy of the input, no separate packing kernel
+        CV_TRY(U.inc0.set_exps(kInputExp, U.a_inc0.exp, s));
+        if (e.profiling) e.prof_begin(U.inc0.name, true, 27.0 * 64 * 65536 * n, s, (double)n * 65536 * ((x_u8 ? 3 : 12) + 64 * esz) + 27 * 64 * esz);
+        CV_TRY(timed("inc0_mfma", inc0_mfma(dt, x, x_u8, n, U.inc0_wpk.ptr, (const float*)U.inc0.scale.ptr, (const float*)U.inc0.shift.ptr,
+                                            kInputExp, U.a_inc0.ref(n), e.guard_ptr(), U.inc0.layer_id, s)));
+        if (e.calibrating) CV_TRY(e.measure(U.a_inc0.ref(n), s));
+    } else {
+        begin("pack_input", (double)n * 65536 * ((x_u8 ? 3 : 12) + 8 * esz));
+        if (x_u8) CV_TRY(timed("pack_hwc3_u8", pack_hwc3_u8(dt, (const uint8_t*)x, U.in8.ref(n, 0, 8), s)));
+        else      CV_TRY(timed("pack_nchw_f32", pack_nchw_f32(dt, (const float*)x, 3, U.in8.ref(n, 0, 8), e.guard_ptr(), s)));
+        CV_TRY(e.run_conv(U.inc0, U.in8.ref(n, 0, 8), U.a_inc0.ref(n), nullptr, true, s));
+    }
     // every encoder level's second conv also emits its 2x2 max-pool (fused into the epilogue where the halo kernel runs)
     const TensorRef pool0 = U.pool[0].ref(n);
     CV_TRY(e.run_conv(U.inc1, U.a_inc0.ref(n), U.cat[0].ref(n, 0, 64), nullptr, true, s, nullptr, &pool0));

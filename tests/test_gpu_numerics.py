@@ -62,7 +62,6 @@ def test_unet_with_stressed_ranges_matches_oracle(prec, bilinear):
         # the tensor that carries ~2e5 in the oracle is held at an exponent that maps it into [16, 32)
         e = eng.activation_exponent("unet", "down3.maxpool_conv.1.double_conv.2")
         assert 10 <= e <= 15, e
-        assert eng.activation_exponent("unet", "input") == -7
     eng.close()
     assert err <= 1e-3, err
     away = ref.abs() > 1e-3                                # masks agree wherever the logit is not within the error bar of 0

@@ -1,23 +1,20 @@
 #!/bin/bash
-# One MI355X pass over everything profiles/ quotes: GPU tests, PMC traffic, the three bench lines, the rocprofv3 kernel
-# summary of the default bench, per-layer profiles and single-board latency.
+# One MI355X pass over everything profiles/ quotes for this round: PMC traffic, the rocprofv3 kernel trace of the default bench,
+# the SQ counters, per-layer profiles, single-board latency, the bilinear bench line.
 #   usage (repo root, on the GPU box):  bash tools/collect_evidence.sh gpurun_out/final
 set -u
 OUT=${1:-gpurun_out/final}
-REPO=$(pwd)
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-timeout 900 python3 -m pytest tests -m gpu -x -q 2>&1 | tail -3 > "$OUT/tests.txt"
-bash tools/pmc_collect.sh "$OUT" > "$OUT/pmc.log" 2>&1
-[ -s "$OUT/traffic.json" ] && cp "$OUT/traffic.json" profiles/r01_pmc_traffic.json
-for d in f16x3 f32 f16; do
-  python3 bench.py --dtype $d > "$OUT/bench_$d.json" 2> "$OUT/bench_$d.err"
-done
-rm -rf /tmp/rp
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp -o r1 -- python3 "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$REPO/$OUT/bench_f16x3_rocprof.json" 2> "$REPO/$OUT/rocprof.err")
-find /tmp/rp -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats.csv" \;
+PRECS="f16x3 f32" bash tools/pmc_collect.sh "$OUT" > "$OUT/pmc.log" 2>&1
+bash tools/rocprof_bench.sh "$OUT" > "$OUT/rocprof_reduce.log" 2>&1
+bash tools/pmc_sq.sh "$OUT" f16x3 unet > "$OUT/pmc_sq_unet.log" 2>&1
+bash tools/pmc_sq.sh "$OUT" f16x3 resnet18 > "$OUT/pmc_sq_resnet18.log" 2>&1
+bash tools/pmc_sq2.sh "$OUT" f16x3 unet > "$OUT/pmc_sq2_unet.log" 2>&1
 for d in f16x3 f32 f16; do
   python3 tools/layer_profile.py --prec $d > "$OUT/layer_profile_$d.txt" 2>&1
 done
+python3 bench.py --unet-variant bilinear --no-cpu-baseline --no-extras > "$OUT/bench_bilinear.json" 2> "$OUT/bench_bilinear.err"
 python3 tools/latency.py > "$OUT/latency.txt" 2>&1
-cat "$OUT/tests.txt"; cut -c1-200 "$OUT"/bench_f16x3.json; head -5 "$OUT/kernel_stats.csv" | cut -c1-160; cat "$OUT/latency.txt"
+python3 tools/e2e_profile.py > "$OUT/e2e_profile.txt" 2>&1
+cat "$OUT/rocprof_reduce.log" | tail -3; cat "$OUT/latency.txt" | tail -5

@@ -6,7 +6,7 @@ OUT=${1:-gpurun_out/pmc}
 REPO=$(pwd)
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-for prec in f16x3 f32 f16; do
+for prec in ${PRECS:-f16x3 f32 f16}; do
   for model in unet resnet18; do
     for ctr in FETCH_SIZE WRITE_SIZE; do
       d=/tmp/pmc_${prec}_${model}_${ctr}

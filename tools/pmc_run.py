@@ -2,8 +2,13 @@
 
 usage: python3 tools/pmc_run.py <f32|f16|f16x3> <unet|resnet18> [batch] [iters]
 """
+import os
 import sys
 from pathlib import Path
+
+# counter passes average over every dispatch of a kernel name: keep the load-time range calibration (small launches of the same
+# kernels) out of them.  Exponents do not change what the kernels do per byte or per MFMA.
+os.environ.setdefault("CV_CALIBRATE", "0")
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "chessvision-3lc_amd"))

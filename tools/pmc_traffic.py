@@ -33,6 +33,20 @@ def main():
            "hbm_bytes_per_launch": read_b + write_b,
            "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; read = 2*FETCH_SIZE*1024 (gfx950 "
                      "correction for 16-B/lane reads), write = WRITE_SIZE*1024"}
+    # the memory-bound kernels of the same run, by kernel name (same corrections; their access widths are 16 or 32 B per lane)
+    other = {}
+    for k, (n_, v) in f.items():
+        if conv(n_):
+            continue
+        short = n_.split("(")[0].replace("void cv::", "")
+        if not any(t in short for t in ("stem", "head_kernel", "pack_", "upsample", "maxpool", "outc")):
+            continue
+        o = other.setdefault(short, {"launches": 0, "read_bytes": 0.0, "write_bytes": 0.0})
+        o["launches"] += 1
+        o["read_bytes"] += 2.0 * v * 1024
+        o["write_bytes"] += w.get(k, (None, 0.0))[1] * 1024
+    res["memory_bound_kernels"] = {k: {"launches": o["launches"], "read_bytes_per_launch": o["read_bytes"] / o["launches"],
+                                       "write_bytes_per_launch": o["write_bytes"] / o["launches"]} for k, o in other.items()}
     try:
         allres = json.load(open(out))
     except (OSError, ValueError):
