@@ -412,44 +412,64 @@ __global__ __launch_bounds__(256) void stem_pool_mfma_kernel(const XT* __restric
             if (SPLIT) plane[1][at] = (half_t)(v - (float)hi);
         }
         __syncthreads();
-        for (int py = wave; py < 16; py += 4) {              // one pooled row (16 pixels) per fragment
-            float best[16];
+        // Each wave owns four consecutive pooled rows = conv-output rows 8w-1 .. 8w+7.  A conv row is computed ONCE, as its
+        // even-column and odd-column fragments (lane l15 <-> columns 2*l15 and 2*l15+1); the third pool-window column
+        // (2*l15-1) is the odd fragment shifted by one lane (DPP row_shr:1, zero fill = the window's left padding), and the
+        // conv row shared by two vertically adjacent windows is carried in registers: 9 x 2 fragment computations per four
+        // pooled rows instead of the 4 x 9 of a window-by-window walk (r01).  Out-of-range rows / columns contribute 0, which
+        // equals -inf padding after ReLU.
+        auto conv_row_max = [&](int cy, float* hm) __attribute__((always_inline)) {   // max over the three window columns: 16 channels per lane
+            float ev[16], od[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) best[i] = 0.f;
+            for (int par = 0; par < 2; ++par) {
+                f4 acc[4];
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
+                for (int f = 0; f < 4; ++f) acc[f] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const int cy = 2 * py - 1 + dy, cx = 2 * l15 - 1 + dx;      // conv-output pixel of this window slot
-                    const bool valid = cy >= 0 && cx >= 0;
-                    f4 acc[4];
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int row = 2 * cy + 2 + ks * 4 + q;                   // plane row of filter row ky = 4*ks+q
+                    const int dw = (row * LD + 2 * (2 * l15 + par) + 2) >> 1;  // conv column 2*l15 + par
+                    union { unsigned u[4]; half8 h; } bh, bl;
 #pragma unroll
-                    for (int f = 0; f < 4; ++f) acc[f] = f4{0.f, 0.f, 0.f, 0.f};
+                    for (int j = 0; j < 4; ++j) { bh.u[j] = p32h[dw + j]; bl.u[j] = SPLIT ? p32l[dw + j] : 0u; }
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        const int row = 2 * cy + 2 + ks * 4 + q;               // plane row of filter row ky = 4*ks+q
-                        const int dw = (row * LD + 2 * cx + 2) >> 1;
-                        union { unsigned u[4]; half8 h; } bh, bl;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) { bh.u[j] = p32h[dw + j]; bl.u[j] = SPLIT ? p32l[dw + j] : 0u; }
-#pragma unroll
-                        for (int f = 0; f < 4; ++f) {
-                            acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks][f], bh.h, acc[f], 0, 0, 0);
-                            if (SPLIT) {
-                                acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ks][f], bh.h, acc[f], 0, 0, 0);
-                                acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks][f], bl.h, acc[f], 0, 0, 0);
-                            }
+                    for (int f = 0; f < 4; ++f) {
+                        acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks][f], bh.h, acc[f], 0, 0, 0);
+                        if (SPLIT) {
+                            acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ks][f], bh.h, acc[f], 0, 0, 0);
+                            acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks][f], bl.h, acc[f], 0, 0, 0);
                         }
                     }
-#pragma unroll
-                    for (int f = 0; f < 4; ++f)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float v = acc[f][r] * sc[f * 4 + r] + sh[f * 4 + r];
-                            v = valid && v > 0.f ? v : 0.f;
-                            best[f * 4 + r] = fmaxf(best[f * 4 + r], v);
-                        }
                 }
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = __builtin_fmaxf(acc[f][r] * sc[f * 4 + r] + sh[f * 4 + r], 0.f);
+                        if (par == 0) ev[f * 4 + r] = v; else od[f * 4 + r] = v;
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float left = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(od[i]), 0x111, 0xf, 0xf, true));   // od of lane - 1
+                hm[i] = __builtin_fmaxf(__builtin_fmaxf(ev[i], od[i]), left);
+            }
+        };
+        float carry[16];
+        if (wave == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) carry[i] = 0.f;                       // conv row -1: padding
+        } else {
+            conv_row_max(8 * wave - 1, carry);
+        }
+#pragma unroll 1
+        for (int j = 0; j < 4; ++j) {
+            const int py = 4 * wave + j;
+            float mid[16], low[16], best[16];
+            conv_row_max(2 * py, mid);
+            conv_row_max(2 * py + 1, low);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { best[i] = __builtin_fmaxf(__builtin_fmaxf(carry[i], mid[i]), low[i]); carry[i] = low[i]; }
             const size_t opix = pix_index(dst, sq, py, l15);
 #pragma unroll
             for (int i = 0; i < 16; i += Grp<T>::N) {
@@ -572,69 +592,100 @@ __global__ __launch_bounds__(256) void inc0_mfma_kernel(const XT* __restrict__ x
     report_bad(flag, layer_id, out_bad);
 }
 
-// ---- head: adaptive_avg_pool2d(1) + Linear(C -> 13) (+ softmax) ------------------------------------
-// One wave per square; lane owns channel groups lane, lane+64, ...; 13 wave-wide xor-butterfly reductions.
+// ---- head: adaptive_avg_pool2d(1) + Linear(512 -> 13) (+ softmax) ----------------------------------
+// Persistent waves, one square at a time.  Lane l always owns channels 8l .. 8l+7, so its 13 x 8 fc weights are loaded ONCE
+// into registers and reused for every square the wave walks (r01 re-read them from L2 for each square: 104 vector loads per
+// wave and square, which -- not the 2 KB of activations -- set the kernel's time).  Per square: 32-byte loads of the lane's
+// channels at each pixel, 104 FMAs, then the 13 partial sums are reduced across the 64 lanes by a halving butterfly (each step
+// exchanges half of the live values with the partner lane: 7 + 4 + 2 + 1 shuffles, then 2 for the last four lanes) instead of
+// 13 full butterflies (78 shuffles); soft-max runs across the 13 lanes that end up holding one logit each.
 template <typename T>
 __global__ __launch_bounds__(256) void head_kernel(TensorRef src, const float* __restrict__ w,
                                                    const float* __restrict__ b, float mul, float* __restrict__ out,
                                                    int softmax, unsigned* flag, unsigned layer_id) {
     constexpr int NC = 13;
-    constexpr int GN = Grp<T>::N;
+    constexpr int GN = Grp<T>::N, GPL = 8 / GN;              // groups per lane: 1 (f16, split-f16) or 2 (f32)
     const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= src.N) return;                                    // whole wave exits together
-    float acc[NC];
+    const int wave0 = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    float wr[NC][8];
 #pragma unroll
-    for (int j = 0; j < NC; ++j) acc[j] = 0.f;
+    for (int k = 0; k < NC; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; j += 4) {
+            const f4 t = *reinterpret_cast<const f4*>(w + k * 512 + lane * 8 + j);
+            wr[k][j] = t[0]; wr[k][j + 1] = t[1]; wr[k][j + 2] = t[2]; wr[k][j + 3] = t[3];
+        }
+    // which logit this lane holds after the halving butterfly, and its bias
+    const int b5 = (lane >> 5) & 1, b4 = (lane >> 4) & 1, b3 = (lane >> 3) & 1, b2 = (lane >> 2) & 1;
+    const int slot = b4 * 4 + b3 * 2 + b2;
+    const bool holds = b5 ? slot < 6 : slot < 7;
+    const int cls = b5 * 7 + slot;
+    const float bias = holds ? b[cls] : 0.f;
     const float inv = mul / (float)(src.H * src.W);           // mul = 2^exp of the stored tensor (exact)
-    const int groups = src.C / GN;
-    for (int g = lane; g < groups; g += 64) {
-        float s[GN], v[GN];
+    float bad = 0.f;
+    for (int n = wave0; n < src.N; n += nwaves) {
+        float s8[8];
 #pragma unroll
-        for (int j = 0; j < GN; ++j) s[j] = 0.f;
+        for (int j = 0; j < 8; ++j) s8[j] = 0.f;
         for (int y = 0; y < src.H; ++y)
             for (int x = 0; x < src.W; ++x) {
-                int par;
-                Grp<T>::load(grp_ptr<T>(src, pix_index(src, n, y, x), g, &par), par, v);
+                const size_t pix = pix_index(src, n, y, x);
 #pragma unroll
-                for (int j = 0; j < GN; ++j) s[j] += v[j];
+                for (int g = 0; g < GPL; ++g) {
+                    int par;
+                    float v[GN];
+                    Grp<T>::load(grp_ptr<T>(src, pix, lane * GPL + g, &par), par, v);
+#pragma unroll
+                    for (int j = 0; j < GN; ++j) s8[g * GN + j] += v[j];
+                }
             }
+        float acc[NC + 1];
 #pragma unroll
-        for (int j = 0; j < GN; ++j) {
-            const float mean = s[j] * inv;
+        for (int k = 0; k < NC; ++k) {
+            float a = 0.f;
 #pragma unroll
-            for (int k = 0; k < NC; ++k) acc[k] = __builtin_fmaf(mean, w[k * src.C + g * GN + j], acc[k]);
+            for (int j = 0; j < 8; ++j) a = __builtin_fmaf(s8[j] * inv, wr[k][j], a);
+            acc[k] = a;
         }
+        acc[NC] = 0.f;
+        // halving butterfly: 14 -> 7 -> 4 -> 2 -> 1 live values, the upper lane of each pair keeps the upper half
+        float v7[8];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const float r = __shfl_xor(b5 ? acc[i] : acc[7 + i], 32);
+            v7[i] = (b5 ? acc[7 + i] : acc[i]) + r;
+        }
+        v7[7] = 0.f;
+        float v4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float r = __shfl_xor(b4 ? v7[i] : v7[4 + i], 16);
+            v4[i] = (b4 ? v7[4 + i] : v7[i]) + r;
+        }
+        float v2[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float r = __shfl_xor(b3 ? v4[i] : v4[2 + i], 8);
+            v2[i] = (b3 ? v4[2 + i] : v4[i]) + r;
+        }
+        float v = (b2 ? v2[1] : v2[0]) + __shfl_xor(b2 ? v2[0] : v2[1], 4);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 1);
+        v += bias;
+        if (holds) bad = __builtin_fmaf(v, 0.f, bad);
+        if (softmax) {
+            float mx = holds ? v : -INFINITY;
+#pragma unroll
+            for (int m = 32; m >= 4; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m));
+            const float e = holds ? __expf(v - mx) : 0.f;
+            float sum = e;
+#pragma unroll
+            for (int m = 32; m >= 4; m >>= 1) sum += __shfl_xor(sum, m);
+            v = e / sum;
+        }
+        if (holds && (lane & 3) == 0) out[(size_t)n * NC + cls] = v;
     }
-#pragma unroll
-    for (int j = 0; j < NC; ++j) {
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) acc[j] += __shfl_xor(acc[j], m);
-        acc[j] += b[j];
-    }
-    {
-        float bad = 0.f;
-#pragma unroll
-        for (int j = 0; j < NC; ++j) bad = __builtin_fmaf(acc[j], 0.f, bad);
-        if (lane == 0) report_bad(flag, layer_id, bad);
-    }
-    if (softmax) {
-        float mx = acc[0];
-#pragma unroll
-        for (int j = 1; j < NC; ++j) mx = fmaxf(mx, acc[j]);
-        float sum = 0.f;
-#pragma unroll
-        for (int j = 0; j < NC; ++j) { acc[j] = __expf(acc[j] - mx); sum += acc[j]; }
-        const float r = 1.f / sum;
-#pragma unroll
-        for (int j = 0; j < NC; ++j) acc[j] *= r;
-    }
-    if (lane < NC) {
-        float v = acc[0];
-#pragma unroll
-        for (int j = 1; j < NC; ++j) v = lane == j ? acc[j] : v;
-        out[(size_t)n * NC + lane] = v;
-    }
+    report_bad(flag, layer_id, bad);
 }
 
 __global__ void softmax13_kernel(const float* __restrict__ logits, int n, float* __restrict__ probs) {
@@ -770,8 +821,9 @@ hipError_t inc0_mfma(int dt, const void* x, bool x_is_u8, int n, const void* wpk
 }
 hipError_t head_avgpool_fc(int dt, const TensorRef& src, const float* w, const float* b, float* out,
                            int softmax, unsigned* flag, unsigned layer_id, hipStream_t s) {
-    if (src.C % dtype_group(dt)) return hipErrorInvalidValue;
-    const dim3 g((unsigned)((src.N + 3) / 4)), blk(256);
+    if (src.C != 512 || src.Coff != 0 || src.Cs != 512) return hipErrorInvalidValue;      // the kernel keeps lane l on channels 8l..8l+7
+    const int blocks = (src.N + 3) / 4;
+    const dim3 g((unsigned)(blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks)), blk(256);
     const float mul = pow2f(src.exp);
     if (dt == kF16) hipLaunchKernelGGL(head_kernel<half_t>, g, blk, 0, s, src, w, b, mul, out, softmax, flag, layer_id);
     else if (dt == kSplit) hipLaunchKernelGGL(head_kernel<split_t>, g, blk, 0, s, src, w, b, mul, out, softmax, flag, layer_id);
