@@ -218,8 +218,8 @@ def rooflines(eng, x, sq, dtype, B, quiet=False):
                 conv_bytes += e["bytes"]
                 per_model[model][1] += 2.0 * e["macs"]
             else:
-                h = hbm.setdefault(e["name"], [0.0, 0.0, 0])
-                h[0] += e["ms"]; h[1] += e["bytes"]; h[2] += 1
+                h = hbm.setdefault(e["name"], [0.0, 0.0, 0, 0.0])
+                h[0] += e["ms"]; h[1] += e["bytes"]; h[2] += 1; h[3] += 2.0 * e["macs"]
             t = table.setdefault(f"{model}:{e['name']}", [0.0, 0.0, 0.0])
             t[0] += e["ms"]; t[1] += 2.0 * e["macs"]; t[2] += e["bytes"]
     if not quiet:
@@ -238,10 +238,17 @@ def rooflines(eng, x, sq, dtype, B, quiet=False):
             "mfma_issued_tflops": round(achieved * MFMA_PER_MAC[dtype], 2),
             "frac_of_raw_mfma_peak": round(achieved * MFMA_PER_MAC[dtype] / (157.3 if dtype == "f32" else 2500.0), 4),
             "conv_family_hbm_gbs": round(conv_bytes / (conv_ms * 1e-3) / 1e9, 1)}
-    roof_hbm = {name: {"bound": "hbm", "achieved": round(by / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                       "frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "launches": cnt, "ms_per_step": round(ms, 4),
-                       "algorithmic_mb_per_launch": round(by / cnt / 1e6, 2)}
-                for name, (ms, by, cnt) in hbm.items() if ms > 0}
+    roof_hbm = {}
+    for name, (ms, by, cnt, fl) in hbm.items():
+        if ms <= 0:
+            continue
+        blk = {"bound": "hbm", "achieved": round(by / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "launches": cnt, "ms_per_step": round(ms, 4),
+               "algorithmic_mb_per_launch": round(by / cnt / 1e6, 2)}
+        if fl > 1e9:      # the fused stem is a conv on the matrix cores (K padded 49 -> 64): carry its MFMA figure as well
+            blk["mfma_tflops_algorithmic"] = round(fl / (ms * 1e-3) / 1e12, 1)
+            blk["mfma_frac_of_dtype_peak"] = round(fl / (ms * 1e-3) / 1e12 / peak, 4)
+        roof_hbm[name] = blk
     return roof, roof_hbm, launches, conv_ms, conv_n, all_ms
 
 
