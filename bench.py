@@ -230,7 +230,7 @@ def rooflines(eng, x, sq, dtype, B, quiet=False):
     roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4),
             "algorithmic_bytes": conv_bytes / max(conv_n, 1),
-            "kernel": "cv::conv_igemm_kernel + cv::conv3x3_halo_kernel (the conv family, all instantiations)", "launches_per_step": conv_n,
+            "kernel": "cv::conv3x3_halo_kernel + cv::conv_igemm_kernel + cv::inc0_mfma_kernel (the conv family, all instantiations)", "launches_per_step": conv_n,
             "avg_launch_ms": round(conv_ms / max(conv_n, 1), 4), "algorithmic_gflop_per_step": round(conv_flop / 1e9, 2),
             "by_model": {m: {"achieved": round(fl / (ms * 1e-3) / 1e12, 2), "frac": round(fl / (ms * 1e-3) / 1e12 / peak, 4)}
                          for m, (ms, fl) in per_model.items()},       # north_star: >= 50 % on the UNet conv stages

@@ -35,7 +35,16 @@ def read_checkpoint(checkpoint_path: str | os.PathLike) -> tuple[Mapping[str, An
     {"model_state_dict", "metadata"?} | {"state_dict", ...} | {"model", ...} | a bare state dict."""
     assert checkpoint_path is not None and Path(checkpoint_path).exists(), f"Checkpoint not found: {checkpoint_path}"
     logger.info(f"Loading checkpoint from {checkpoint_path}")
-    blob = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+    # weights_only=True (the torch >= 2.6 default the reference's plain torch.load gets, utils.py:51): a checkpoint path is user
+    # input, and unpickling arbitrary objects executes code.  The reference's formats (tensors + a plain metadata dict) load in
+    # this mode; a checkpoint that really needs full unpickling must be opted in explicitly.
+    try:
+        blob = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
+    except Exception as exc:
+        if os.environ.get("CHESSVISION_ALLOW_PICKLE") != "1":
+            raise RuntimeError(f"{checkpoint_path} does not load with weights_only=True ({type(exc).__name__}: {exc}); "
+                               "set CHESSVISION_ALLOW_PICKLE=1 to unpickle it fully if you trust the file") from exc
+        blob = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
     metadata: dict = {}
     if isinstance(blob, dict):
         for key in ("model_state_dict", "state_dict", "model"):

@@ -80,3 +80,23 @@ def test_checkpoint_layouts(tmp_path):
         assert meta == ({"epoch": 3} if i == 0 else {})
     with pytest.raises(AssertionError, match="Checkpoint not found"):
         utils.read_checkpoint(tmp_path / "missing.pth")
+
+
+class _Payload:                                           # an arbitrary (non-tensor) object: needs full unpickling
+    def __init__(self):
+        self.note = "not a tensor"
+
+
+def test_checkpoints_are_loaded_without_unpickling_arbitrary_objects(tmp_path, monkeypatch):
+    """A checkpoint path is user input (ChessVision kwargs, evaluate.py): the loader uses torch's weights_only mode, which
+    the reference's formats satisfy, and refuses anything that needs arbitrary unpickling unless explicitly opted in."""
+    from chessvision import utils
+
+    p = tmp_path / "odd.pth"
+    torch.save({"model_state_dict": {"fc.bias": torch.zeros(13)}, "metadata": {"obj": _Payload()}}, p)
+    monkeypatch.delenv("CHESSVISION_ALLOW_PICKLE", raising=False)
+    with pytest.raises(RuntimeError, match="weights_only"):
+        utils.read_checkpoint(p)
+    monkeypatch.setenv("CHESSVISION_ALLOW_PICKLE", "1")
+    state, meta = utils.read_checkpoint(p)
+    assert set(state) == {"fc.bias"} and isinstance(meta["obj"], _Payload)
