@@ -206,12 +206,14 @@ def rooflines(eng, x, sq, dtype, B, quiet=False):
     family and the HBM roofline of each memory-bound kernel (algorithmic bytes / event time / 8 TB/s)."""
     conv_ms = conv_n = 0
     conv_flop = conv_bytes = all_ms = 0.0
-    table, launches, per_model, hbm = {}, {}, {}, {}
+    table, launches, per_model, hbm, chunks = {}, {}, {}, {}, {}
     for model, inp in (("unet", x), ("resnet18", sq)):
         c_ms, c_n, a_ms, entries = eng.profile(model, inp, iters=1)
         conv_ms += c_ms; conv_n += c_n; all_ms += a_ms
         launches[model] = c_n
         per_model[model] = [c_ms, 0.0]
+        probe = "down1.maxpool_conv.1.double_conv.0" if model == "unet" else "layer1.0.conv1"      # one launch per chunk
+        chunks[model] = max(1, sum(e["name"] == probe for e in entries))
         for e in entries:
             if e["conv"]:
                 conv_flop += 2.0 * e["macs"]
@@ -249,6 +251,7 @@ def rooflines(eng, x, sq, dtype, B, quiet=False):
             blk["mfma_tflops_algorithmic"] = round(fl / (ms * 1e-3) / 1e12, 1)
             blk["mfma_frac_of_dtype_peak"] = round(fl / (ms * 1e-3) / 1e12 / peak, 4)
         roof_hbm[name] = blk
+    launches["chunks"] = chunks
     return roof, roof_hbm, launches, conv_ms, conv_n, all_ms
 
 
@@ -327,11 +330,9 @@ def main():
     macs_board = eng.model_macs("unet") + 64 * eng.model_macs("resnet18")
     log(f"  step: {ms_per_step:.2f} ms; event-timed kernels {all_ms:.2f} ms; conv family {conv_ms:.2f} ms over {conv_n} launches")
 
-    # effective chunk sizes from the launch counts (the f32 engine halves the classifier chunk to stay under 4 GiB per tensor)
-    n_unet_layers, n_resnet_layers = (18 if bilinear else 22), 19
-    assert launches["unet"] % n_unet_layers == 0 and launches["resnet18"] % n_resnet_layers == 0, launches
-    eff_unet = B // (launches["unet"] // n_unet_layers)
-    eff_resnet = B * 64 // (launches["resnet18"] // n_resnet_layers)
+    # effective chunk sizes from the number of passes (the f32 engine halves the classifier chunk to stay under 4 GiB per tensor)
+    eff_unet = B // launches["chunks"]["unet"]
+    eff_resnet = B * 64 // launches["chunks"]["resnet18"]
     traffic = None if bilinear else pmc_traffic(args.dtype, args.unet_chunk, args.resnet_chunk, launches["unet"], launches["resnet18"])
     roof["traffic"] = traffic
     roof["traffic_source"] = (f"{PMC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950-corrected; a committed profile "

@@ -246,10 +246,17 @@ class ChessVision:
             shape = images[ids[0]].shape
             staged = pinned((len(ids),) + shape, torch.uint8)
             view = staged.numpy()
-            list(pool.map(lambda k: np.copyto(view[k], images[ids[k]]), range(len(ids))))
+            with torch.cuda.stream(up):
+                batch = torch.empty((len(ids),) + shape, dtype=torch.uint8, device=dev)
+            # staged and uploaded in slices of 16 images: the upload of a slice overlaps the host copies of the next one (what
+            # matters for the first job of a call, whose staging nothing else hides)
+            for k0 in range(0, len(ids), 16):
+                k1 = min(len(ids), k0 + 16)
+                list(pool.map(lambda k: np.copyto(view[k], images[ids[k]]), range(k0, k1)))
+                with torch.cuda.stream(up):
+                    batch[k0:k1].copy_(staged[k0:k1], non_blocking=True)
             clock("stage_s", t0)
             with torch.cuda.stream(up):
-                batch = staged.to(dev, non_blocking=True)
                 arrived = torch.cuda.Event()
                 arrived.record()
             main.wait_event(arrived)

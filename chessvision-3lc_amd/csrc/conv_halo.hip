@@ -36,8 +36,13 @@ namespace cv {
 // halo buffer: at every channel-block boundary the workgroup drains, DMAs the next halo and waits for it -- a bubble that the
 // second workgroup resident on the CU fills; what it buys is LDS: a 64-channel tile over a 16 x 16 patch (four patch rows per
 // wave = twice the MFMAs per weight byte and per fragment read of the 8 x 16 tile) then fits twice per CU.
-template <typename T, int CT, int TH, int WGC, int NW, int TPS, int NSW, int IMG, bool PERSIST, bool DBH = true>
+// FUSE0 (single halo buffer only): the halo is not DMA'd but PRODUCED in LDS by the network's first layer (3 -> 64 channels, K =
+// 27 -> one MFMA k-step) from a 20 x 20 x 3 patch of the caller's image -- UNet inc.double_conv.0 fused into inc.double_conv.3.
+// The 64-channel full-resolution tensor between the two convs (1.07 GB per 64 images, written once and read 1.27x) never
+// exists; the recompute is the 18^2/16^2 halo overlap of a layer that holds 0.2 % of the network's MACs.
+template <typename T, int CT, int TH, int WGC, int NW, int TPS, int NSW, int IMG, bool PERSIST, bool DBH = true, bool FUSE0 = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_halo_kernel(const ConvParams p) {
+    static_assert(!FUSE0 || (!DBH && !PERSIST && IMG == 0 && CT == 64 && NW == 4 && __is_same(T, split_t)), "fused producer: split-f16 64-channel single-halo tile");
     static_assert(TPS == 1 && (NSW == 3 || NSW == 4), "stage shape");
     constexpr int SPC = 9 / TPS;                        // stages per channel block
     constexpr int WGP = NW / WGC;                       // wave groups along the patch rows
@@ -117,6 +122,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         wsrc = p.w + (size_t)ctTile * p.nStages * WTAP + wi * 1024 + lane * 16;
     };
 
+    const int q = lane >> 4, l15 = lane & 15;
     auto issue_w = [&](int s, int slot) __attribute__((always_inline)) {
         char* sW = smem + slot * WSTAGE;
 #pragma unroll
@@ -145,8 +151,93 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
     };
 
+    // ---- fused producer (FUSE0) --------------------------------------------------------------------------------------
+    constexpr int PW0 = 20;                                        // patch pitch (floats): image rows / cols ty*16-2 .. +17
+    float* const patch0 = reinterpret_cast<float*>(halo + HBYTES);   // [3][20][20] f32 + one zero slot (4864 B)
+    half8* const w0lds = reinterpret_cast<half8*>(halo + HBYTES + 4864);      // first-layer fragments of channel block 1 (4 KB)
+    float* const sc0lds = reinterpret_cast<float*>(halo + HBYTES + 4864 + 4096);   // scale[64], shift[64]
+    auto load_patch0 = [&]() __attribute__((always_inline)) {
+        // everything the two productions need that is not lane-private goes to LDS once, in one round of global latency: the
+        // image patch, the weight fragments of channel block 1 (block 0's are used right away, from registers) and the BN constants
+        w0lds[tid] = reinterpret_cast<const half8*>(p.f0_w)[2 * 2 * 64 + tid];
+        if (tid < 64) { sc0lds[tid] = p.f0_scale[tid]; sc0lds[64 + tid] = p.f0_shift[tid]; }
+        float bad0 = 0.f;
+        for (int idx = tid; idx < 3 * 20 * PW0 + 1; idx += 64 * NW) {
+            const int c = idx / (20 * PW0), rem = idx - c * (20 * PW0), r = rem / PW0, col = rem - r * PW0;
+            const int gy = ty * TH - 2 + r, gx = tx * 16 - 2 + col;
+            float v = 0.f;
+            if (idx < 3 * 20 * PW0 && gy >= 0 && gy < p.xHp - 2 && gx >= 0 && gx < p.xWp - 2) {
+                const int Hh = p.xHp - 2, Ww = p.xWp - 2;
+                if (p.f0_u8) v = (float)reinterpret_cast<const uint8_t*>(p.f0_x)[((size_t)(n * Hh + gy) * Ww + gx) * 3 + c] / 255.f;
+                else v = reinterpret_cast<const float*>(p.f0_x)[((size_t)(n * 3 + c) * Hh + gy) * Ww + gx];
+            }
+            bad0 = __builtin_fmaf(v, 0.f, bad0);
+            patch0[idx] = v * p.f0_in_mul;
+        }
+        if (bad0 != bad0 && p.flag) atomicMin(p.flag, 0u);         // layer id 0 = the caller's input tensor
+    };
+    // halo(cb) <- relu(bn(conv3x3(patch))) for channels 32*cb .. 32*cb+31 of the 18 x 18 halo pixels, zero outside the image (the
+    // zero padding of THIS layer), written in the layout the tap views read: pixel row of 128 B, 16-byte chunks swizzled by the
+    // pixel column, [hi, lo] / [lo, hi] by group parity.  Lane (pixel l15, group q) ends with the 8 channels of group q.
+    auto produce0 = [&](int cb) __attribute__((always_inline)) {
+        half8 ah0, al0, ah1, al1;
+        if (cb == 0) {                                   // wave-uniform
+            const half8* w0 = reinterpret_cast<const half8*>(p.f0_w) + lane;
+            ah0 = w0[0 * 64]; al0 = w0[1 * 64]; ah1 = w0[2 * 64]; al1 = w0[3 * 64];
+        } else {
+            ah0 = w0lds[0 * 64 + lane]; al0 = w0lds[1 * 64 + lane]; ah1 = w0lds[2 * 64 + lane]; al1 = w0lds[3 * 64 + lane];
+        }
+        float sc0[8], sh0[8];
+#pragma unroll
+        for (int j = 0; j < 8; j += 4) {
+            const f4 a = *reinterpret_cast<const f4*>(sc0lds + cb * 32 + q * 8 + j);
+            const f4 b = *reinterpret_cast<const f4*>(sc0lds + 64 + cb * 32 + q * 8 + j);
+            sc0[j] = a[0]; sc0[j + 1] = a[1]; sc0[j + 2] = a[2]; sc0[j + 3] = a[3];
+            sh0[j] = b[0]; sh0[j + 1] = b[1]; sh0[j + 2] = b[2]; sh0[j + 3] = b[3];
+        }
+        int ko[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = q * 8 + j, tap = k / 3, c = k - tap * 3, ky = tap / 3, kx = tap - ky * 3;
+            ko[j] = k < 27 ? (c * 20 + ky) * PW0 + kx : 3 * 20 * PW0;      // relative to the halo pixel's patch origin | the zero slot
+        }
+        for (int fr = wave; fr < (HR + 15) / 16; fr += NW) {
+            const int hp = fr * 16 + l15;
+            const int hpc = hp < HR ? hp : HR - 1;
+            const int hy = hpc / 18, hx = hpc - hy * 18;
+            const int pb = hy * PW0 + hx;
+            half8 bh, bl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = patch0[(q * 8 + j < 27 ? pb : 0) + ko[j]];
+                bh[j] = (half_t)v;
+                bl[j] = (half_t)(v - (float)bh[j]);
+            }
+            f4 a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bh, f4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            f4 a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bh, f4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, bh, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, bh, a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bl, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bl, a1, 0, 0, 0);
+            const int iy = ty * TH - 1 + hy, ix = tx * 16 - 1 + hx;
+            const bool inside = iy >= 0 && iy < p.xHp - 2 && ix >= 0 && ix < p.xWp - 2;
+            half8 hi8, lo8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float v = (j < 4 ? a0[j] : a1[j - 4]) * sc0[j] + sh0[j];
+                v = inside ? __builtin_fmaxf(v, 0.f) : 0.f;
+                hi8[j] = (half_t)v;
+                lo8[j] = (half_t)(v - (float)hi8[j]);
+            }
+            if (hp < HR) {
+                char* row = halo + hpc * 128;
+                *reinterpret_cast<half8*>(row + (((2 * q + (q & 1)) ^ (hx & 7)) << 4)) = hi8;
+                *reinterpret_cast<half8*>(row + (((2 * q + 1 - (q & 1)) ^ (hx & 7)) << 4)) = lo8;
+            }
+        }
+    };
+
     const int wci = wave / WGP, wpi = wave % WGP;
-    const int q = lane >> 4, l15 = lane & 15;
     const int rowW = (wci * 64 + l15) * 128;
     const int wrow0 = wpi * FP;                          // first patch row of this wave
     const int l7 = lane & 7;
@@ -245,7 +336,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     Frags F0, F1;
     int s = 0;
     auto issue_prologue = [&]() __attribute__((always_inline)) {                        // first DMAs of the tile `decode` was last called for
-        if (is_h) issue_halo(0, 0, std::integral_constant<int, 0>{}, std::integral_constant<int, H>{});
+        if (is_h && !FUSE0) issue_halo(0, 0, std::integral_constant<int, 0>{}, std::integral_constant<int, H>{});
         if (is_w) {
             issue_w(0, 0); issue_w(1, 1); issue_w(2, 2);
             if (NSW == 4) issue_w(3 < nS ? 3 : nS - 1, 3);
@@ -286,7 +377,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         // one or two stages ago.  Roles: the halo waves drain theirs at tap 7 (its last pieces leave at tap 5; the
         // next block's pixel reads start in the head of tap 8).
         // the next halo is younger than W(s+1): double buffered, issued at tap 0; single buffer, issued at tap 7
-        const bool halo_young = !kRoles && more_cb && (DBH ? (J >= 1 && J <= NSW - 1) : J == 8);
+        const bool halo_young = !kRoles && !FUSE0 && more_cb && (DBH ? (J >= 1 && J <= NSW - 1) : J == 8);
 #if CV_STAMP
         const unsigned long long st_a = __builtin_amdgcn_s_memtime();
 #endif
@@ -313,7 +404,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             else if (DBH && J < 6 && more_cb) issue_halo(cb + 1, HB ^ 1, std::integral_constant<int, J * HPS>{}, std::integral_constant<int, HPS>{});
         } else {
             issue_w(s + NSW < nS ? s + NSW : nS - 1, NSW == 3 ? J % 3 : wslot / WSTAGE);
-            if (kRefillIssue && more_cb) issue_halo(cb + 1, 0, std::integral_constant<int, 0>{}, std::integral_constant<int, H>{});
+            if (kRefillIssue && !FUSE0 && more_cb) issue_halo(cb + 1, 0, std::integral_constant<int, 0>{}, std::integral_constant<int, H>{});
             if (DBH && J == 0 && more_cb) issue_halo(cb + 1, HB ^ 1, std::integral_constant<int, 0>{}, std::integral_constant<int, H>{});
         }
 #endif
@@ -328,7 +419,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #if CV_SCHED_HINTS
         if constexpr (!kRoles) {
 #pragma unroll
-            for (int i = 0; i < LW + (kRefillIssue ? H : 0); ++i) {
+            for (int i = 0; i < LW + (kRefillIssue && !FUSE0 ? H : 0); ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);           // one LDS-DMA (VMEM read)
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           // one MFMA
             }
@@ -342,8 +433,15 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         if constexpr (kRefill) {
             if (more_cb) {                               // wave-uniform
                 __builtin_amdgcn_sched_barrier(0);
-                // everybody's pieces of the next halo have landed (only the weight stage issued after them may still fly)
-                asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LW) : "memory");
+                if constexpr (FUSE0) {
+                    // this wave passed tap 8's barrier, so every wave passed tap 7's, before which all reads of the old halo
+                    // were drained: the buffer is free.  Produce the next block's halo, then publish it.
+                    produce0(cb + 1);
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                } else {
+                    // everybody's pieces of the next halo have landed (only the weight stage issued after them may still fly)
+                    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LW) : "memory");
+                }
                 load_b(nxt, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -368,6 +466,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     unsigned tile = lid;
     decode(tile);
     issue_prologue();
+    if constexpr (FUSE0) {                               // the first weight stages fly while the first halo is produced
+        load_patch0();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        produce0(0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
     for (bool first = true;; first = false) {
 #pragma unroll
     for (int f = 0; f < FC; ++f)
@@ -611,10 +715,22 @@ template <int NW> static bool halo_persistent() {
     return NW == 8 && on;
 }
 
+constexpr size_t kFuse0Lds = 4864 + 4096 + 512;         // [3][20][20] f32 input patch + zero slot | block-1 weight fragments | BN constants
+template <typename T, int CT, int TH> static constexpr bool halo_can_fuse0() { return CT == 64 && TH == 16 && __is_same(T, split_t); }
+
 template <typename T, int CT, int TH, int WGC, int NW, int TPS, int NSW, int IMG>
 static hipError_t launch_halo(const ConvParams& p, int n_images, hipStream_t stream) {
     const int tiles = (IMG ? (n_images + 3) / 4 : n_images * (p.Ho / TH) * (p.Wo / 16)) * p.nCt;
     const size_t lds = halo_lds<CT, TH, NW, TPS, NSW, IMG>();
+    if (p.f0_x) {
+        if constexpr (halo_can_fuse0<T, CT, TH>() && IMG == 0) {
+            auto kern = conv3x3_halo_kernel<T, CT, TH, WGC, NW, TPS, NSW, IMG, false, false, true>;
+            hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(64 * NW), lds + kFuse0Lds, stream, p);
+            return hipGetLastError();
+        } else {
+            return hipErrorInvalidValue;
+        }
+    }
     static_assert(halo_lds<CT, TH, NW, TPS, NSW, IMG>() <= 160 * 1024, "LDS budget");
     // persistent only where it pays (same-box A/B, r01_tuning.md step 22): several tiles per CU and a K loop short enough
     // for the hidden prologue to matter; long loops lose ~1 % to the single-row staging
@@ -634,6 +750,11 @@ template <typename T, int CT, int TH, int WGC, int NW, int TPS, int NSW, int IMG
 static hipError_t prepare_halo() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<T, CT, TH, WGC, NW, TPS, NSW, IMG, false, halo_double<CT, TH>()>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if constexpr (halo_can_fuse0<T, CT, TH>() && IMG == 0) {
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<T, CT, TH, WGC, NW, TPS, NSW, IMG, false, false, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
     if (e != hipSuccess || NW != 8) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<T, CT, TH, WGC, NW, TPS, NSW, IMG, NW == 8, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -677,6 +798,8 @@ hipError_t conv_halo_prepare() {
 
 // The 64-row tile (4 waves, two workgroups per CU) beats conv_igemm's 64x256 tile on the 64-channel layers (r01_tuning.md step
 // 16, r02_tuning.md); CV_HALO64=0 switches it off for A/B runs, CV_HALO_IMG8=0 the packed-image mode.
+bool conv_halo_can_fuse_first_layer(int ct, int dt) { return ct == 64 && CV_HALO_TH64 == 16 && dt == kSplit; }
+
 bool conv_halo_supported(int ct, int Ho, int Wo) {
     static const bool allow64 = [] { const char* v = std::getenv("CV_HALO64"); return !(v && v[0] == '0'); }();
     static const bool allow_img8 = [] { const char* v = std::getenv("CV_HALO_IMG8"); return !(v && v[0] == '0'); }();

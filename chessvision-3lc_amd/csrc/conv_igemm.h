@@ -27,6 +27,7 @@ int conv_cfg_ct(int cfg);
 // conv_halo.hip: 3x3 / stride-1 layers with the input patch (+halo) resident in LDS across the nine taps
 hipError_t conv_halo_prepare();
 bool conv_halo_supported(int ct, int Ho, int Wo);
+bool conv_halo_can_fuse_first_layer(int ct, int dt);     // ConvParams::f0_* (the 64-channel single-halo tile, split-f16)
 hipError_t conv_halo_launch(int ct, int dt, const ConvParams& p, int n_images, hipStream_t stream);
 int conv_cfg_pt(int cfg);
 

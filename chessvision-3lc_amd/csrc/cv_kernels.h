@@ -87,6 +87,15 @@ struct ConvParams {
     unsigned* flag;
     unsigned layer_id;
     int tune;                 // experiment bits (CV_TUNE), 0 in production
+    // optional fused producer (conv_halo.hip, 64-channel single-halo tile only): the 64-channel input of THIS layer is never read
+    // from memory -- every workgroup computes the haloed patch it needs in LDS from the caller's 3-channel image with the
+    // network's first conv + BN + ReLU (UNet inc.double_conv.0).  Null f0_x = off.
+    const void* f0_x;         // (n,3,256,256) f32 or (n,256,256,3) u8
+    const void* f0_w;         // first-layer weights: [channel block 2][fragment 2][hi|lo][lane 64] x half8, k = (ky*3 + kx)*3 + c
+    const float* f0_scale;    // [64] epilogue constants of the first layer (range factors folded)
+    const float* f0_shift;
+    float f0_in_mul;          // 2^-in_exp applied to the image values
+    int f0_u8;
     unsigned long long* stamp;   // diagnostic builds (-DCV_STAMP=1) only: per-workgroup cycle stamps, else null
 };
 

@@ -380,7 +380,7 @@ size_t Engine::workspace_bytes() const {
 }
 
 Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, const TensorRef* res, bool relu,
-                        hipStream_t s, const Head* head, const TensorRef* pool_out) {
+                        hipStream_t s, const Head* head, const TensorRef* pool_out, const Fuse0* fuse0) {
     if (x.C != L.cinPad) return fail(1, L.name + ": input slice has " + std::to_string(x.C) + " channels, layer packs " + std::to_string(L.cinPad));
     const int esz = dtype_size(dt);
     if (dt == kSplit && (x.Coff % 8 || y.Coff % 8 || (res && res->Coff % 8)))
@@ -441,6 +441,11 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
     const bool halo = L.k == 3 && L.stride == 1 && !L.shuffle && kbase != nullptr && L.nStages % 9 == 0 &&
                       knobs().halo && conv_halo_supported(ct, Ho, Wo) &&
                       blocks_for(L.rows, p.M, ct, 256) >= 128;        // single boards: 128x128 tiles give more workgroups
+    if (fuse0) {
+        if (!halo || !conv_halo_can_fuse_first_layer(ct, dt)) { Status ns; ns.code = kNotFused; return ns; }   // caller runs the layers apart
+        p.f0_x = fuse0->x; p.f0_u8 = fuse0->u8 ? 1 : 0; p.f0_w = fuse0->w; p.f0_scale = fuse0->scale; p.f0_shift = fuse0->shift;
+        p.f0_in_mul = fuse0->in_mul;
+    }
     const bool fuse_pool = pool_out && halo && !head && knobs().fuse_pool;
     if (pool_out) {
         if (pool_out->H * 2 != y.H || pool_out->W * 2 != y.W || pool_out->C != y.C || pool_out->N != y.N)
@@ -463,11 +468,12 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
         // + residual) once, weights once -- at the engine's storage width; the fused head writes one f32 (+ mask byte)
         const double in_px = (L.k == 1 && L.stride == 2) ? (double)p.M : (double)x.N * x.H * x.W;
         const double out_px = L.shuffle ? 4.0 * p.M : (double)p.M;
-        double b = in_px * L.cinPad * esz + (double)L.rows * L.k * L.k * L.cin * esz;
+        double b = (fuse0 ? in_px * (fuse0->u8 ? 3.0 : 12.0) : in_px * L.cinPad * esz) + (double)L.rows * L.k * L.k * L.cin * esz;
         b += head ? (double)p.M * (4 + (head->mask ? 1 : 0)) : out_px * L.cout * esz;
         if (res) b += out_px * L.cout * esz;
         if (pool_out) b += out_px / 4 * L.cout * esz;
-        prof_begin(L.name, true, (double)L.macs_per_out_pixel() * (double)p.M, s, b);
+        prof_begin(fuse0 ? "inc.double_conv.0+3 (fused)" : L.name, true,
+                   ((double)L.macs_per_out_pixel() + (fuse0 ? fuse0->macs_per_pixel : 0.0)) * (double)p.M, s, b);
     }
     hipError_t e = halo ? conv_halo_launch(ct, dt, p, x.N, s) : conv_igemm_launch(cfg, ns, dt, p, s);
     if (profiling) prof_end(s);

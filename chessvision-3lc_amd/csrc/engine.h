@@ -172,10 +172,13 @@ class Engine {
     ~Engine();
 
     struct Head { const float* w; const float* b; float* logits; uint8_t* mask; float thr; };
+    // fused producer of the layer's input (ConvParams::f0_*): the network's first conv computed inside this layer's kernel
+    struct Fuse0 { const void* x; bool u8; const void* w; const float* scale; const float* shift; float in_mul; double macs_per_pixel; };
+    static constexpr int kNotFused = 100;           // run_conv's status code when `fuse0` was requested but the launch cannot take it
     // pool_out: also produce max_pool2d(y, 2) -- fused into the conv epilogue when the halo kernel runs the layer,
     // otherwise by the stand-alone pooling kernel right after it
     Status run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, const TensorRef* res, bool relu,
-                    hipStream_t s, const Head* head = nullptr, const TensorRef* pool_out = nullptr);
+                    hipStream_t s, const Head* head = nullptr, const TensorRef* pool_out = nullptr, const Fuse0* fuse0 = nullptr);
     void prof_begin(const std::string& name, bool is_conv, double macs, hipStream_t s, double bytes = 0);
     void prof_end(hipStream_t s);
     Status prof_collect();

@@ -19,7 +19,9 @@ struct Engine::UNet {
     unsigned up_id[4] = {0, 0, 0, 0}, outc_id = 0;  // numeric-guard ids of the non-conv producers
     DeviceBuffer outc_w, outc_b;
     DeviceBuffer inc0_wpk;                          // f16-based engines: MFMA image of inc.double_conv.0 for the fused first-layer kernel
-    bool fused_inc0 = false;
+    DeviceBuffer inc0_wpk2;                         // split-f16: the same layer for the in-kernel producer of inc.double_conv.3 (conv_halo.hip: FUSE0)
+    bool fused_inc0 = false;                        // first layer + input packing in one kernel (pointwise.hip: inc0_mfma)
+    bool fused_inc = false;                         // first layer produced inside inc.double_conv.3's halo kernel
     // activations
     Activation in8, a_inc0, cat[4], pool[4], dmid[4], bott, umid[4], uout[4];
     std::vector<Activation*> acts;                  // every tensor above that exists in this variant

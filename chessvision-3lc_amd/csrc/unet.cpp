@@ -164,6 +164,31 @@ Status unet_load(Engine& e, const ParamMap& pm) {
                     }
                 }
         CV_TRY(U.inc0_wpk.upload(pk.data(), pk.size() * sizeof(_Float16)));
+        if (dt == kSplit) {
+            // ... and for the producer inside inc.double_conv.3's kernel: two 16-row fragments per 32-channel block, lane
+            // (i, q) of fragment f <-> channel 32*cb + 8*(i/4) + 4*f + i%4, so that a lane ends with the 8 channels of group q
+            const char* v2 = std::getenv("CV_FUSE_INC");
+            U.fused_inc = U.fused_inc0 && !(v2 && v2[0] == '0');
+            std::vector<_Float16> pk2((size_t)2 * 2 * 2 * 64 * 8);
+            for (int cb = 0; cb < 2; ++cb)
+                for (int f = 0; f < 2; ++f)
+                    for (int hl = 0; hl < 2; ++hl)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int i = lane & 15, q = lane >> 4;
+                            const int ch = 32 * cb + 8 * (i / 4) + 4 * f + (i % 4);
+                            float mx = 0.f;
+                            for (int t = 0; t < 27; ++t) mx = std::max(mx, std::fabs(w[ch * 27 + t]));
+                            int ex = 0;
+                            if (mx > 0.f) (void)std::frexp(mx, &ex);
+                            for (int j = 0; j < 8; ++j) {
+                                const int k = q * 8 + j, tap = k / 3, c = k % 3;
+                                const float val = k < 27 ? std::ldexp(w[(ch * 3 + c) * 9 + tap], -ex) : 0.f;
+                                const _Float16 hi = (_Float16)val;
+                                pk2[((((size_t)cb * 2 + f) * 2 + hl) * 64 + lane) * 8 + j] = hl ? (_Float16)(val - (float)hi) : hi;
+                            }
+                        }
+            CV_TRY(U.inc0_wpk2.upload(pk2.data(), pk2.size() * sizeof(_Float16)));
+        }
     }
     for (int i = 0; i < 4; ++i) {
         const std::string p = "down" + std::to_string(i + 1) + ".maxpool_conv.1.double_conv.";
@@ -296,7 +321,7 @@ static Status unet_reserve(Engine& e, int n) {
     U.taps.clear();
     // module-name taps for cv_get_activation (names follow the reference state-dict prefixes)
     if (!U.fused_inc0) U.taps["input"] = U.in8.ref(S, 0, 8);
-    U.taps["inc.double_conv.2"] = U.a_inc0.ref(S);
+    if (!U.fused_inc) U.taps["inc.double_conv.2"] = U.a_inc0.ref(S);     // fused: the tensor exists only inside inc.double_conv.3's kernel
     U.taps["inc.double_conv.5"] = U.cat[0].ref(S, 0, 64);
     U.taps["inc"] = U.taps["inc.double_conv.5"];
     for (int i = 0; i < 4; ++i) {
@@ -346,7 +371,20 @@ static Status unet_chunk(Engine& e, const void* x, bool x_u8, int n, float* logi
     auto begin = [&](const char* name, double bytes = 0) { if (e.profiling) e.prof_begin(name, false, 0, s, bytes); };
     const double esz = dtype_size(dt);
 
-    if (U.fused_inc0) {
+    const TensorRef pool0 = U.pool[0].ref(n);
+    bool inc_done = false;
+    if (U.fused_inc && !e.calibrating) {
+        // inc.double_conv.0 produced inside inc.double_conv.3's kernel: the tensor between them never reaches memory.  (Calibration
+        // runs the layers apart so that the intermediate's exponent is measured; launches the halo tile does not take fall back.)
+        CV_TRY(U.inc0.set_exps(kInputExp, U.a_inc0.exp, s));
+        const Engine::Fuse0 f0{x, x_u8, U.inc0_wpk2.ptr, (const float*)U.inc0.scale.ptr, (const float*)U.inc0.shift.ptr,
+                               std::ldexp(1.f, -kInputExp), 27.0 * 64};
+        Status st = e.run_conv(U.inc1, U.a_inc0.ref(n), U.cat[0].ref(n, 0, 64), nullptr, true, s, nullptr, &pool0, &f0);
+        if (st.ok()) inc_done = true;
+        else if (st.code != Engine::kNotFused) return st;
+    }
+    if (inc_done) {
+    } else if (U.fused_inc0) {
         // first layer straight from the caller's image: no packed copy of the input, no separate packing kernel
         CV_TRY(U.inc0.set_exps(kInputExp, U.a_inc0.exp, s));
         if (e.profiling) e.prof_begin(U.inc0.name, true, 27.0 * 64 * 65536 * n, s, (double)n * 65536 * ((x_u8 ? 3 : 12) + 64 * esz) + 27 * 64 * esz);
@@ -360,8 +398,7 @@ static Status unet_chunk(Engine& e, const void* x, bool x_u8, int n, float* logi
         CV_TRY(e.run_conv(U.inc0, U.in8.ref(n, 0, 8), U.a_inc0.ref(n), nullptr, true, s));
     }
     // every encoder level's second conv also emits its 2x2 max-pool (fused into the epilogue where the halo kernel runs)
-    const TensorRef pool0 = U.pool[0].ref(n);
-    CV_TRY(e.run_conv(U.inc1, U.a_inc0.ref(n), U.cat[0].ref(n, 0, 64), nullptr, true, s, nullptr, &pool0));
+    if (!inc_done) CV_TRY(e.run_conv(U.inc1, U.a_inc0.ref(n), U.cat[0].ref(n, 0, 64), nullptr, true, s, nullptr, &pool0));
     for (int i = 0; i < 4; ++i) {
         CV_TRY(e.run_conv(U.d[i][0], U.pool[i].ref(n), U.dmid[i].ref(n), nullptr, true, s));
         TensorRef out = (i < 3) ? U.cat[i + 1].ref(n, 0, enc_c[i + 1]) : U.bott.ref(n);

@@ -121,3 +121,66 @@ def test_all_reference_label_masks_give_their_annotated_corners(find_quadrangle)
     assert worst <= 2.0, worst
     for i in range(0, 631, 40):
         assert _same(quads[i], ChessVision._find_quadrangle(masks[i]))
+
+
+# ---- borderline cases of the reference's filter / simplification rules (core.py:357-411), C++ == numpy restatement --------------
+# Both implementations trace every border pixel (CHAIN_APPROX_NONE); the reference asks OpenCV for CHAIN_APPROX_TC89_KCOS, whose
+# dominant-point chain is what contourArea / arcLength / approxPolyDP then see.  The area of the compressed polygon is the same to
+# within the boundary pixels; its perimeter is up to ~8 % shorter on slanted edges (an 8-connected chain overestimates the length
+# of an edge at ~22 degrees by that much), so epsilon = 10 % of the perimeter differs by at most that factor.  These cases sit
+# where such a difference could matter and pin what this port does there.
+def _blank(size=256):
+    return np.zeros((size, size), np.uint8)
+
+
+def _both(find_quadrangle, mask):
+    a, b = find_quadrangle(mask), ChessVision._find_quadrangle(mask)
+    assert _same(a, b)
+    return a
+
+
+def test_area_share_threshold_applies_only_with_several_contours(find_quadrangle):
+    size = 256
+    for side, expect in ((154, True), (150, False)):         # 154^2 / 256^2 = 0.362 >= 0.35 ; 150^2 / 256^2 = 0.343 < 0.35
+        m = _blank(size)
+        m[20:20 + side, 30:30 + side] = 255
+        m[230:236, 230:236] = 255                             # a second contour switches the area / box filter on
+        assert (_both(find_quadrangle, m) is not None) == expect
+        m[230:236, 230:236] = 0                               # alone, the same small square is accepted: no filter with one contour
+        assert _both(find_quadrangle, m) is not None
+
+
+def test_box_ratio_threshold(find_quadrangle):
+    for h, w, expect in ((170, 250, True), (146, 250, False)):    # 170/250 = 0.68 >= 0.6 ; 146/250 = 0.584 < 0.6 (area share 0.56)
+        m = _blank()
+        m[10:10 + h, 3:3 + w] = 255
+        m[240:246, 120:126] = 255
+        assert (_both(find_quadrangle, m) is not None) == expect
+
+
+def test_cut_corner_becomes_a_fifth_vertex_only_when_it_exceeds_epsilon(find_quadrangle):
+    yy, xx = np.mgrid[0:256, 0:256]
+    for cut, expect in ((40, True), (120, False)):            # perimeter ~800 -> epsilon ~80 px: a 40 px bevel is absorbed, a 120 px one is not
+        m = _blank()
+        m[28:228, 28:228] = 255
+        m[(xx - 28) + (yy - 28) < cut] = 0                    # bevel the top-left corner
+        q = _both(find_quadrangle, m)
+        assert (q is not None) == expect
+
+
+def test_rotated_board_vertex_order(find_quadrangle):
+    """A board rotated by ~30 degrees: four vertices, list starts at the right-most of the two top corners and runs
+    counter-clockwise on screen (reference _rotate_quadrangle, core.py:399-411)."""
+    yy, xx = np.mgrid[0:256, 0:256].astype(np.float64)
+    t = np.deg2rad(30.0)
+    u = (xx - 128) * np.cos(t) + (yy - 128) * np.sin(t)
+    v = -(xx - 128) * np.sin(t) + (yy - 128) * np.cos(t)
+    m = np.where((np.abs(u) < 80) & (np.abs(v) < 80), 255, 0).astype(np.uint8)
+    q = _both(find_quadrangle, m).reshape(4, 2)
+    assert q[0, 0] >= q[2, 0]                                  # the rotation rule's postcondition
+    cross = sum(q[i, 0] * q[(i + 1) % 4, 1] - q[(i + 1) % 4, 0] * q[i, 1] for i in range(4))
+    assert cross < 0                                           # counter-clockwise on screen (y down)
+    corners = np.array([[128 + 80 * (sx * np.cos(t) - sy * np.sin(t)), 128 + 80 * (sx * np.sin(t) + sy * np.cos(t))]
+                        for sx, sy in ((1, -1), (-1, -1), (-1, 1), (1, 1))])
+    for c in corners:
+        assert np.min(np.hypot(*(q - c).T)) <= 3.0
