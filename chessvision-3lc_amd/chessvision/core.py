@@ -241,17 +241,18 @@ class ChessVision:
         if pool is None:
             pool = self._copy_pool = ThreadPoolExecutor(max_workers=16, thread_name_prefix="cv-stage")
 
-        def segment(ids):                                   # host -> device (own stream), resize, UNet; masks start back
+        def segment(ids, slice_upload=False):               # host -> device (own stream), resize, UNet; masks start back
             t0 = time.perf_counter()
             shape = images[ids[0]].shape
             staged = pinned((len(ids),) + shape, torch.uint8)
             view = staged.numpy()
             with torch.cuda.stream(up):
                 batch = torch.empty((len(ids),) + shape, dtype=torch.uint8, device=dev)
-            # staged and uploaded in slices of 16 images: the upload of a slice overlaps the host copies of the next one (what
-            # matters for the first job of a call, whose staging nothing else hides)
-            for k0 in range(0, len(ids), 16):
-                k1 = min(len(ids), k0 + 16)
+            # the first job of a call is staged and uploaded in slices of 16 images (the upload of a slice overlaps the host copies
+            # of the next one: nothing else hides that job's staging); later jobs are staged in one go behind the GPU's work
+            step_ = 16 if slice_upload else len(ids)
+            for k0 in range(0, len(ids), step_):
+                k1 = min(len(ids), k0 + step_)
                 list(pool.map(lambda k: np.copyto(view[k], images[ids[k]]), range(k0, k1)))
                 with torch.cuda.stream(up):
                     batch[k0:k1].copy_(staged[k0:k1], non_blocking=True)
@@ -352,7 +353,7 @@ class ChessVision:
             st["keep"] = st["keep2"] = None
 
         # software pipeline over the jobs: segment(k+1) is enqueued before the host works on job k
-        seg = segment(jobs[0])
+        seg = segment(jobs[0], slice_upload=True)
         cls = None
         for k in range(len(jobs)):
             nxt = segment(jobs[k + 1]) if k + 1 < len(jobs) else None

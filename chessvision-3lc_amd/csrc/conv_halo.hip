@@ -780,7 +780,8 @@ static hipError_t prepare_halo() {
 #define CV_FOR_EACH_HALO(X, T)                \
     X(T, 64, CV_HALO_TH64, 1, 4, 1, CV_HALO_NSW64, 0)    \
     X(T, 128, 16, 2, 8, 1, CV_HALO_NSW128, 0) \
-    X(T, 128, 16, 2, 8, 1, 3, 8)
+    X(T, 128, 16, 2, 8, 1, 3, 8)              \
+    X(T, 64, 16, 1, 4, 1, 3, 8)
 
 hipError_t conv_halo_prepare() {
     hipError_t e;
@@ -803,7 +804,9 @@ bool conv_halo_can_fuse_first_layer(int ct, int dt) { return ct == 64 && CV_HALO
 bool conv_halo_supported(int ct, int Ho, int Wo) {
     static const bool allow64 = [] { const char* v = std::getenv("CV_HALO64"); return !(v && v[0] == '0'); }();
     static const bool allow_img8 = [] { const char* v = std::getenv("CV_HALO_IMG8"); return !(v && v[0] == '0'); }();
+    static const bool img8_64 = [] { const char* v = std::getenv("CV_HALO_IMG8_64"); return v && v[0] == '1'; }();
     if (ct == 128 && Ho == 8 && Wo == 8) return allow_img8;
+    if (ct == 64 && Ho == 8 && Wo == 8) return allow_img8 && img8_64 && CV_HALO_TH64 == 16;
     return (ct == 128 || (ct == 64 && allow64)) && Ho % 16 == 0 && Wo % 16 == 0;
 }
 

@@ -95,7 +95,7 @@ static void pack_rows(int dt, std::vector<char>& out, int CT, int nCt, int nStag
 
 static Status finish_layer(ConvLayer& L, std::vector<float>& Wk, int K, const std::vector<float>& scale,
                            const std::vector<float>& shift) {
-    const int CT = L.ct = choose_ct(L.rows, L.pixels_hint, L.halo_ok);
+    const int CT = L.ct = choose_ct(L.rows, L.pixels_hint, L.halo_ok, L.halo_img8);
     L.nStages = (chunks_for(L.dt, K) + 7) / 8;
     L.nCt = (L.rows + CT - 1) / CT;
     L.rowsPad = L.nCt * CT;
@@ -181,6 +181,7 @@ Status ConvLayer::build_conv(const std::string& name_, int dt_, const float* w_o
     shuffle = false; rows = cout_; pixels_hint = pixels_hint_;
     halo_ok = k_ == 3 && stride_ == 1 && out_hw_ > 0 && (out_hw_ % 16 == 0 || (out_hw_ == 8 && cout_ % 128 == 0)) &&
               cinPad_ % (128 / dtype_size(dt_)) == 0;
+    halo_img8 = out_hw_ == 8;
     if (cinPad % 8 || cinPad < cin) return fail(1, name + ": input channel padding must be a multiple of 8");
     if (k != 1 && k != 3) return fail(1, name + ": implicit-GEMM path supports 1x1 and 3x3 kernels");
     if (cout % 16) return fail(1, name + ": output channels must be a multiple of 16");
@@ -285,7 +286,14 @@ static int env_cached(int idx) {                      // 0: CV_CONV_W8, 1: CV_CO
 // channel-tile height of a layer: fixed at pack time (weights are packed per channel tile).  256-row tiles (fewest
 // L2->LDS bytes per MFMA: the r01 ablation shows the DMA side alone costs 60-85 % of a layer's time) are used when
 // the layer still fills the chip with 256x256 workgroups at the engine's chunk size.
-int choose_ct(int rows, int64_t pixels_hint, bool halo_ok) {
+int choose_ct(int rows, int64_t pixels_hint, bool halo_ok, bool img8) {
+    // The 64-row halo tile (4 waves, single halo buffer, two workgroups per CU) beats the 128-row 8-wave tile on every UNet layer it
+    // was tried on, 64 to 1024 output channels (r02_tuning.md step 14: two resident workgroups cover each other's barrier, DMA-issue
+    // and epilogue phases; the halo of a patch is simply fetched once per 64-channel tile, from L2).  The 128-row tile remains for
+    // the packed 8x8-image mode (ResNet-18 layer2).  CV_CT64_MAXROWS=64 restores round 1's choice for A/B runs.
+    static const int ct64_max_rows = env_int("CV_CT64_MAXROWS", 1024);
+    static const int img8_64 = env_int("CV_HALO_IMG8_64", 0);        // experiment: the packed 8x8-image mode on the 64-row tile too
+    if (halo_ok && knobs().halo && (!img8 || img8_64) && rows <= ct64_max_rows && rows % 64 == 0) return 64;
     if (halo_ok && knobs().halo) return rows % 128 == 0 ? 128 : 64;   // the halo kernel has 64- and 128-row tiles
     if (rows % 256 == 0 && knobs().ct256 && blocks_for(rows, pixels_hint, 256, 256) >= knobs().ct256_min_blocks)
         return 256;

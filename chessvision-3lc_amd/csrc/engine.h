@@ -95,6 +95,7 @@ struct ConvLayer {
     int rows = 0, rowsPad = 0, nStages = 0, nCt = 0;
     int ct = 64;                                    // channel-tile height the weights are packed for (64 | 128)
     bool halo_ok = false;                           // 3x3 s1 on a 16-divisible square grid: conv_halo.hip tiles (64 | 128 rows)
+    bool halo_img8 = false;                         // ... on 8x8 feature maps: the packed-image mode of the 128-row tile
     int64_t pixels_hint = 0;                        // output pixels per launch at the engine's chunk size (tile choice)
     int kgroup = 8;                                 // input channels per K block (see engine.cpp: K ordering)
     int dt = kF16;
@@ -186,7 +187,7 @@ class Engine {
 };
 
 bool calibration_enabled();                         // CV_CALIBRATE=0 switches the activation exponents off (tests of the guard)
-int choose_ct(int rows, int64_t pixels_hint, bool halo_ok);
+int choose_ct(int rows, int64_t pixels_hint, bool halo_ok, bool img8);
 int choose_cfg(int ct, int rows, int64_t pixels, int n_stages);
 int choose_ns(int cfg, int dt, int rows, int64_t pixels, int n_stages);
 
