@@ -804,7 +804,7 @@ bool conv_halo_can_fuse_first_layer(int ct, int dt) { return ct == 64 && CV_HALO
 bool conv_halo_supported(int ct, int Ho, int Wo) {
     static const bool allow64 = [] { const char* v = std::getenv("CV_HALO64"); return !(v && v[0] == '0'); }();
     static const bool allow_img8 = [] { const char* v = std::getenv("CV_HALO_IMG8"); return !(v && v[0] == '0'); }();
-    static const bool img8_64 = [] { const char* v = std::getenv("CV_HALO_IMG8_64"); return v && v[0] == '1'; }();
+    static const bool img8_64 = [] { const char* v = std::getenv("CV_HALO_IMG8_64"); return !(v && v[0] == '0'); }();
     if (ct == 128 && Ho == 8 && Wo == 8) return allow_img8;
     if (ct == 64 && Ho == 8 && Wo == 8) return allow_img8 && img8_64 && CV_HALO_TH64 == 16;
     return (ct == 128 || (ct == 64 && allow64)) && Ho % 16 == 0 && Wo % 16 == 0;

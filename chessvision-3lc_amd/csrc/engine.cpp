@@ -292,7 +292,7 @@ int choose_ct(int rows, int64_t pixels_hint, bool halo_ok, bool img8) {
     // and epilogue phases; the halo of a patch is simply fetched once per 64-channel tile, from L2).  The 128-row tile remains for
     // the packed 8x8-image mode (ResNet-18 layer2).  CV_CT64_MAXROWS=64 restores round 1's choice for A/B runs.
     static const int ct64_max_rows = env_int("CV_CT64_MAXROWS", 1024);
-    static const int img8_64 = env_int("CV_HALO_IMG8_64", 0);        // experiment: the packed 8x8-image mode on the 64-row tile too
+    static const int img8_64 = env_int("CV_HALO_IMG8_64", 1);        // the packed 8x8-image mode (ResNet-18 layer2) on the 64-row tile too: +3-7 %
     if (halo_ok && knobs().halo && (!img8 || img8_64) && rows <= ct64_max_rows && rows % 64 == 0) return 64;
     if (halo_ok && knobs().halo) return rows % 128 == 0 ? 128 : 64;   // the halo kernel has 64- and 128-row tiles
     if (rows % 256 == 0 && knobs().ct256 && blocks_for(rows, pixels_hint, 256, 256) >= knobs().ct256_min_blocks)
