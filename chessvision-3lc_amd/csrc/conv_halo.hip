@@ -763,9 +763,12 @@ static hipError_t prepare_halo() {
 // configurations: 64 channels x 16x16 patch (4 waves, four patch rows each), one tap per stage, ring 3, ONE halo buffer: 68 KB,
 //                 so two workgroups share a CU; each fills the other's barrier stalls and its halo refill at the channel-block
 //                 boundaries (r02_tuning.md: +8-16 % over the double-buffered 8x16 patch of round 1, which did half the MFMAs per
-//                 weight byte and per fragment read; -DCV_HALO_TH64=8 builds that tile);
-//                 128 channels x 16x16 patch (8 waves as 2 x 4, four patch rows each), one tap per stage, ring 3;
-//                 the same 128-channel tile over four packed 8x8 images (ResNet-18 layer2).
+//                 weight byte and per fragment read; -DCV_HALO_TH64=8 builds that tile).  THE production tile: layers of any
+//                 width run it as Cout/64 channel tiles (engine.cpp: choose_ct), with the fused first-layer producer for
+//                 UNet inc (FUSE0) and over four packed 8x8 images for ResNet-18 layer2;
+//                 128 channels x 16x16 patch (8 waves as 2 x 4, four patch rows each, halo double buffered, persistent for short
+//                 K) and its packed-image form: round 1's tile for Cout >= 128, now an A/B option (CV_CT64_MAXROWS=64,
+//                 CV_HALO_IMG8_64=0) -- one 136 KB workgroup per CU loses to two 68 KB ones at every width (r02_tuning.md step 14).
 // (Measured and dropped: an 8-wave 64 x 16x16 variant, -10 % (r01_tuning.md step 17); the 16x16 patch with a double-buffered halo
 //  and therefore one workgroup per CU, -8..-17 %; a 4-deep weight ring, +-1 % (r02_tuning.md).)
 #ifndef CV_HALO_NSW64
