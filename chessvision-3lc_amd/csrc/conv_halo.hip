@@ -78,20 +78,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // experiments (CV_TUNE): static priority that differs between the two waves sharing a SIMD, so that they stop running in
-    // lockstep (both in their MFMA phase, then both in their DMA / barrier phase)
-    if (NW == 4 && (p.tune & 1)) {                       // 4-wave tile, two workgroups per CU: by wave slot parity
-        if (__builtin_amdgcn_s_getreg(6148) & 1u) __builtin_amdgcn_s_setprio(2);     // HW_REG_HW_ID[3:0] = wave slot of the SIMD
-    }
-    if (NW == 4 && (p.tune & 2)) {                       // ... by dispatch generation of the workgroup
-        if ((blockIdx.x >> 8) & 1u) __builtin_amdgcn_s_setprio(2);
-    }
-    if (NW == 8 && (p.tune & 4)) {                       // 8-wave tile: the younger half (waves 4..7) wins arbitration
-        if (wave >= 4) __builtin_amdgcn_s_setprio(1);
-    }
-    if (NW == 8 && (p.tune & 8)) {
-        if (wave < 4) __builtin_amdgcn_s_setprio(1);
-    }
     const unsigned nwg = gridDim.x, bid = blockIdx.x;   // XCD-aware remap, as in conv_igemm.hip
     const unsigned xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
     const unsigned lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);

@@ -86,7 +86,6 @@ struct ConvParams {
     // with atomicMin; the host turns it into CV_ERR_NUMERIC naming the layer (cv_engine_numeric_status).  Null = off.
     unsigned* flag;
     unsigned layer_id;
-    int tune;                 // experiment bits (CV_TUNE), 0 in production
     // optional fused producer (conv_halo.hip, 64-channel single-halo tile only): the 64-channel input of THIS layer is never read
     // from memory -- every workgroup computes the haloed patch it needs in LDS from the caller's 3-channel image with the
     // network's first conv + BN + ReLU (UNet inc.double_conv.0).  Null f0_x = off.

@@ -426,8 +426,6 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
     }
     p.flag = guard_ptr();
     p.layer_id = L.layer_id;
-    static const int tune = env_int("CV_TUNE", 0);
-    p.tune = tune;
     p.y = reinterpret_cast<char*>(y.base);
     p.M = x.N * Ho * Wo; p.Ho = Ho; p.Wo = Wo;
     p.xHp = x.H + 2; p.xWp = x.W + 2; p.stride = L.stride; p.xCs = x.Cs; p.xCoffBytes = x.Coff * esz;
