@@ -72,6 +72,7 @@ SYMBOLS = [
                               ctypes.POINTER(_i)]),
     ("cv_op_conv2d", _i, [_vp, _vp, _i, _i, _i, _i, _fp, _i, _i, _i, _fp, _fp, _vp, _i, _vp, _vp]),
     ("cv_op_conv_transpose2x2", _i, [_vp, _vp, _i, _i, _i, _i, _fp, _i, _fp, _vp, _vp]),
+    ("cv_op_outc_1x1", _i, [_vp, _vp, _i, _i, _i, _i, _fp, _fp, _f, _vp, _vp, _vp]),
     ("cv_op_maxpool2x2", _i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     ("cv_op_maxpool3x3s2", _i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     ("cv_op_upsample_bilinear2x", _i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
@@ -421,6 +422,17 @@ class HipEngine:
         _check(self._lib.cv_op_conv_transpose2x2(self._h, _ptr(x), n, cin, h, wd, w.ctypes.data_as(_fp), cout,
                                                  bias.ctypes.data_as(_fp), _ptr(y), _stream_ptr(self.device)))
         return y
+
+    def op_outc_1x1(self, x, w, bias, threshold: float = 0.5):
+        """(n,c,h,w) -> (logits (n,1,h,w) f32, mask (n,h,w) u8) through the stand-alone OutConv kernel."""
+        x = x.to(self.device, torch.float32).contiguous()
+        w, bias = _np_f32(w).reshape(-1), _np_f32(bias).reshape(-1)
+        n, c, h, wd = x.shape
+        logits = torch.empty((n, 1, h, wd), dtype=torch.float32, device=self.device)
+        mask = torch.empty((n, h, wd), dtype=torch.uint8, device=self.device)
+        _check(self._lib.cv_op_outc_1x1(self._h, _ptr(x), n, c, h, wd, w.ctypes.data_as(_fp), bias.ctypes.data_as(_fp),
+                                        float(threshold), _ptr(logits), _ptr(mask), _stream_ptr(self.device)))
+        return logits, mask
 
     def _op_pool(self, fn, x, ho, wo) -> torch.Tensor:
         x = x.to(self.device, torch.float32).contiguous()

@@ -367,6 +367,36 @@ static int pool_like(cv_engine_t* eng, const float* x, int n, int c, int h, int 
     return finish(s);
 }
 
+// conv 1x1 C -> 1 + bias (+ sigmoid / threshold mask): the stand-alone OutConv kernel, as a single-layer entry point
+static int impl_cv_op_outc_1x1(cv_engine_t* eng, const float* x, int n, int c, int h, int w_, const float* w_host, const float* bias_host,
+                               float threshold, float* logits, uint8_t* mask, void* stream) {
+    Status s = check_engine(eng);
+    if (!s.ok()) return finish(s);
+    if (!x || !w_host || !bias_host || !logits || n <= 0 || c <= 0 || h <= 0 || w_ <= 0)
+        return finish(fail(CV_ERR_INVALID, "cv_op_outc_1x1: bad argument"));
+    std::lock_guard<std::mutex> lk(eng->impl.mu);
+    DeviceGuard g(eng->impl.device);
+    Engine& e = eng->impl;
+    hipStream_t st = (hipStream_t)stream;
+    const int cp = round_up(c, 8);
+    const int lpp = cp / dtype_group(e.dt);
+    if (lpp > 64 || (lpp & (lpp - 1))) return finish(fail(CV_ERR_INVALID, "cv_op_outc_1x1: channel count must give a power-of-two lane group <= 64"));
+    std::vector<float> wpad(cp, 0.f);
+    std::copy(w_host, w_host + c, wpad.begin());
+    Activation ax;
+    DeviceBuffer dw, db;
+    if ((s = ax.create(n, h, w_, cp, e.dt)).ok() && (s = dw.upload(wpad.data(), cp * sizeof(float))).ok() &&
+        (s = db.upload(bias_host, sizeof(float))).ok()) {
+        hipError_t err = pack_nchw_f32(e.dt, x, c, ax.ref(n), e.guard_ptr(), st);
+        if (err == hipSuccess)
+            err = outc_1x1(e.dt, ax.ref(n), (const float*)dw.ptr, (const float*)db.ptr, logits, mask, threshold, e.guard_ptr(),
+                           e.register_layer("op_outc_1x1"), st);
+        if (err == hipSuccess) err = hipStreamSynchronize(st);
+        if (err != hipSuccess) s = hip_fail(err, "cv_op_outc_1x1");
+    }
+    return finish(s);
+}
+
 static int impl_cv_op_maxpool2x2(cv_engine_t* eng, const float* x, int n, int c, int h, int w_, float* y, void* stream) {
     return pool_like(eng, x, n, c, h, w_, h / 2, w_ / 2, y, stream, maxpool2x2, "cv_op_maxpool2x2");
 }
@@ -639,6 +669,13 @@ int cv_extract_squares_u8(cv_engine_t* eng, const uint8_t* images, int n, int h,
 
 int cv_selftest_mfma(cv_engine_t* eng, float* max_err_f16, float* max_err_f32) {
     return guarded("cv_selftest_mfma", [&]() -> int { return impl_cv_selftest_mfma(eng, max_err_f16, max_err_f32); });
+}
+
+int cv_op_outc_1x1(cv_engine_t* eng, const float* x, int n, int c, int h, int w_, const float* w_host, const float* bias_host,
+                   float threshold, float* logits, uint8_t* mask, void* stream) {
+    return guarded("cv_op_outc_1x1", [&]() -> int {
+        return impl_cv_op_outc_1x1(eng, x, n, c, h, w_, w_host, bias_host, threshold, logits, mask, stream);
+    });
 }
 
 int cv_profile_entry_bytes(cv_engine_t* eng, int index, double* bytes) {

@@ -165,6 +165,10 @@ int cv_op_conv2d(cv_engine_t* eng, const float* x, int n, int cin, int h, int w_
 /*   conv-transpose k2 s2:  y(n,cout,2h,2w) = convT(x, w) + bias;  w: HOST (cin,cout,2,2) */
 int cv_op_conv_transpose2x2(cv_engine_t* eng, const float* x, int n, int cin, int h, int w_,
                             const float* w_host, int cout, const float* bias_host, float* y, void* stream);
+/*   conv 1x1 c -> 1 + bias: logits (n,1,h,w) float32; mask (nullable, n x h x w uint8) = sigmoid(logit) > threshold ? 255 : 0
+ *   (the stand-alone OutConv kernel; the model path fuses it into the last conv's epilogue).  w: HOST (c), bias: HOST (1) */
+int cv_op_outc_1x1(cv_engine_t* eng, const float* x, int n, int c, int h, int w_, const float* w_host, const float* bias_host,
+                   float threshold, float* logits, uint8_t* mask, void* stream);
 int cv_op_maxpool2x2(cv_engine_t* eng, const float* x, int n, int c, int h, int w_, float* y, void* stream);
 int cv_op_maxpool3x3s2(cv_engine_t* eng, const float* x, int n, int c, int h, int w_, float* y, void* stream);
 int cv_op_upsample_bilinear2x(cv_engine_t* eng, const float* x, int n, int c, int h, int w_, float* y,

@@ -103,3 +103,29 @@ def test_stem_and_head_ops_through_the_model(engines):
     act1 = eng.activation("resnet18", "act1")
     assert np.abs(act1 - d["stem_y"]).max() <= 1e-4
     eng.close()
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3", "f16"])
+def test_outconv_golden_vector_and_edge_logits(prec):
+    """ops.npz `outc_*` (conv 1x1 64 -> 1 + bias) and the edge logits of the sigmoid/threshold rule (core.py:273, utils.py:101-112)
+    through the stand-alone OutConv kernel.  The edge logits travel in channel 0 with weight 1 (exact in the f32 engine); |logit|
+    <= 1e-7 sits within one ulp of sigmoid = 0.5, where the device's exp-based sigmoid may round to the other side of the threshold."""
+    from chessvision.hip_backend import HipEngine
+
+    d = np.load(G / "ops.npz")
+    eng = HipEngine(precision=prec)
+    logits, _ = eng.op_outc_1x1(torch.from_numpy(d["outc_x"]), d["outc_w"], d["outc_b"])
+    tol = 1e-5 if prec != "f16" else 2e-2
+    assert np.abs(logits.cpu().numpy() - d["outc_y"]).max() <= tol
+    edge = d["edge_logits"]
+    x = torch.zeros(1, 8, 1, len(edge))
+    x[0, 0, 0] = torch.from_numpy(edge)
+    w = np.zeros(8, np.float32)
+    w[0] = 1.0
+    lg, mk = eng.op_outc_1x1(x, w, np.zeros(1, np.float32), threshold=0.5)
+    eng.close()
+    decided = np.abs(edge) > 1e-7                                  # 0.0 itself is decided too: sigmoid(0) == 0.5 exactly -> 0
+    decided[0] = True
+    assert mk.cpu().numpy().reshape(-1)[decided].tolist() == d["edge_mask"][decided].tolist()
+    if prec == "f32":
+        assert np.array_equal(lg.cpu().numpy().reshape(-1), edge)
