@@ -49,6 +49,14 @@ __device__ __forceinline__ void glds16(const char* g, char* l) {
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
+// the same with the address split into a wave-uniform base and a per-lane 32-bit byte offset: lets the compiler pick the
+// SGPR-base form of the instruction, so the per-piece 64-bit address arithmetic runs on the scalar unit instead of taking vector
+// issue slots that the MFMAs of both resident waves share
+__device__ __forceinline__ void glds16s(const char* sbase, unsigned voff, char* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sbase + voff),
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
 template <int N> __device__ __forceinline__ void wait_vm_barrier() {
     // every wave: its own DMA of the stage about to be read has landed (all but N younger ones), its
     // LDS reads of the stage about to be overwritten have returned; then the workgroup rendezvous.

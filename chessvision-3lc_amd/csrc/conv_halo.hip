@@ -88,7 +88,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     // the tile the DMA side works on (in a persistent workgroup that is already the NEXT tile during an epilogue)
     int ctTile, tx, ty, n;
     unsigned hbase;
-    const char* wsrc;
+    const char* wsrc;                                   // wave-uniform: this wave's first weight piece of the tile (stage 0)
+    // 4-wave tiles have registers to spare: the byte offsets of this lane's halo rows are computed once per tile instead of
+    // once per channel block (a divide by 18 and a swizzle per piece: ~14 vector instructions x 11 pieces in one stage)
+    constexpr bool kHoistHalo = NW == 4;
+    unsigned hoff[kHoistHalo ? H : 1];
 
     // DMA sources of this lane's halo rows: row r of the halo <-> padded input pixel (ty*TH + r/18, tx*16 + r%18).
     // Needed once per channel block only, so they are re-derived at each use (the lane id is made opaque to keep LICM
@@ -98,6 +102,21 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const bool is_w = !kRoles || wave < NWI;            // this wave moves weight stages / halo pieces
     const bool is_h = !kRoles || wave >= NWI;
     const int wi = kRoles && wave >= NWI ? wave - NWI : wave;     // index among the waves of its role
+    const unsigned lane16 = (unsigned)lane * 16u;
+    // byte offset (from xsrc, channel block 0) of the halo row this lane moves in piece i
+    auto halo_row_offset = [&](int i) __attribute__((always_inline)) -> unsigned {
+        const int r = (i * NWI + wi) * 8 + (lane >> 3);
+        const int rr = r < HR ? r : HR - 1;             // rows of the padded tail re-read the last real one
+        if constexpr (IMG == 0) {
+            const int hy = rr / 18, hx = rr - hy * 18;
+            return (hbase + (unsigned)(hy * p.xWp + hx)) * xpix + (unsigned)(((lane & 7) ^ (hx & 7)) * 16);
+        } else {                                         // 400 consecutive pixels; images past the batch re-read the last one
+            const int lim = (nImg - n) * (HLW * HLW) - 1;
+            const int rc = rr < lim ? rr : lim;
+            const int hx = (rr % (HLW * HLW)) % HLW;
+            return (unsigned)(n * (HLW * HLW) + rc) * xpix + (unsigned)(((lane & 7) ^ (hx & 7)) * 16);
+        }
+    };
     auto decode = [&](unsigned tile) __attribute__((always_inline)) {
         ctTile = tile % p.nCt;
         int pt = tile / p.nCt;
@@ -105,35 +124,47 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         ty = pt % tilesY;
         n = IMG ? 4 * (pt / tilesY) : pt / tilesY;      // (first) image of the tile
         hbase = (unsigned)((n * p.xHp + ty * TH) * p.xWp + tx * 16);
-        wsrc = p.w + (size_t)ctTile * p.nStages * WTAP + wi * 1024 + lane * 16;
+        wsrc = p.w + (size_t)ctTile * p.nStages * WTAP + wi * 1024;
+        if constexpr (kHoistHalo) {
+#pragma unroll
+            for (int i = 0; i < H; ++i) hoff[i] = halo_row_offset(i);
+        }
     };
 
     const int q = lane >> 4, l15 = lane & 15;
     auto issue_w = [&](int s, int slot) __attribute__((always_inline)) {
         char* sW = smem + slot * WSTAGE;
 #pragma unroll
-        for (int i = 0; i < LW; ++i) glds16(wsrc + (size_t)s * WSTAGE + i * (NWI * 1024), sW + (i * NWI + wi) * 1024);   // stage s = TPS consecutive taps
+        for (int i = 0; i < LW; ++i) glds16s(wsrc + (size_t)s * WSTAGE + i * (NWI * 1024), lane16, sW + (i * NWI + wi) * 1024);   // stage s = TPS consecutive taps
     };
     auto issue_halo = [&](int cb, int hb, auto i0_tag, auto n_tag) __attribute__((always_inline)) {          // pieces [I0, I0 + N) of this wave's H
         constexpr int I0 = decltype(i0_tag)::value, N = decltype(n_tag)::value;
         char* sH = halo + hb * HBYTES;
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
+        const char* const src = xsrc + cb * 128;        // wave-uniform base of this channel block
+        if constexpr (kHoistHalo) {
 #pragma unroll
-        for (int i = I0; i < I0 + N && i < H; ++i) {
-            const int r = (i * NWI + wi) * 8 + (ln >> 3);
-            const int rr = r < HR ? r : HR - 1;         // rows of the padded tail re-read the last real one
-            unsigned off;
-            if constexpr (IMG == 0) {
-                const int hy = rr / 18, hx = rr - hy * 18;
-                off = (hbase + (unsigned)(hy * p.xWp + hx)) * xpix + (unsigned)(((ln & 7) ^ (hx & 7)) * 16);
-            } else {                                     // 400 consecutive pixels; images past the batch re-read the last one
-                const int lim = (nImg - n) * (HLW * HLW) - 1;
-                const int rc = rr < lim ? rr : lim;
-                const int hx = (rr % (HLW * HLW)) % HLW;
-                off = (unsigned)(n * (HLW * HLW) + rc) * xpix + (unsigned)(((ln & 7) ^ (hx & 7)) * 16);
+            for (int i = I0; i < I0 + N && i < H; ++i) glds16s(src, hoff[i], sH + (i * NWI + wi) * 1024);
+        } else {
+            // 8-wave tiles sit at the register limit: the offsets are re-derived at each use (needed once per channel block; the
+            // lane id is made opaque to keep LICM from parking H more VGPRs across the whole K loop)
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+#pragma unroll
+            for (int i = I0; i < I0 + N && i < H; ++i) {
+                const int r = (i * NWI + wi) * 8 + (ln >> 3);
+                const int rr = r < HR ? r : HR - 1;     // rows of the padded tail re-read the last real one
+                unsigned off;
+                if constexpr (IMG == 0) {
+                    const int hy = rr / 18, hx = rr - hy * 18;
+                    off = (hbase + (unsigned)(hy * p.xWp + hx)) * xpix + (unsigned)(((ln & 7) ^ (hx & 7)) * 16);
+                } else {                                 // 400 consecutive pixels; images past the batch re-read the last one
+                    const int lim = (nImg - n) * (HLW * HLW) - 1;
+                    const int rc = rr < lim ? rr : lim;
+                    const int hx = (rr % (HLW * HLW)) % HLW;
+                    off = (unsigned)(n * (HLW * HLW) + rc) * xpix + (unsigned)(((ln & 7) ^ (hx & 7)) * 16);
+                }
+                glds16s(src, off, sH + (i * NWI + wi) * 1024);
             }
-            glds16(xsrc + off + cb * 128, sH + (i * NWI + wi) * 1024);
         }
     };
 
