@@ -76,6 +76,20 @@ template <int N> struct OutVec<half_t, N> {
             *reinterpret_cast<half8*>(dst + i) = h;
         }
     }
+    // residual already in registers (kRawChunks 16-byte chunks per unit, fetched ahead of the epilogue)
+    static constexpr int kRawChunks = N / 8;
+    static __device__ __forceinline__ void fetch(const half_t* src, f4* raw) {
+#pragma unroll
+        for (int i = 0; i < N / 8; ++i) raw[i] = *reinterpret_cast<const f4*>(src + i * 8);
+    }
+    static __device__ __forceinline__ void add_raw(const f4* raw, int, float* v, float mul) {
+#pragma unroll
+        for (int i = 0; i < N; i += 8) {
+            const half8 h = __builtin_bit_cast(half8, raw[i / 8]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[i + j] = __builtin_fmaf((float)h[j], mul, v[i + j]);
+        }
+    }
     static __device__ __forceinline__ void add(const half_t* src, int, float* v, float mul) {
 #pragma unroll
         for (int i = 0; i < N; i += 8) {
@@ -94,6 +108,15 @@ template <int N> struct OutVec<float, N> {
             for (int j = 0; j < 4; ++j) bad = __builtin_fmaf(o[j], 0.f, bad);
             *reinterpret_cast<f4*>(dst + i) = o;
         }
+    }
+    static constexpr int kRawChunks = N / 4;
+    static __device__ __forceinline__ void fetch(const float* src, f4* raw) {
+#pragma unroll
+        for (int i = 0; i < N / 4; ++i) raw[i] = *reinterpret_cast<const f4*>(src + i * 4);
+    }
+    static __device__ __forceinline__ void add_raw(const f4* raw, int, float* v, float) {
+#pragma unroll
+        for (int i = 0; i < N; i += 4) { v[i] += raw[i / 4][0]; v[i + 1] += raw[i / 4][1]; v[i + 2] += raw[i / 4][2]; v[i + 3] += raw[i / 4][3]; }
     }
     static __device__ __forceinline__ void add(const float* src, int, float* v, float) {   // the f32 engine never rescales
 #pragma unroll
@@ -132,6 +155,21 @@ template <int N> struct OutVec<split_t, N> {
             o[j] = want_hi ? hi : (half_t)(v[j] - (float)hi);
         }
         *reinterpret_cast<half8*>(reinterpret_cast<char*>(dst) + ((want_hi ? par : par ^ 1) ? 16 : 0)) = o;
+    }
+    static constexpr int kRawChunks = N / 4;
+    static __device__ __forceinline__ void fetch(const split_t* src, f4* raw) {
+        const char* p = reinterpret_cast<const char*>(src);
+#pragma unroll
+        for (int i = 0; i < N / 4; ++i) raw[i] = *reinterpret_cast<const f4*>(p + i * 16);
+    }
+    static __device__ __forceinline__ void add_raw(const f4* raw, int, float* v, float mul) {   // hi + lo: chunk order does not matter
+#pragma unroll
+        for (int i = 0; i < N; i += 8) {
+            const half8 a = __builtin_bit_cast(half8, raw[i / 4]);
+            const half8 b = __builtin_bit_cast(half8, raw[i / 4 + 1]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[i + j] = __builtin_fmaf((float)a[j] + (float)b[j], mul, v[i + j]);
+        }
     }
     static __device__ __forceinline__ void add(const split_t* src, int ch0, float* v, float mul) {
         const char* p = reinterpret_cast<const char*>(src);

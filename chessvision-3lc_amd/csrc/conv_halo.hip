@@ -605,6 +605,29 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
         }
     };
     float hold[UPL][UN];                                 // RG == 1 only
+    // Residual (ResNet shortcut): every unit this lane will add is fetched NOW, in one burst, so that the loads' latency passes
+    // behind the staging of the first rows instead of being paid unit by unit inside the store loop (in-kernel stamps, r02: the
+    // epilogue of a residual layer took 26 k cycles against 11 k without one -- as long as the 18-stage K loop itself).
+    constexpr int RC = OutVec<T, UN>::kRawChunks;
+    constexpr bool kPrefetchRes = !PERSIST && NW == 4;   // the 4-wave tile has the registers (FP x UPL units x RC chunks)
+    f4 rraw[kPrefetchRes ? FP : 1][UPL][RC];
+    if constexpr (kPrefetchRes) {
+        if (rbase) {
+#pragma unroll
+            for (int g = 0; g < FP; ++g)
+#pragma unroll
+                for (int i = 0; i < UPL; ++i) {
+                    const int unit = lane + 64 * i, px = unit / UPP, co = slab0 + (unit % UPP) * UN;
+                    bool live;
+                    const unsigned ob = out_pixel(g, px, &live);
+                    if (co < p.rows && live) OutVec<T, UN>::fetch(rbase + (ob * (unsigned)p.rCs + (unsigned)(p.rCoff + co)), rraw[g][i]);
+                    else {
+#pragma unroll
+                        for (int c = 0; c < RC; ++c) rraw[g][i][c] = f4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+        }
+    }
     float bad = 0.f;
 #pragma unroll
     for (int g0 = 0; g0 < FP; g0 += RG) {
@@ -642,7 +665,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 const unsigned ob = out_pixel(g0 + r, px, &live);
                 if (co < p.rows && live) {
                     if (rbase) {                         // tensors stay below 4 GiB (checked on the host): 32-bit element offsets
-                        OutVec<T, UN>::add(rbase + (ob * (unsigned)p.rCs + (unsigned)(p.rCoff + co)), p.rCoff + co, w[r], p.res_mul);
+                        if constexpr (kPrefetchRes) OutVec<T, UN>::add_raw(rraw[g0 + r][i], p.rCoff + co, w[r], p.res_mul);
+                        else OutVec<T, UN>::add(rbase + (ob * (unsigned)p.rCs + (unsigned)(p.rCoff + co)), p.rCoff + co, w[r], p.res_mul);
                         if (p.relu) {
 #pragma unroll
                             for (int j = 0; j < UN; ++j) w[r][j] = __builtin_fmaxf(w[r][j], 0.f);
