@@ -90,10 +90,6 @@ def ratio(a: float, b: float) -> float:
     return min(a, b) / float(max(a, b))
 
 
-def listdir_nohidden(path: str) -> list[str]:
-    return [f for f in os.listdir(path) if not f.startswith(".")]
-
-
 def create_binary_mask(mask: NDArray[np.float32], threshold: float = 0.5) -> NDArray[np.uint8]:
     """probability > threshold -> 255 else 0 (reference utils.py:101-112)."""
     assert isinstance(mask, np.ndarray), "Mask must be a numpy array"

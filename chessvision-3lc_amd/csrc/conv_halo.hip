@@ -776,11 +776,16 @@ static hipError_t launch_halo(const ConvParams& p, int n_images, hipStream_t str
     // persistent only where it pays (same-box A/B, r01_tuning.md step 22): several tiles per CU and a K loop short enough
     // for the hidden prologue to matter; long loops lose ~1 % to the single-row staging
     static const int max_k = [] { const char* v = std::getenv("CV_HALO_PERSIST_MAXK"); return v && *v ? std::atoi(v) : 72; }();
-    if (NW == 8 && halo_persistent<NW>() && tiles >= 4 * g_halo_cus && p.nStages <= max_k) {
-        auto kern = conv3x3_halo_kernel<T, CT, TH, WGC, NW, TPS, NSW, IMG, NW == 8, true>;
-        const int grid = tiles < g_halo_cus ? tiles : g_halo_cus;
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * NW), lds, stream, p);
-    } else {
+    bool launched = false;
+    if constexpr (NW == 8) {
+        if (halo_persistent<NW>() && tiles >= 4 * g_halo_cus && p.nStages <= max_k) {
+            auto kern = conv3x3_halo_kernel<T, CT, TH, WGC, NW, TPS, NSW, IMG, true, true>;
+            const int grid = tiles < g_halo_cus ? tiles : g_halo_cus;
+            hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * NW), lds, stream, p);
+            launched = true;
+        }
+    }
+    if (!launched) {
         auto kern = conv3x3_halo_kernel<T, CT, TH, WGC, NW, TPS, NSW, IMG, false, halo_double<CT, TH>()>;
         hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(64 * NW), lds, stream, p);
     }
@@ -796,9 +801,12 @@ static hipError_t prepare_halo() {
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<T, CT, TH, WGC, NW, TPS, NSW, IMG, false, false, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
-    if (e != hipSuccess || NW != 8) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<T, CT, TH, WGC, NW, TPS, NSW, IMG, NW == 8, true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if constexpr (NW == 8) {                             // the persistent variant exists for the 8-wave (double-buffered) tiles only
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<T, CT, TH, WGC, NW, TPS, NSW, IMG, true, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
+    return e;
 }
 
 // configurations: 64 channels x 16x16 patch (4 waves, four patch rows each), one tap per stage, ring 3, ONE halo buffer: 68 KB,

@@ -306,7 +306,7 @@ int choose_cfg(int ct, int rows, int64_t pixels, int n_stages) {
     const bool wide = ct == 128;
     const int w8 = env_cached(0), force_pt = env_cached(1);
     if (force_pt == 128 || force_pt == 256)
-        return force_pt == 256 ? (wide ? kCfg128x256 : kCfg64x256) : (wide ? kCfg128x128 : kCfg64x128);
+        return force_pt == 256 ? (wide ? kCfg128x256w8 : kCfg64x256) : (wide ? kCfg128x128 : kCfg64x128);
     if (!wide) {
         if (knobs().n64 == 1 && n_stages > 4 && blocks_for(rows, pixels, 64, 256) >= 512) return kCfg64x256;
         return kCfg64x128;
