@@ -119,3 +119,27 @@ def test_device_warp_gray_flip_split_matches_host_chain(engines):
         assert diff.max() <= 1 and float((diff > 0).mean()) <= 1e-3
         want = ChessVision.extract_squares(boards[k].cpu().numpy())[..., 0]
         assert np.array_equal(squares[k * 64:(k + 1) * 64].cpu().numpy(), want)
+
+
+def test_batched_api_with_mixed_sizes_and_missing_boards(tmp_path_factory):
+    """One call with images of two sizes (jobs are formed per shape), a frame without a board (position None, no fallback)
+    and a non-square photo: every result equals the per-image API's (device resize / warp vs the numpy restatements)."""
+    d = tmp_path_factory.mktemp("weights_seg")
+    pe, pc = synthetic.save_checkpoints(d, segmenting=True)
+    cv = ChessVision(board_extractor_weights=str(pe), classifier_weights=str(pc))
+    rng = np.random.default_rng(3)
+    wide = np.zeros((384, 512, 3), np.uint8)
+    wide[:, :384] = synthetic.board_photo(5, 384)
+    images = [synthetic.board_photo(1), rng.integers(0, 50, (512, 512, 3), dtype=np.uint8), wide, synthetic.board_photo(2)]
+    batched = cv.process_images(images, return_crops=True)
+    assert [r.position is None for r in batched] == [False, True, False, False]
+    for im, b in zip(images, batched):
+        a = cv.process_image(im)
+        assert (a.position is None) == (b.position is None)
+        assert float((a.board_extraction.binary_mask != b.board_extraction.binary_mask).mean()) <= 1e-4
+        if a.position is None:
+            assert b.board_extraction.board_image is None and b.board_extraction.quadrangle is None
+            continue
+        assert np.array_equal(a.board_extraction.quadrangle, b.board_extraction.quadrangle)
+        assert np.abs(a.position.model_probabilities - b.position.model_probabilities).max() <= 2e-2
+        assert b.position.squares.shape == (64, 64, 64, 1)
