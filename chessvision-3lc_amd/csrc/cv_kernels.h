@@ -41,6 +41,10 @@ struct TensorRef {            // a channel slice of a PHWC tensor
     // the f16 / split-f16 engines, engine.h: Activation); owner = the Activation the slice belongs to
     int exp;
     void* owner;
+    // a slice that spans both halves of a concatenated buffer: channels >= split (counted inside the slice) are held with
+    // exponent exp + exp_delta (the consumer folds 2^exp_delta into its weights for those input channels); 0 / 0 otherwise
+    int split;
+    int exp_delta;
 };
 
 // Implicit-GEMM convolution:  D[ch][pix] = sum_k Wt[ch][k] * X[pix][k]

@@ -95,6 +95,7 @@ static void pack_rows(int dt, std::vector<char>& out, int CT, int nCt, int nStag
 
 static Status finish_layer(ConvLayer& L, std::vector<float>& Wk, int K, const std::vector<float>& scale,
                            const std::vector<float>& shift) {
+    if (L.keep_host_weights && L.Wk0.empty()) { L.Wk0 = Wk; L.b_scale = scale; L.b_shift = shift; L.Kdim = K; }
     const int CT = L.ct = choose_ct(L.rows, L.pixels_hint, L.halo_ok, L.halo_img8);
     L.nStages = (chunks_for(L.dt, K) + 7) / 8;
     L.nCt = (L.rows + CT - 1) / CT;
@@ -140,6 +141,28 @@ static Status finish_layer(ConvLayer& L, std::vector<float>& Wk, int K, const st
     CV_TRY(L.shift.upload(L.h_shift.data(), L.h_shift.size() * sizeof(float)));
     L.koff.clear();
     return Status();
+}
+
+static inline void k_decode(int kgroup, int ntaps, int kk, int* tap, int* ci);
+
+// Consumer of a concatenated buffer whose halves carry different exponents: input channels >= split are held 2^delta smaller than
+// the first half's scale says, so their weights take the factor (a power of two: exact), then the rows are re-normalised and
+// re-packed.  Happens during load-time calibration only.
+Status ConvLayer::set_input_split(int split, int delta, hipStream_t s) {
+    if (split == in_split && delta == in_delta) return Status();
+    if (Wk0.empty()) return fail(1, name + ": the halves of its concatenated input need different exponents but the layer kept no host weights");
+    CV_HIP(hipStreamSynchronize(s));
+    std::vector<float> Wk = Wk0;
+    const int ntaps = k * k;
+    if (delta != 0)
+        for (int kk = 0; kk < Kdim; ++kk) {
+            int tap, ci;
+            k_decode(kgroup, ntaps, kk, &tap, &ci);
+            if (ci < split) continue;
+            for (int r = 0; r < rows; ++r) Wk[(size_t)r * Kdim + kk] = std::ldexp(Wk[(size_t)r * Kdim + kk], delta);
+        }
+    in_split = split; in_delta = delta;
+    return finish_layer(*this, Wk, Kdim, b_scale, b_shift);
 }
 
 // Re-fold the tensor exponents into the device copies of the epilogue constants (only when they change: calibration).
@@ -373,10 +396,12 @@ Status Engine::measure(const TensorRef& t, hipStream_t s) {
     unsigned bits = 0;
     CV_HIP(hipMemcpyAsync(&bits, cal_word.ptr, sizeof(bits), hipMemcpyDeviceToHost, s));
     CV_HIP(hipStreamSynchronize(s));
-    if (bits >= 0x7f800000u) { a->seen_bad = true; return Status(); }
+    const bool second = a->split_c && t.Coff >= a->split_c;         // producers write one half of a concatenation each
+    if (bits >= 0x7f800000u) { (second ? a->seen_bad2 : a->seen_bad) = true; return Status(); }
     float stored;
     std::memcpy(&stored, &bits, sizeof(stored));
-    a->seen_max = std::max(a->seen_max, std::ldexp(stored, t.exp));
+    float& seen = second ? a->seen_max2 : a->seen_max;
+    seen = std::max(seen, std::ldexp(stored, t.exp));
     return Status();
 }
 
@@ -414,6 +439,7 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
     p.kbase = knobs().sep ? kbase : nullptr;
     // tensor exponents (Activation): the fused head writes f32 logits, i.e. an output at exponent 0
     const int out_exp = head ? 0 : y.exp;
+    if (x.exp_delta != 0 || L.in_delta != 0) CV_TRY(L.set_input_split(x.split, x.exp_delta, s));
     CV_TRY(L.set_exps(x.exp, out_exp, s));
     p.scale = reinterpret_cast<const float*>(L.scale.ptr);
     p.shift = reinterpret_cast<const float*>(L.shift.ptr);

@@ -70,9 +70,14 @@ struct Activation {
     int cap = 0, H = 0, W = 0, C = 0;
     int dt = kF16;
     int exp = 0;
+    // A concatenated buffer (UNet decoder: [skip | up-sampled]) keeps a second exponent for channels >= split_c: the two halves
+    // come from different producers and can differ by orders of magnitude, and one shared exponent would push the smaller
+    // half (and, after the consumer's row normalisation, its weights) into the f16 subnormals.
+    int split_c = 0;                                // 0 = not a concatenation
+    int exp2 = 0;
     // calibration statistics of the current pass (real-valued maximum = stored maximum * 2^exp) and policy
-    float seen_max = 0.f;
-    bool seen_bad = false;
+    float seen_max = 0.f, seen_max2 = 0.f;
+    bool seen_bad = false, seen_bad2 = false;
     bool fixed_exp = false;                         // inputs: exp is set by construction, not measured
     Activation* tie = nullptr;                      // same exp as `tie` (pooled copy of a tensor, concat halves)
     void shape(int h, int w, int c, int dt_) { H = h; W = w; C = c; dt = dt_; }
@@ -81,9 +86,12 @@ struct Activation {
     TensorRef ref(int n, int coff = 0, int c = -1) const {
         TensorRef t;
         t.base = buf.ptr; t.N = n; t.H = H; t.W = W; t.Cs = C; t.Coff = coff; t.C = c < 0 ? C - coff : c;
-        t.exp = exp; t.owner = const_cast<Activation*>(this);
+        t.owner = const_cast<Activation*>(this);
+        t.exp = exp_of(coff); t.split = 0; t.exp_delta = 0;
+        if (split_c && coff < split_c && coff + t.C > split_c) { t.split = split_c - coff; t.exp_delta = exp2 - exp; }
         return t;
     }
+    int exp_of(int coff) const { return split_c && coff >= split_c ? exp2 : exp; }
     size_t bytes_per_image() const { return (size_t)(H + 2) * (W + 2) * C * dtype_size(dt); }
 };
 
@@ -107,6 +115,12 @@ struct ConvLayer {
     // tensor exponents the layer currently runs with (set_exps).
     std::vector<float> h_scale, h_shift;
     int in_exp = 0, out_exp = 0;
+    // consumers of a concatenated buffer: the un-normalised weights stay on the host so that 2^exp_delta can be folded into
+    // the input channels of the second half when calibration gives the halves different exponents (set_input_split)
+    bool keep_host_weights = false;
+    std::vector<float> Wk0, b_scale, b_shift;
+    int Kdim = 0, in_split = 0, in_delta = 0;
+    Status set_input_split(int split, int delta, hipStream_t s);
     unsigned layer_id = 0xfffffffeu;                // numeric guard id (Engine::register_layer)
     // koff tables are geometry dependent: keyed by (xWp, xCs, xCoff)
     struct KoffKey { int xWp, xCs, xCoff; bool operator<(const KoffKey& o) const {
@@ -208,7 +222,7 @@ template <class Fwd>
 Status Engine::calibrate(const std::vector<Activation*>& acts, Fwd&& forward, hipStream_t s, const char* what) {
     if (dt == kF32 || !calibration_enabled()) return Status();
     for (int pass = 0; pass < 10; ++pass) {
-        for (Activation* a : acts) { a->seen_max = 0.f; a->seen_bad = false; }
+        for (Activation* a : acts) { a->seen_max = a->seen_max2 = 0.f; a->seen_bad = a->seen_bad2 = false; }
         calibrating = true;
         Status st = forward();
         calibrating = false;
@@ -216,18 +230,22 @@ Status Engine::calibrate(const std::vector<Activation*>& acts, Fwd&& forward, hi
         CV_HIP(hipStreamSynchronize(s));
         CV_HIP(hipMemset(guard.ptr, 0xff, sizeof(unsigned)));      // overflow during calibration is expected, not an error
         bool changed = false;
-        for (Activation* a : acts) {
-            if (a->fixed_exp || a->tie) continue;
-            int want = a->exp;
-            if (a->seen_bad) want = a->exp + 12;
-            else if (a->seen_max > 0.f) {
+        auto adjust = [&](int& ex, float seen, bool bad) {
+            int want = ex;
+            if (bad) want = ex + 12;
+            else if (seen > 0.f) {
                 int e2;
-                (void)std::frexp(a->seen_max, &e2);                // seen_max = f * 2^e2, f in [0.5, 1)
-                const int stored_e = e2 - a->exp;                  // stored maximum in [2^(stored_e-1), 2^stored_e)
+                (void)std::frexp(seen, &e2);                       // seen = f * 2^e2, f in [0.5, 1)
+                const int stored_e = e2 - ex;                      // stored maximum in [2^(stored_e-1), 2^stored_e)
                 if (stored_e < 4 || stored_e > 6) want = e2 - 5;   // re-centre on [16, 32)
             }
             want = want < -60 ? -60 : want > 60 ? 60 : want;
-            if (want != a->exp) { a->exp = want; changed = true; }
+            if (want != ex) { ex = want; changed = true; }
+        };
+        for (Activation* a : acts) {
+            if (a->fixed_exp || a->tie) continue;
+            adjust(a->exp, a->seen_max, a->seen_bad);
+            if (a->split_c) adjust(a->exp2, a->seen_max2, a->seen_bad2);
         }
         for (Activation* a : acts)
             if (a->tie && a->exp != a->tie->exp) { a->exp = a->tie->exp; changed = true; }

@@ -225,6 +225,7 @@ Status unet_load(Engine& e, const ParamMap& pm) {
         up_c[i] = cat_c - skip_c;
         const std::string c = p + ".conv.double_conv.";
         double_conv_keys(known, c);
+        U.u[i][0].keep_host_weights = dt != kF32;     // consumer of cat([skip, up]): the halves may end up with different exponents
         CV_TRY(build_conv_bn(e, U.u[i][0], pm, c + "0", c + "1", mid_c, cat_c, 3, 1, cat_c, px(lvl), res[lvl]));
         CV_TRY(build_conv_bn(e, U.u[i][1], pm, c + "3", c + "4", out_c, mid_c, 3, 1, mid_c, px(lvl), res[lvl]));
         deep_c = out_c;
@@ -253,6 +254,7 @@ Status unet_load(Engine& e, const ParamMap& pm) {
     for (int lvl = 0; lvl < 4; ++lvl) {
         const int skip_c = enc_c[lvl];
         U.cat[lvl].shape(res[lvl], res[lvl], skip_c + up_c[3 - lvl], dt);
+        U.cat[lvl].split_c = dt == kF32 ? 0 : skip_c;   // [skip | up-sampled]: one exponent per half
         U.pool[lvl].shape(res[lvl + 1], res[lvl + 1], skip_c, dt);
         U.pool[lvl].tie = &U.cat[lvl];               // max-pool of the skip half: same scale
         U.dmid[lvl].shape(res[lvl + 1], res[lvl + 1], enc_c[lvl + 1], dt);
@@ -352,7 +354,7 @@ Status unet_activation(Engine& e, const std::string& name, TensorRef* out) {
     auto it = e.unet->taps.find(name);
     if (it == e.unet->taps.end()) return fail(1, "unknown UNet activation '" + name + "'");
     *out = it->second;
-    out->exp = static_cast<Activation*>(out->owner)->exp;
+    out->exp = static_cast<Activation*>(out->owner)->exp_of(out->Coff);
     out->N = e.unet->last_n;
     return Status();
 }

@@ -129,6 +129,10 @@ def stress_unet_state_dict(seed: int = 1, bilinear: bool = False, push: float = 
     push_activation(sd, "down3.maxpool_conv.1.double_conv.1", [("down3.maxpool_conv.1.double_conv.3", 0, 512)], push)
     mid = sd["up2.conv.double_conv.3.weight"].shape[1]
     push_activation(sd, "up2.conv.double_conv.1", [("up2.conv.double_conv.3", 0, mid)], push / 3)
+    # ... and one SKIP tensor: down2's output feeds the pool of down3 and the first 256 input channels of up2's first conv, whose
+    # other half (the up-sampled tensor) stays O(1) -- the two halves of one concatenated buffer then differ by ~2^15
+    push_activation(sd, "down2.maxpool_conv.1.double_conv.4",
+                    [("down3.maxpool_conv.1.double_conv.0", 0, 256), ("up2.conv.double_conv.0", 0, 256)], push)
     return sd
 
 

@@ -62,6 +62,9 @@ def test_unet_with_stressed_ranges_matches_oracle(prec, bilinear):
         # the tensor that carries ~2e5 in the oracle is held at an exponent that maps it into [16, 32)
         e = eng.activation_exponent("unet", "down3.maxpool_conv.1.double_conv.2")
         assert 10 <= e <= 15, e
+        # the halves of cat([skip, up]) at level 2 keep separate exponents: the skip tensor carries ~2e5, its partner O(10)
+        e_skip, e_up = eng.activation_exponent("unet", "down2"), eng.activation_exponent("unet", "up2.up")
+        assert 10 <= e_skip <= 15 and -4 <= e_up <= 3, (e_skip, e_up)
     eng.close()
     assert err <= 1e-3, err
     away = ref.abs() > 1e-3                                # masks agree wherever the logit is not within the error bar of 0
@@ -126,14 +129,15 @@ for name, fn, x in (("unet", eng.unet_forward, synth.unet_input(3, 2)), ("resnet
 
 def test_guard_names_the_layer_when_calibration_is_off(tmp_path):
     """CV_CALIBRATE=0 keeps every tensor at exponent 0: the ~2e5 activations of the stressed networks exceed 65504, and the
-    forward must fail loudly with the producing layer's name instead of returning numbers."""
+    forward must fail loudly with the name of the FIRST layer that overflows (the pushed skip tensor of down2; ResNet: the
+    pushed intermediate of layer3.0) instead of returning numbers."""
     script = tmp_path / "guard.py"
     script.write_text(_GUARD_SCRIPT.format(root=str(ROOT)))
     env = dict(os.environ, CV_CALIBRATE="0")
     out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = {ln.split()[0]: ln for ln in out.stdout.splitlines() if ln.startswith(("unet", "resnet18"))}
-    assert "RAISED" in lines["unet"] and "status 5" in lines["unet"] and "down3.maxpool_conv.1.double_conv.0" in lines["unet"], lines
+    assert "RAISED" in lines["unet"] and "status 5" in lines["unet"] and "down2.maxpool_conv.1.double_conv.3" in lines["unet"], lines
     assert "RAISED" in lines["resnet18"] and "layer3.0.conv1" in lines["resnet18"], lines
 
 

@@ -106,3 +106,4 @@ def test_range_stressed_networks_compute_the_same_function():
     for h in hooks:
         h.remove()
     assert seen["down3.maxpool_conv.1.double_conv.2"] > 65504 < seen["up2.conv.double_conv.2"]   # beyond the f16 range
+    assert seen["down2.maxpool_conv.1.double_conv.5"] > 65504                                     # a skip tensor, too
