@@ -251,9 +251,15 @@ class ChessVision:
             # the first job of a call is staged and uploaded in slices of 16 images (the upload of a slice overlaps the host copies
             # of the next one: nothing else hides that job's staging); later jobs are staged in one go behind the GPU's work
             step_ = 16 if slice_upload else len(ids)
+
+            def copy_group(lo, hi):                          # one task per group of images: few Python-level dispatches, the
+                for k in range(lo, hi):                      # memcpys themselves run without the GIL
+                    np.copyto(view[k], images[ids[k]])
+
             for k0 in range(0, len(ids), step_):
                 k1 = min(len(ids), k0 + step_)
-                list(pool.map(lambda k: np.copyto(view[k], images[ids[k]]), range(k0, k1)))
+                per = max(1, -(-(k1 - k0) // 16))
+                list(pool.map(lambda lo: copy_group(lo, min(k1, lo + per)), range(k0, k1, per)))
                 with torch.cuda.stream(up):
                     batch[k0:k1].copy_(staged[k0:k1], non_blocking=True)
             clock("stage_s", t0)
@@ -262,6 +268,7 @@ class ChessVision:
                 arrived.record()
             main.wait_event(arrived)
             batch.record_stream(main)
+            tm.setdefault("first_enqueue_s", time.time() - started)      # host time until the first kernel of the call is queued
             small = gpu_timed("resize_ms", lambda: eng.resize_area_u8(batch, (constants.INPUT_SIZE[1], constants.INPUT_SIZE[0])))
             lg, mk = gpu_timed("unet_ms", lambda: eng.unet_forward_u8(small, threshold=threshold, want_mask=True))
             done = torch.cuda.Event()
@@ -300,16 +307,20 @@ class ChessVision:
                 clock("homography_s", t0)
                 src = st["batch"] if len(found) == len(ids) else st["batch"][torch.as_tensor(found, device=dev)]
                 squares_dev, boards_dev = gpu_timed("warp_ms", lambda: eng.extract_squares_u8(src, inv))
+                warped = torch.cuda.Event()
+                warped.record()
+                st["boards"] = pinned((len(found), h, w), torch.uint8)
+                with torch.cuda.stream(down):                # the rectified boards travel back while the classifier runs
+                    down.wait_event(warped)
+                    st["boards"].copy_(boards_dev, non_blocking=True)
                 probs_dev = gpu_timed("resnet_ms", lambda: eng.resnet18_forward_u8(squares_dev))
                 done = torch.cuda.Event()
                 done.record()
                 st["probs"] = pinned((len(found) * 64, constants.NUM_CLASSES), torch.float32)
-                st["boards"] = pinned((len(found), h, w), torch.uint8)
                 st["keep2"] = (probs_dev, boards_dev, squares_dev)
                 with torch.cuda.stream(down):
                     down.wait_event(done)
                     st["probs"].copy_(probs_dev, non_blocking=True)
-                    st["boards"].copy_(boards_dev, non_blocking=True)
                     st["ev2"] = torch.cuda.Event()
                     st["ev2"].record()
             else:
@@ -361,8 +372,10 @@ class ChessVision:
             if cls is not None:
                 finish(cls)
             cls, seg = cur, nxt
+        t_last = time.perf_counter()
         finish(cls)
         eng.check_numerics()                               # one look at the numeric guard for the whole call
+        tm["drain_s"] = time.perf_counter() - t_last       # last job: wait for its classifier, copies back, decode
 
         t0 = time.perf_counter()
         per_image = (time.time() - started) / n
