@@ -39,8 +39,9 @@ def _worker(rank: int, world: int, port: int, q):
         ordered = cvd.interleave_shards(gathered, world)
         ok_order = ordered[:, 0].tolist() == list(range(n_boards))
         t = cvd.max_over_ranks(float(rank + 1), device)
+        seen = cvd.count_ranks(device)                 # bench.py's `rccl_ranks_seen`: an all-reduce of ones
         cvd.barrier(device)
-        q.put((rank, same, mine, ok_order, t))
+        q.put((rank, same, mine, ok_order, t, seen))
     finally:
         if dist.is_initialized():
             dist.destroy_process_group()
@@ -57,7 +58,8 @@ def test_world2_broadcast_shard_gather():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, same0, mine0, ord0, t0), (r1, same1, mine1, ord1, t1) = results
+    (r0, same0, mine0, ord0, t0, seen0), (r1, same1, mine1, ord1, t1, seen1) = results
+    assert seen0 == seen1 == 2
     assert same0 and same1, "broadcast state dict differs from the source"
     assert mine0 == [0, 2, 4, 6, 8] and mine1 == [1, 3, 5, 7, 9]
     assert ord0 and ord1
@@ -76,3 +78,4 @@ def test_single_process_paths_are_identity():
     x = torch.arange(6.0).reshape(3, 2)
     assert torch.equal(cvd.all_gather_rows(x), x)
     assert list(cvd.shard_indices(7, 2, 4)) == [2, 6]
+    assert cvd.count_ranks(torch.device("cpu")) == 1
