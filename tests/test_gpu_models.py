@@ -240,3 +240,47 @@ def test_errors_are_exceptions_not_aborts():
     with pytest.raises(HipBackendError):
         eng.unet_forward(torch.zeros(1, 3, 128, 128))
     eng.close()
+
+
+def test_baseline_config1_unet_fp32_batch32_mask_iou():
+    """BASELINE.json configs[1]: UNet 256x256 fp32 forward, batch = 32, against the CPU oracle: logits within 1e-3, mask IoU."""
+    from chessvision.hip_backend import HipEngine
+
+    net = synth.make_unet(seed=1)
+    x = synth.unet_input(seed=41, batch=32)
+    with torch.no_grad():
+        ref = net.to(memory_format=torch.channels_last)(x)
+    eng = HipEngine(precision="f32", unet_chunk=32)
+    eng.load_unet(net.state_dict())
+    out = eng.unet_forward(x).cpu()
+    eng.close()
+    err = float((out - ref).abs().max())
+    m_ref, m_got = ref > 0, out > 0
+    iou = float((m_ref & m_got).sum()) / max(1.0, float((m_ref | m_got).sum()))
+    _record("config1_unet_f32_b32", {"logit_max_abs_err": err, "mask_iou": iou})
+    assert err <= 1e-3 and iou >= 0.9999, (err, iou)
+
+
+def test_baseline_config2_resnet18_fp16_batch4096():
+    """BASELINE.json configs[2]: ResNet-18 classifier, 64 x 64 squares = batch 4096, against the fp32 CPU oracle.  SURVEY.md section 8d
+    config 3 asks for soft-max probabilities within 1e-3 and arg-max agreement with fp16 storage / fp32 accumulate: the plain f16
+    engine agrees on every arg-max but its worst probability over 4096 squares is off by 1.4e-3 (9e-4 over 200 squares) -- it does
+    NOT meet the bar and is a throughput mode; the f16x3 engine meets it with three orders of magnitude to spare."""
+    from chessvision.hip_backend import HipEngine
+
+    net = synth.make_resnet(seed=2)
+    sq = synth.squares_input(seed=42, n=4096)
+    with torch.no_grad():
+        ref = net(sq)
+    p_ref = torch.softmax(ref, 1)
+    res = {}
+    for prec in ("f16", "f16x3"):
+        eng = HipEngine(precision=prec, resnet_chunk=4096)
+        eng.load_resnet18(net.state_dict())
+        out = eng.resnet18_forward(sq).cpu()
+        eng.close()
+        p = torch.softmax(out, 1)
+        res[prec] = (float((out - ref).abs().max()), float((p - p_ref).abs().max()), float((p.argmax(1) == p_ref.argmax(1)).float().mean()))
+    _record("config2_resnet18_b4096", {k: {"logit_err": v[0], "prob_err": v[1], "argmax_agreement": v[2]} for k, v in res.items()})
+    assert res["f16"][1] <= 3e-3 and res["f16"][2] >= 0.999, res          # the f16 rounding floor, not the 1e-3 bar
+    assert res["f16x3"][0] <= 1e-3 and res["f16x3"][2] == 1.0, res
