@@ -33,8 +33,8 @@ import torch  # noqa: E402  (importing torch does not initialise the GPU)
 # MI355X dense MFMA peaks (MI355X_MICROARCH.md, chip table): f32-input MFMA 157.3 TF, f16 MFMA ~2500 TF; HBM3E 8 TB/s.
 # f16x3 computes every algorithmic MAC with THREE f16 MFMA products (hi*hi + hi*lo + lo*hi), so the dense peak of
 # that arithmetic type is 2500 / 3 algorithmic TFLOP/s; the line also carries the fraction of the raw f16 peak.
-PEAK_TFLOPS = {"f32": 157.3, "f16": 2500.0, "f16x3": 2500.0 / 3.0}
-MFMA_PER_MAC = {"f32": 1, "f16": 1, "f16x3": 3}
+PEAK_TFLOPS = {"f32": 157.3, "f16": 2500.0, "f16x3": 2500.0 / 3.0, "f16r": 2500.0}
+MFMA_PER_MAC = {"f32": 1, "f16": 1, "f16x3": 3, "f16r": 1}
 HBM_PEAK_GBS = 8000.0
 PMC_FILE = "profiles/r02_pmc_traffic.json"
 
@@ -46,8 +46,11 @@ def log(*a):
 def relaunch_under_torchrun(args, argv) -> int:
     """--gpus N > 1 without a launcher: start N ranks as a CHILD process tree (never exec: a process that has touched the GPU
     must not be replaced, and this parent has not touched it yet) and hand back its return code."""
-    n_dev = torch.cuda.device_count()                       # counting devices does not initialise the GPU
-    if n_dev < args.gpus:
+    # The count may bring up the HIP runtime in THIS process on ROCm (there is no NVML-style shortcut), which is harmless because
+    # the ranks are only ever started as child processes below -- never turn this into an os.exec*.
+    n_dev = torch.cuda.device_count()
+    share = os.environ.get("CV_DIST_BACKEND") == "gloo"      # gloo ranks may share a GPU (the N > 1 path on a one-GPU box)
+    if n_dev < args.gpus and not (share and n_dev >= 1):
         log(f"bench.py: --gpus {args.gpus} but only {n_dev} device(s) visible")
         return 2
     with socket.socket() as sock:
@@ -152,12 +155,12 @@ def pipeline_e2e(dtype: str, n_boards: int = 256, n_checked: int = 8):
         pe, pc = synthetic.save_checkpoints(d, segmenting=True)
         cv = ChessVision(board_extractor_weights=str(pe), classifier_weights=str(pc), precision=dtype)
         images = [synthetic.board_photo(s) for s in range(n_boards)]
-        cv.process_images(images[:96], fallback_quad=True)                # warm-up (lazy model init, pinned buffers, workspace)
+        cv.process_images(images[:96], fallback_quad=True, return_crops=False)   # warm-up (lazy model init, pinned buffers, workspace)
         best, tm_best, res = None, None, None
         for _ in range(3):
             tm = {}
             t0 = time.perf_counter()
-            res = cv.process_images(images, fallback_quad=True, timings=tm)
+            res = cv.process_images(images, fallback_quad=True, timings=tm, return_crops=False)
             dt = time.perf_counter() - t0
             if best is None or dt < best:
                 best, tm_best = dt, tm
@@ -169,6 +172,107 @@ def pipeline_e2e(dtype: str, n_boards: int = 256, n_checked: int = 8):
              "note": "host images in, FEN out (best of 3 calls); one host thread software-pipelined against the GPU in jobs of 64 boards, "
                      "copies on side streams; stages: host seconds (*_s) and event-timed GPU milliseconds (*_ms) summed over the jobs"}
     return block, images[:n_checked], res[:n_checked]
+
+
+class _LazyPhotos:
+    """The global list of synthetic board photos; a photo is only rendered when its index is touched (a rank touches its shard)."""
+
+    def __init__(self, n):
+        self.n = n
+        self.cache = {}
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        from chessvision import synthetic
+        if i not in self.cache:
+            self.cache[i] = synthetic.board_photo(i)
+        return self.cache[i]
+
+
+def pipeline_e2e_sharded(dtype, boards_per_rank, rank, world, device, cvd):
+    """BASELINE configs[4] literally: ONE list of world * B photos, ``distributed.process_images_sharded`` (rank r processes
+    photos r::world through host staging, resize, UNet, contours, warp, ResNet-18, FEN; probabilities / quadrangles / masks are
+    all-gathered and re-interleaved).  Every rank times its own shard; the block carries min / mean / max over the ranks and
+    the whole-job rate (all boards / slowest rank, gather included).  Collective: every rank must call this."""
+    import tempfile
+
+    from chessvision import ChessVision, synthetic
+
+    n_global = world * boards_per_rank
+    photos = _LazyPhotos(n_global)
+    with tempfile.TemporaryDirectory() as d:
+        pe, pc = synthetic.save_checkpoints(d, segmenting=True)      # same seeds on every rank: identical weights
+        cv = ChessVision(board_extractor_weights=str(pe), classifier_weights=str(pc), precision=dtype)
+        for i in cvd.shard_indices(n_global, rank, world):
+            photos[i]                                                 # render this rank's shard before any clock starts
+        warm = _LazyPhotos(min(96, boards_per_rank) * world)
+        warm.cache = photos.cache
+        cvd.process_images_sharded(cv, warm, fallback_quad=True, gather=False, return_crops=False)
+        best = None
+        for _ in range(3):
+            tm = {}
+            cvd.barrier(device)
+            t0 = time.perf_counter()
+            res = cvd.process_images_sharded(cv, photos, fallback_quad=True, return_crops=False, timings=tm)
+            total = time.perf_counter() - t0
+            if best is None or total < best[0]:
+                best = (total, tm["shard_s"], tm["gather_s"], res)
+    total, shard_s, gather_s, res = best
+    rate = cvd.stats_over_ranks(boards_per_rank / shard_s, device)
+    whole = n_global / cvd.max_over_ranks(total, device)
+    gather = cvd.stats_over_ranks(gather_s, device)
+    fens = sum(r is not None and r.position is not None for r in res)
+    return {"boards_per_sec_per_rank": {k: round(v, 1) for k, v in rate.items()}, "boards_per_sec_whole_job": round(whole, 1),
+            "gather_s": {k: round(v, 4) for k, v in gather.items()}, "global_boards": n_global, "fens_on_rank0": fens,
+            "note": "host photos in, FEN out on every rank (best of 3 calls); per-rank rate = shard boards / that rank's process_images time; "
+                    "whole job = all boards / slowest rank's call including the all_gather of probabilities, quadrangles and masks"}
+
+
+def classifier_fp16(eng_main, x, sq, B, rsd, args, device, cvd, oracle_out):
+    """BASELINE configs[2]'s arithmetic for the classifier: precision "f16r" (one f16 MFMA product per MAC, f32 accumulate, f32
+    residual trunk, f32 shortcut convolutions) -- throughput of the ResNet-18 pass alone, of the step with the UNet left on the
+    headline engine, its own MFMA roofline (dense f16 peak, 1 product per MAC) and its parity against the same oracle outputs
+    as `parity_vs_oracle` (4096 squares = configs[2]'s batch when 64 boards were checked)."""
+    from chessvision.hip_backend import HipEngine
+
+    XS, XW = args.extra_steps, args.extra_warmup
+    e = HipEngine(device, precision="f16r", unet_chunk=args.unet_chunk, resnet_chunk=args.resnet_chunk)
+    e.load_resnet18(rsd)
+
+    def timed(fn):
+        for _ in range(XW):
+            fn()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(XS):
+            o = fn()
+        torch.cuda.synchronize(device)
+        return (time.perf_counter() - t0) / XS, o
+
+    t_cls, cls = timed(lambda: e.resnet18_forward(sq, check=False))
+    t_ref, _ = timed(lambda: eng_main.resnet18_forward(sq, check=False))
+    t_step, _ = timed(lambda: (eng_main.unet_forward(x, check=False), e.resnet18_forward(sq, check=False)))
+    e.check_numerics()
+    c_ms, c_n, a_ms, entries = e.profile("resnet18", sq, iters=1)
+    flop = sum(2.0 * en["macs"] for en in entries if en["conv"])
+    ach = flop / (c_ms * 1e-3) / 1e12
+    block = {"precision": "f16r", "squares": int(sq.shape[0]), "ms_per_pass": round(t_cls * 1e3, 3), "squares_per_sec": round(sq.shape[0] / t_cls, 1),
+             "headline_engine_ms_per_pass": round(t_ref * 1e3, 3), "steps": XS, "warmup": XW,
+             "step_with_headline_unet": {"ms_per_step": round(t_step * 1e3, 3), "boards_per_sec": round(B / t_step, 2)},
+             "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS["f16r"], "unit": "TFLOP/s",
+                          "frac": round(ach / PEAK_TFLOPS["f16r"], 4), "launches": c_n, "avg_launch_ms": round(c_ms / max(c_n, 1), 4)}}
+    if oracle_out is not None:
+        ref = oracle_out[1]
+        got = cls[:ref.shape[0]].cpu()
+        p, p_ref = torch.softmax(got, 1), torch.softmax(ref, 1)
+        block["parity_vs_oracle"] = {"squares_checked": int(ref.shape[0]), "prob_max_abs_err": float((p - p_ref).abs().max()),
+                                     "logit_max_abs_err": float((got - ref).abs().max()),
+                                     "argmax_agreement": float((p.argmax(1) == p_ref.argmax(1)).float().mean()),
+                                     "bar": "soft-max probabilities within 1e-3 of the fp32 oracle (SURVEY.md section 8d config 3)"}
+    e.close()
+    return block
 
 
 def measure(eng, x, sq, steps, warmup, device, cvd, streams=None):
@@ -206,7 +310,7 @@ def rooflines(eng, x, sq, dtype, B, quiet=False):
     family and the HBM roofline of each memory-bound kernel (algorithmic bytes / event time / 8 TB/s)."""
     conv_ms = conv_n = 0
     conv_flop = conv_bytes = all_ms = 0.0
-    table, launches, per_model, hbm, chunks = {}, {}, {}, {}, {}
+    table, launches, per_model, hbm, chunks, by_kernel = {}, {}, {}, {}, {}, {}
     for model, inp in (("unet", x), ("resnet18", sq)):
         c_ms, c_n, a_ms, entries = eng.profile(model, inp, iters=1)
         conv_ms += c_ms; conv_n += c_n; all_ms += a_ms
@@ -219,6 +323,8 @@ def rooflines(eng, x, sq, dtype, B, quiet=False):
                 conv_flop += 2.0 * e["macs"]
                 conv_bytes += e["bytes"]
                 per_model[model][1] += 2.0 * e["macs"]
+                k = by_kernel.setdefault(e["kernel"], [0.0, 0.0, 0])
+                k[0] += e["ms"]; k[1] += 2.0 * e["macs"]; k[2] += 1
             else:
                 h = hbm.setdefault(e["name"], [0.0, 0.0, 0, 0.0])
                 h[0] += e["ms"]; h[1] += e["bytes"]; h[2] += 1; h[3] += 2.0 * e["macs"]
@@ -240,6 +346,15 @@ def rooflines(eng, x, sq, dtype, B, quiet=False):
             "mfma_issued_tflops": round(achieved * MFMA_PER_MAC[dtype], 2),
             "frac_of_raw_mfma_peak": round(achieved * MFMA_PER_MAC[dtype] / (157.3 if dtype == "f32" else 2500.0), 4),
             "conv_family_hbm_gbs": round(conv_bytes / (conv_ms * 1e-3) / 1e9, 1)}
+    # the instantiation that holds most of the step's time, reproducible from a rocprofv3 kernel trace by template name
+    dom = max(by_kernel, key=lambda k: by_kernel[k][0])
+    roof["dominant"] = {"kernel": dom, "launches_per_step": by_kernel[dom][2], "avg_launch_ms": round(by_kernel[dom][0] / by_kernel[dom][2], 4),
+                        "ms_per_step": round(by_kernel[dom][0], 3), "share_of_conv_time": round(by_kernel[dom][0] / conv_ms, 4),
+                        "algorithmic_gflop": round(by_kernel[dom][1] / 1e9, 2),
+                        "achieved": round(by_kernel[dom][1] / (by_kernel[dom][0] * 1e-3) / 1e12, 2),
+                        "frac": round(by_kernel[dom][1] / (by_kernel[dom][0] * 1e-3) / 1e12 / peak, 4)}
+    roof["by_kernel"] = {k: {"launches": v[2], "ms_per_step": round(v[0], 3), "achieved": round(v[1] / (v[0] * 1e-3) / 1e12, 2)}
+                         for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1][0])}
     roof_hbm = {}
     for name, (ms, by, cnt, fl) in hbm.items():
         if ms <= 0:
@@ -271,6 +386,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the by_dtype / by_variant / pipeline_e2e blocks")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
+    ap.add_argument("--extra-steps", type=int, default=10, help="timed steps of each by_dtype / by_variant / classifier_fp16 leg")
+    ap.add_argument("--extra-warmup", type=int, default=3)
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -309,17 +426,36 @@ def main():
     eng = make_engine(args.dtype)
 
     # ---- synthetic inputs, resident in HBM before the timed region ----
+    # ONE global batch of world * B boards, board i drawn from its own seed; rank r holds boards r::world of it (SURVEY.md
+    # section 8e, BASELINE configs[4]) -- no rank ever materialises another rank's boards.
     B = args.boards
+    mine = list(cvd.shard_indices(world * B, rank, world))
+    x = torch.empty((B, 3, 256, 256), dtype=torch.float32, device=device)
+    sq = torch.empty((B * 64, 1, 64, 64), dtype=torch.float32, device=device)
     gen = torch.Generator(device=device)
-    gen.manual_seed(1234 + rank)
-    x = (torch.randint(0, 256, (B, 3, 256, 256), dtype=torch.uint8, device=device, generator=gen).float() / 255)
-    sq = torch.randint(0, 256, (B * 64, 1, 64, 64), dtype=torch.uint8, device=device, generator=gen).float()
+    for k, i in enumerate(mine):
+        gen.manual_seed(1234 + i)
+        x[k] = torch.randint(0, 256, (3, 256, 256), dtype=torch.uint8, device=device, generator=gen)
+        sq[k * 64:(k + 1) * 64] = torch.randint(0, 256, (64, 1, 64, 64), dtype=torch.uint8, device=device, generator=gen)
+    x /= 255.0
     sq /= 255.0
     streams = [torch.cuda.Stream(device), torch.cuda.Stream(device)] if args.overlap else None
 
     elapsed, out = measure(eng, x, sq, args.steps, args.warmup, device, cvd, streams)
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
+
+    # outputs stay rank-local in a throughput run; one small gather proves the shard map: per board its global index and a
+    # checksum of its 64 x 13 logits travel rank-major and must re-interleave to 0 .. world*B-1
+    tag = torch.stack([torch.tensor(mine, dtype=torch.float64, device=device),
+                       out[1].double().reshape(B, -1).sum(1)], dim=1)
+    gathered = cvd.interleave_shards(cvd.all_gather_rows(tag), world).cpu()
+    shard_ok = bool((gathered[:, 0] == torch.arange(world * B, dtype=torch.float64)).all()) and bool(torch.isfinite(gathered[:, 1]).all())
+
+    # N > 1: every rank also runs the full host-images-to-FEN pipeline on its shard of one global list of photos
+    e2e_ranks = None
+    if world > 1 and not args.no_extras:
+        e2e_ranks = pipeline_e2e_sharded(args.dtype, B, rank, world, device, cvd)
 
     if rank != 0:
         cvd.barrier(device)                              # leave together with rank 0 (it still profiles and reports)
@@ -351,11 +487,15 @@ def main():
                    "boards_per_gpu": B, "global_boards_per_step": world * B, "unet_chunk": eff_unet,
                    "resnet_chunk": eff_resnet, "parallelism": f"replicas x{world}, boards sharded, weights RCCL-broadcast once",
                    "gflop_per_board": round(2 * macs_board / 1e9, 3)},
-        "rccl_ranks_seen": rccl_ranks,
+        "rccl_ranks_seen": rccl_ranks, "dist_backend": cvd.backend_name(),
+        "sharding": {"global_boards": world * B, "rule": "rank r owns boards r::world", "gathered_in_order": shard_ok},
+        "host_threads_per_rank": cvd.host_threads(),
         "e2e_tflops": round(2 * macs_board * value / 1e12, 2),
         "roofline": roof,
         "roofline_hbm": roof_hbm,
     }
+    if e2e_ranks is not None:
+        result["pipeline_e2e_ranks"] = e2e_ranks
     oracle_out = None
     if world == 1 and not args.no_cpu_baseline:
         e2e_block = e2e_imgs = e2e_res = None
@@ -377,16 +517,17 @@ def main():
                 e2e_block.update({"fen_checked": len(ref_fens), "fen_mismatches": mism, "prob_max_abs_err_vs_oracle": perr})
             result["pipeline_e2e"] = e2e_block
     if world == 1 and not args.no_extras:
-        # the other arithmetic types and the other checkpoint variant, 3 steps each, with their own roofline and parity
+        # the other arithmetic types and the other checkpoint variant, XS steps after XW warm-ups each, with their own roofline and parity
+        XS, XW = args.extra_steps, args.extra_warmup
         by_dtype = {}
         for dt in ("f32", "f16"):
             if dt == args.dtype:
                 continue
             try:
                 e2 = make_engine(dt)
-                el, o2 = measure(e2, x, sq, 3, 1, device, cvd)
+                el, o2 = measure(e2, x, sq, XS, XW, device, cvd)
                 r2, _, _, _, _, _ = rooflines(e2, x, sq, dt, B, quiet=True)
-                entry = {"value": round(B * 3 / el, 2), "unit": "boards/sec", "ms_per_step": round(el / 3 * 1e3, 3), "steps": 3,
+                entry = {"value": round(B * XS / el, 2), "unit": "boards/sec", "ms_per_step": round(el / XS * 1e3, 3), "steps": XS, "warmup": XW,
                          "roofline": {k: r2[k] for k in ("bound", "achieved", "peak", "unit", "frac", "by_model")}}
                 if oracle_out is not None:                                # same oracle outputs as parity_vs_oracle above
                     nb_ = oracle_out[0].shape[0]
@@ -398,14 +539,18 @@ def main():
             except Exception as exc:
                 by_dtype[dt] = {"error": repr(exc)}
         result["by_dtype"] = by_dtype
+        try:
+            result["classifier_fp16"] = classifier_fp16(eng, x, sq, B, rsd, args, device, cvd, oracle_out)
+        except Exception as exc:
+            result["classifier_fp16"] = {"error": repr(exc)}
         if not bilinear:
             try:
                 usd_b = synthetic.unet_state_dict(1, True)
                 e3 = make_engine(args.dtype, usd_b)
-                el, _ = measure(e3, x, sq, 3, 1, device, cvd)
+                el, _ = measure(e3, x, sq, XS, XW, device, cvd)
                 r3, h3, _, _, _, _ = rooflines(e3, x, sq, args.dtype, B, quiet=True)
                 mb = e3.model_macs("unet") + 64 * e3.model_macs("resnet18")
-                result["by_variant"] = {"bilinear": {"value": round(B * 3 / el, 2), "unit": "boards/sec", "ms_per_step": round(el / 3 * 1e3, 3),
+                result["by_variant"] = {"bilinear": {"value": round(B * XS / el, 2), "unit": "boards/sec", "ms_per_step": round(el / XS * 1e3, 3), "steps": XS, "warmup": XW,
                                                      "gflop_per_board": round(2 * mb / 1e9, 3),
                                                      "roofline": {k: r3[k] for k in ("bound", "achieved", "peak", "unit", "frac", "by_model")},
                                                      "roofline_hbm": {k: v for k, v in h3.items() if "upsample" in k}}}

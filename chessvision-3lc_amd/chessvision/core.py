@@ -171,7 +171,7 @@ class ChessVision:
                                                    square_crops=squares)
 
     def process_images(self, images: Sequence[NDArray[np.uint8]], threshold: float = 0.5, flip: bool = False,
-                       fallback_quad: bool = False, pipeline_chunk: int = 64, return_crops: bool = False,
+                       fallback_quad: bool = False, pipeline_chunk: int = 64, return_crops: bool = True,
                        timings: dict | None = None, first_job: int | None = None) -> list[ChessVisionResult]:
         """Batched pipeline (new; the reference processes one image per call, core.py:152-195).
 
@@ -185,9 +185,11 @@ class ChessVision:
         compute stream.
 
         Results have the layout of ``process_image``; their arrays are views into the page-locked result buffers of the
-        call (copy them if they must outlive a long-running server's memory budget).  ``return_crops=False`` (default)
-        leaves ``PositionResult.squares`` as None -- the crops are ``ChessVision.extract_squares(board_image)`` and cost a
-        256 KB copy per board; ``timings`` (a dict) receives host-side seconds per stage and event-timed GPU milliseconds."""
+        call (copy them if they must outlive a long-running server's memory budget).  ``PositionResult.squares`` carries the
+        (64,64,64,1) crops as in the reference; throughput callers pass ``return_crops=False`` (None instead: the crops are
+        ``ChessVision.extract_squares(board_image)`` and cost a 256 KB host copy per board); ``timings`` (a dict) receives
+        host-side seconds per stage and event-timed GPU milliseconds.  Host worker threads (staging copies, contour stage) are
+        sized per rank: ``distributed.host_threads()`` = CPUs of this process / ranks on the host, capped."""
         started = time.time()
         for image in images:
             assert isinstance(image, np.ndarray) and image.dtype == np.uint8 and image.ndim == 3
@@ -196,7 +198,10 @@ class ChessVision:
         _ = self.board_extractor, self.classifier
         from concurrent.futures import ThreadPoolExecutor
 
+        from .distributed import host_threads
         from .hip_backend import decode_positions, find_quadrangles
+
+        n_host = host_threads()
 
         eng = self._get_engine()
         dev = self.device
@@ -239,7 +244,7 @@ class ChessVision:
         up, down = self._pipeline_streams()
         pool = self._copy_pool
         if pool is None:
-            pool = self._copy_pool = ThreadPoolExecutor(max_workers=16, thread_name_prefix="cv-stage")
+            pool = self._copy_pool = ThreadPoolExecutor(max_workers=min(16, n_host), thread_name_prefix="cv-stage")
 
         def segment(ids, slice_upload=False):               # host -> device (own stream), resize, UNet; masks start back
             t0 = time.perf_counter()
@@ -290,7 +295,7 @@ class ChessVision:
             clock("wait_masks_s", t0)
             ids = st["ids"]
             t0 = time.perf_counter()
-            found_quads = find_quadrangles(st["masks"].numpy())
+            found_quads = find_quadrangles(st["masks"].numpy(), n_threads=n_host)
             clock("contours_s", t0)
             t0 = time.perf_counter()
             quads = []

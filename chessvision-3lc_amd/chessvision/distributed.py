@@ -23,11 +23,66 @@ def env_world() -> tuple[int, int, int]:
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
+def local_world_size() -> int:
+    """Ranks sharing this host (torchrun exports LOCAL_WORLD_SIZE; one node: the world size)."""
+    return max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
+
+
+def host_threads(cap: int = 32) -> int:
+    """Host worker threads ONE rank may use (contour threads, staging copies, torch intra-op): the CPUs this process may run
+    on divided by the ranks of the host, capped.  Eight ranks that each start 32 contour + 16 copy threads oversubscribe a
+    256-CPU host exactly where the CPU baseline's thread sweep shows it hurts (14 -> 2 boards/s from 16 to 128 threads)."""
+    try:
+        cpus = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cpus = os.cpu_count() or 1
+    if os.environ.get("CV_RANK_CPUS_PINNED") == "1":            # pin_rank_cpus already narrowed the affinity mask to this rank's share
+        return max(1, min(cap, cpus))
+    return max(1, min(cap, cpus // local_world_size()))
+
+
+def pin_rank_cpus() -> list[int] | None:
+    """Give every local rank its own contiguous block of the CPUs the job may use (in-process ``sched_setaffinity``; no
+    ``taskset`` / ``numactl`` wrapper, which would be an exec hop in front of the GPU process).  Off with CV_PIN_RANK_CPUS=0
+    or when the host has fewer CPUs than ranks.  Returns the block, or None when nothing was pinned."""
+    lw = local_world_size()
+    if lw <= 1 or os.environ.get("CV_PIN_RANK_CPUS", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+        return None
+    cpus = sorted(os.sched_getaffinity(0))
+    per = len(cpus) // lw
+    if per < 1:
+        return None
+    lr = int(os.environ.get("LOCAL_RANK", "0")) % lw
+    mine = cpus[lr * per:(lr + 1) * per]
+    os.sched_setaffinity(0, mine)
+    os.environ["CV_RANK_CPUS_PINNED"] = "1"
+    return mine
+
+
+def backend_name() -> str | None:
+    return dist.get_backend() if dist.is_initialized() else None
+
+
+def _coll_device(device: torch.device) -> torch.device:
+    """Where collective buffers live: the GPU under RCCL, host memory under gloo (two ranks may then share ONE GPU, which RCCL
+    refuses -- CV_DIST_BACKEND=gloo is how the N > 1 code path is exercised on a one-GPU box)."""
+    return device if backend_name() == "nccl" else torch.device("cpu")
+
+
 def init_process_group(backend: str | None = None) -> tuple[int, int, torch.device]:
-    """Initialise torch.distributed from env when WORLD_SIZE > 1; returns (rank, world, device)."""
+    """Initialise torch.distributed from env when WORLD_SIZE > 1; returns (rank, world, device).
+
+    Backend: the argument, else CV_DIST_BACKEND, else "nccl" (= RCCL) with a GPU and "gloo" without.  Under gloo the ranks of a
+    host may outnumber its GPUs (rank -> device ``LOCAL_RANK % device_count``).  With several ranks per host every rank is
+    pinned to its share of the CPUs and torch's intra-op pool is sized to it (``host_threads``)."""
     rank, world, local = env_world()
+    backend = backend or os.environ.get("CV_DIST_BACKEND") or None
     use_gpu = torch.cuda.is_available()
     if use_gpu:
+        n_dev = torch.cuda.device_count()
+        if local >= n_dev and backend != "gloo":
+            raise RuntimeError(f"LOCAL_RANK {local} but {n_dev} device(s): RCCL needs one GPU per rank (CV_DIST_BACKEND=gloo shares)")
+        local = local % max(1, n_dev)
         torch.cuda.set_device(local)
     device = torch.device("cuda", local) if use_gpu else torch.device("cpu")
     force = os.environ.get("CV_FORCE_DIST", "0") == "1"          # exercise the RCCL path on one GPU (tests)
@@ -35,10 +90,14 @@ def init_process_group(backend: str | None = None) -> tuple[int, int, torch.devi
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = backend or ("nccl" if use_gpu else "gloo")
         kwargs = {}
-        if use_gpu:
+        if use_gpu and backend == "nccl":
             kwargs["device_id"] = device
-        dist.init_process_group(backend or ("nccl" if use_gpu else "gloo"), rank=rank, world_size=world, **kwargs)
+        dist.init_process_group(backend, rank=rank, world_size=world, **kwargs)
+    if local_world_size() > 1:
+        pin_rank_cpus()
+        torch.set_num_threads(host_threads())
     return rank, world, device
 
 
@@ -80,11 +139,12 @@ def broadcast_state_dict(state: Mapping[str, np.ndarray] | None, spec: Sequence[
         return OrderedDict((k, np.ascontiguousarray(state[k], dtype=np.float32)) for k, _, _ in spec)
     total = sum(int(np.prod(s)) for _, s, _ in spec)
     rank = dist.get_rank()
+    cdev = _coll_device(device)
     if rank == src:
         assert state is not None, "source rank must provide the state dict"
-        flat = flatten_state(state, spec).to(device)
+        flat = flatten_state(state, spec).to(cdev)
     else:
-        flat = torch.empty(total, dtype=torch.float32, device=device)
+        flat = torch.empty(total, dtype=torch.float32, device=cdev)
     dist.broadcast(flat, src=src)
     return unflatten_state(flat, spec)
 
@@ -93,9 +153,11 @@ def all_gather_rows(local: torch.Tensor) -> torch.Tensor:
     """Concatenate equally-shaped per-rank result tensors along dim 0, rank-major."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return local
-    out = [torch.empty_like(local) for _ in range(dist.get_world_size())]
-    dist.all_gather(out, local.contiguous())
-    return torch.cat(out, dim=0)
+    cdev = _coll_device(local.device)
+    mine = local.contiguous().to(cdev)
+    out = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return torch.cat(out, dim=0).to(local.device)
 
 
 def interleave_shards(gathered: torch.Tensor, world: int) -> torch.Tensor:
@@ -107,16 +169,27 @@ def interleave_shards(gathered: torch.Tensor, world: int) -> torch.Tensor:
 def max_over_ranks(value: float, device: torch.device) -> float:
     if not dist.is_initialized():
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device=_coll_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def stats_over_ranks(value: float, device: torch.device) -> dict:
+    """{min, mean, max} of a per-rank scalar (every rank gets the same dict)."""
+    if not dist.is_initialized():
+        return {"min": value, "mean": value, "max": value}
+    t = torch.tensor([value], dtype=torch.float64, device=_coll_device(device))
+    got = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(got, t)
+    vals = [float(g.item()) for g in got]
+    return {"min": min(vals), "mean": sum(vals) / len(vals), "max": max(vals)}
 
 
 def count_ranks(device: torch.device) -> int:
     """All-reduce of a one per rank: the number of ranks that really took part in a collective (1 without a process group)."""
     if not dist.is_initialized():
         return 1
-    t = torch.ones(1, dtype=torch.int32, device=device)
+    t = torch.ones(1, dtype=torch.int32, device=_coll_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return int(t.item())
 
@@ -129,7 +202,88 @@ def shutdown() -> None:
 
 def barrier(device: torch.device) -> None:
     if dist.is_initialized():
-        if device.type == "cuda":
+        if device.type == "cuda" and backend_name() == "nccl":
             dist.barrier(device_ids=[device.index])
         else:
             dist.barrier()
+
+
+def process_images_sharded(cv, images: Sequence, threshold: float = 0.5, flip: bool = False, fallback_quad: bool = False,
+                           gather: bool = True, gather_masks: bool = True, timings: dict | None = None, **kw) -> list:
+    """One global batch of board photos over all ranks (BASELINE configs[4]): rank r runs
+    ``ChessVision.process_images`` on images ``r::world`` -- the reference's per-image loop of ``scripts/eval/evaluate.py:264-271``,
+    sharded -- and, with ``gather``, every rank returns the results of ALL images in the caller's order.
+
+    ``images`` is only indexed at this rank's positions (a lazy sequence may produce them on demand).  What travels: per board the
+    64x13 soft-max probabilities (3.3 KB), the quadrangle (32 B) and, with ``gather_masks``, the 64 KB binary mask -- one
+    ``all_gather`` per field, rank-major, re-interleaved to board order; FEN strings and pawn-rule fixes of the other ranks' boards
+    are re-derived from the gathered probabilities by the same native decoder that produced the local ones, so all ranks hold
+    identical results.  Boards of other ranks carry no rectified image, logits or crops (they stay on the rank that computed them).
+    ``gather=False``: only this rank's results come back, ``None`` elsewhere (throughput runs).  ``timings`` receives the local
+    pipeline's stage times plus ``shard_s`` (this rank's ``process_images``) and ``gather_s``."""
+    import time
+
+    from . import constants
+    from .cv_types import BoardExtractionResult, ChessVisionResult, PositionResult, ValidationFix
+    from .hip_backend import decode_positions
+
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    n = len(images)
+    mine = list(shard_indices(n, rank, world))
+    tm = timings if timings is not None else {}
+    t0 = time.perf_counter()
+    local = cv.process_images([images[i] for i in mine], threshold=threshold, flip=flip, fallback_quad=fallback_quad,
+                              timings=tm, **kw) if mine else []
+    tm["shard_s"] = time.perf_counter() - t0
+    tm["shard_boards"] = len(mine)
+    results: list = [None] * n
+    for i, r in zip(mine, local):
+        results[i] = r
+    if not gather or world == 1:
+        tm["gather_s"] = 0.0
+        return results
+
+    t0 = time.perf_counter()
+    per = -(-n // world)                                         # equal shard size for the collectives; short shards are padded
+    probs = np.zeros((per, 64, constants.NUM_CLASSES), np.float32)
+    quads = np.zeros((per, 9), np.float32)                       # 8 coordinates + "found" flag
+    flags = np.zeros((per, 1), np.float32)                       # board classified
+    masks = np.zeros((per, 256, 256), np.uint8) if gather_masks else None
+    for k, r in enumerate(local):
+        be = r.board_extraction
+        if be.quadrangle is not None:
+            quads[k, :8] = np.asarray(be.quadrangle, np.float32).reshape(8)
+            quads[k, 8] = 1.0
+        if masks is not None:
+            masks[k] = be.binary_mask
+        if r.position is not None:
+            probs[k] = r.position.model_probabilities
+            flags[k, 0] = 1.0
+    g_probs = interleave_shards(all_gather_rows(torch.from_numpy(probs)), world).numpy()[:n]
+    g_quads = interleave_shards(all_gather_rows(torch.from_numpy(quads)), world).numpy()[:n]
+    g_flags = interleave_shards(all_gather_rows(torch.from_numpy(flags)), world).numpy()[:n, 0] > 0
+    g_masks = interleave_shards(all_gather_rows(torch.from_numpy(masks)), world).numpy()[:n] if masks is not None else None
+    names = constants.SQUARE_NAMES_FLIPPED if flip else constants.SQUARE_NAMES_NORMAL
+    remote = [i for i in range(n) if results[i] is None]
+    cls = [i for i in remote if g_flags[i]]
+    fens, origs, fix_lists = [], [], []
+    if cls:
+        fens, origs, _, fixes = decode_positions(np.ascontiguousarray(g_probs[cls]), flip)
+        fix_lists = [[] for _ in cls]
+        for b, sq, old, new in fixes:
+            fix_lists[b].append(ValidationFix(square_name=names[sq], original_piece=constants.LABEL_NAMES[old],
+                                              corrected_piece=constants.LABEL_NAMES[new], rule_name="no_pawns_on_ends"))
+    where = {i: j for j, i in enumerate(cls)}
+    for i in remote:
+        quad = g_quads[i, :8].reshape(4, 1, 2).copy() if g_quads[i, 8] > 0 else None
+        extraction = BoardExtractionResult(board_image=None, binary_mask=None if g_masks is None else g_masks[i],
+                                           quadrangle=quad, probabilities=None)
+        position = None
+        if i in where:
+            j = where[i]
+            position = PositionResult(fen=fens[j], original_fen=origs[j], model_probabilities=g_probs[i], squares=None,
+                                      square_names=names, validation_fixes=fix_lists[j])
+        results[i] = ChessVisionResult(board_extraction=extraction, position=position, processing_time=0.0)
+    tm["gather_s"] = time.perf_counter() - t0
+    return results

@@ -21,10 +21,11 @@ import numpy as np
 import torch
 
 _LIB_NAME = "libchessvision_hip.so"
-PREC_F32, PREC_F16, PREC_F16X3 = 0, 1, 2
+PREC_F32, PREC_F16, PREC_F16X3, PREC_F16R = 0, 1, 2, 3
+ABI_VERSION = 2
 _PRECISIONS = {"f32": PREC_F32, "fp32": PREC_F32, "float32": PREC_F32, "f16": PREC_F16, "fp16": PREC_F16,
-               "float16": PREC_F16, "f16x3": PREC_F16X3, "split": PREC_F16X3}
-_PREC_NAMES = {PREC_F32: "f32", PREC_F16: "f16", PREC_F16X3: "f16x3"}
+               "float16": PREC_F16, "f16x3": PREC_F16X3, "split": PREC_F16X3, "f16r": PREC_F16R}
+_PREC_NAMES = {PREC_F32: "f32", PREC_F16: "f16", PREC_F16X3: "f16x3", PREC_F16R: "f16r"}
 
 
 class HipBackendError(RuntimeError):
@@ -86,6 +87,7 @@ SYMBOLS = [
     ("cv_engine_numeric_status", _i, [_vp, _vp]),
     ("cv_get_activation_exponent", _i, [_vp, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(_i)]),
     ("cv_profile_entry_bytes", _i, [_vp, _i, ctypes.POINTER(ctypes.c_double)]),
+    ("cv_profile_entry_kernel", _i, [_vp, _i, ctypes.c_char_p, _i]),
     ("cv_decode_positions", _i, [_fp, _i, _i, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int8),
                                  ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
 ]
@@ -102,12 +104,16 @@ def load_library():
                     f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                     "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
             lib = ctypes.CDLL(str(path))
+            lib.cv_abi_version.restype = ctypes.c_int
+            lib.cv_abi_version.argtypes = []
+            found = lib.cv_abi_version()
+            if found != ABI_VERSION:               # before binding the rest: a stale build fails with this, not an AttributeError
+                raise HipBackendError(f"{path}: ABI version {found}, this package needs {ABI_VERSION} -- rebuild the library "
+                                      "(`python -c 'import __graft_entry__ as g; g.build()'`)")
             for name, restype, argtypes in SYMBOLS:
                 fn = getattr(lib, name)            # AttributeError if the export is missing
                 fn.restype = restype
                 fn.argtypes = argtypes
-            if lib.cv_abi_version() != 1:
-                raise HipBackendError("libchessvision_hip ABI version mismatch")
             _lib = lib
     return _lib
 
@@ -384,13 +390,14 @@ class HipEngine:
                                           ctypes.byref(all_ms)))
         entries = []
         idx = 0
-        name = ctypes.create_string_buffer(128)
+        name, kern = ctypes.create_string_buffer(128), ctypes.create_string_buffer(160)
         ms, macs, is_conv, nbytes = _f(), ctypes.c_double(), _i(), ctypes.c_double()
         while self._lib.cv_profile_entry(self._h, idx, name, 128, ctypes.byref(ms), ctypes.byref(macs),
                                          ctypes.byref(is_conv)) == 0:
             _check(self._lib.cv_profile_entry_bytes(self._h, idx, ctypes.byref(nbytes)))
+            _check(self._lib.cv_profile_entry_kernel(self._h, idx, kern, 160))
             entries.append({"name": name.value.decode(), "ms": ms.value, "macs": macs.value, "conv": bool(is_conv.value),
-                            "bytes": nbytes.value})
+                            "bytes": nbytes.value, "kernel": kern.value.decode()})
             idx += 1
         return conv_ms.value, launches.value, all_ms.value, entries
 

@@ -90,6 +90,12 @@ def ratio(a: float, b: float) -> float:
     return min(a, b) / float(max(a, b))
 
 
+def listdir_nohidden(path: str) -> list[str]:
+    """Directory entries that do not start with a dot (public helper of the reference's ``utils.py:96-98``; its eval and
+    data scripts import it from here)."""
+    return [name for name in os.listdir(path) if name[:1] != "."]
+
+
 def create_binary_mask(mask: NDArray[np.float32], threshold: float = 0.5) -> NDArray[np.uint8]:
     """probability > threshold -> 255 else 0 (reference utils.py:101-112)."""
     assert isinstance(mask, np.ndarray), "Mask must be a numpy array"

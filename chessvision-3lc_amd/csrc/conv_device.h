@@ -184,6 +184,20 @@ template <int N> struct OutVec<split_t, N> {
 };
 
 
+// f16r engine (f16 kernels only): the residual trunk's f32 twin.  A unit = 8 consecutive channels = two 16-byte chunks.
+__device__ __forceinline__ void trunk32_fetch(const float* src, f4* raw) {
+    raw[0] = *reinterpret_cast<const f4*>(src);
+    raw[1] = *reinterpret_cast<const f4*>(src + 4);
+}
+__device__ __forceinline__ void trunk32_add_raw(const f4* raw, float* v, float mul) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = __builtin_fmaf(raw[0][j], mul, v[j]); v[4 + j] = __builtin_fmaf(raw[1][j], mul, v[4 + j]); }
+}
+__device__ __forceinline__ void trunk32_store(float* dst, const float* v) {
+    *reinterpret_cast<f4*>(dst) = f4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f4*>(dst + 4) = f4{v[4], v[5], v[6], v[7]};
+}
+
 // A lane whose `bad` accumulator went NaN stored a non-finite value: record the launch's layer id (lowest id wins, so
 // the host names the FIRST layer that left the representable range).
 __device__ __forceinline__ void report_bad(const ConvParams& p, float bad) {

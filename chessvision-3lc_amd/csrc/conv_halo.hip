@@ -608,8 +608,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     // Residual (ResNet shortcut): every unit this lane will add is fetched NOW, in one burst, so that the loads' latency passes
     // behind the staging of the first rows instead of being paid unit by unit inside the store loop (in-kernel stamps, r02: the
     // epilogue of a residual layer took 26 k cycles against 11 k without one -- as long as the 18-stage K loop itself).
-    constexpr int RC = OutVec<T, UN>::kRawChunks;
+    constexpr bool kHalf = __is_same(T, half_t);         // f16 kernels can take the shortcut from the trunk's f32 twin (two chunks per unit)
+    constexpr int RC = kHalf ? 2 : OutVec<T, UN>::kRawChunks;
     constexpr bool kPrefetchRes = !PERSIST && NW == 4;   // the 4-wave tile has the registers (FP x UPL units x RC chunks)
+    const bool res32 = kHalf && p.res_f32;               // wave-uniform
+    const float* const rbase32 = reinterpret_cast<const float*>(p.res);
+    float* const ybase32 = kHalf ? reinterpret_cast<float*>(p.y32) : nullptr;
     f4 rraw[kPrefetchRes ? FP : 1][UPL][RC];
     if constexpr (kPrefetchRes) {
         if (rbase) {
@@ -620,8 +624,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     const int unit = lane + 64 * i, px = unit / UPP, co = slab0 + (unit % UPP) * UN;
                     bool live;
                     const unsigned ob = out_pixel(g, px, &live);
-                    if (co < p.rows && live) OutVec<T, UN>::fetch(rbase + (ob * (unsigned)p.rCs + (unsigned)(p.rCoff + co)), rraw[g][i]);
-                    else {
+                    if (co < p.rows && live) {
+                        if (res32) trunk32_fetch(rbase32 + (ob * (unsigned)p.rCs + (unsigned)(p.rCoff + co)), rraw[g][i]);
+                        else OutVec<T, UN>::fetch(rbase + (ob * (unsigned)p.rCs + (unsigned)(p.rCoff + co)), rraw[g][i]);
+                    } else {
 #pragma unroll
                         for (int c = 0; c < RC; ++c) rraw[g][i][c] = f4{0.f, 0.f, 0.f, 0.f};
                     }
@@ -665,7 +671,16 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 const unsigned ob = out_pixel(g0 + r, px, &live);
                 if (co < p.rows && live) {
                     if (rbase) {                         // tensors stay below 4 GiB (checked on the host): 32-bit element offsets
-                        if constexpr (kPrefetchRes) OutVec<T, UN>::add_raw(rraw[g0 + r][i], p.rCoff + co, w[r], p.res_mul);
+                        if (res32) {
+                            if constexpr (kHalf) {
+                                if constexpr (kPrefetchRes) trunk32_add_raw(rraw[g0 + r][i], w[r], p.res_mul);
+                                else {
+                                    f4 raw[2];
+                                    trunk32_fetch(rbase32 + (ob * (unsigned)p.rCs + (unsigned)(p.rCoff + co)), raw);
+                                    trunk32_add_raw(raw, w[r], p.res_mul);
+                                }
+                            }
+                        } else if constexpr (kPrefetchRes) OutVec<T, UN>::add_raw(rraw[g0 + r][i], p.rCoff + co, w[r], p.res_mul);
                         else OutVec<T, UN>::add(rbase + (ob * (unsigned)p.rCs + (unsigned)(p.rCoff + co)), p.rCoff + co, w[r], p.res_mul);
                         if (p.relu) {
 #pragma unroll
@@ -673,6 +688,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
                         }
                     }
                     OutVec<T, UN>::store(ybase + (ob * (unsigned)p.yCs + (unsigned)(p.yCoff + co)), p.yCoff + co, w[r], bad);
+                    if constexpr (kHalf) {
+                        if (ybase32) trunk32_store(ybase32 + (ob * (unsigned)p.yCs + (unsigned)(p.yCoff + co)), w[r]);
+                    }
                 }
             }
             if (IMG == 0 && pbase) {                     // wave-uniform: fused 2x2 max-pool of the (post-ReLU) row pair

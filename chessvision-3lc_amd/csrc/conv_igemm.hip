@@ -371,12 +371,26 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvParams p)
                 ob += (unsigned)((grp >> 1) * p.yWp + (grp & 1));
             }
             if (lv && row < p.rows) {
-                if (rbase) OutVec<T, UN>::add(rbase + (size_t)ob * p.rCs + p.rCoff + co, p.rCoff + co, w, p.res_mul);
+                if (rbase) {
+                    bool done = false;
+                    if constexpr (__is_same(T, half_t)) {
+                        if (p.res_f32) {                 // wave-uniform: the shortcut comes from the trunk's f32 twin
+                            f4 raw[2];
+                            trunk32_fetch(reinterpret_cast<const float*>(p.res) + (size_t)ob * p.rCs + p.rCoff + co, raw);
+                            trunk32_add_raw(raw, w, p.res_mul);
+                            done = true;
+                        }
+                    }
+                    if (!done) OutVec<T, UN>::add(rbase + (size_t)ob * p.rCs + p.rCoff + co, p.rCoff + co, w, p.res_mul);
+                }
                 if (p.relu) {
 #pragma unroll
                     for (int j = 0; j < UN; ++j) w[j] = w[j] > 0.f ? w[j] : 0.f;
                 }
                 OutVec<T, UN>::store(ybase + (size_t)ob * p.yCs + p.yCoff + co, p.yCoff + co, w, bad);
+                if constexpr (__is_same(T, half_t)) {
+                    if (p.y32) trunk32_store(reinterpret_cast<float*>(p.y32) + (size_t)ob * p.yCs + p.yCoff + co, w);
+                }
             }
         }
         asm volatile("" ::: "memory");

@@ -62,6 +62,8 @@ Status to_map(const cv_param_t* params, int n, ParamMap& pm) {
     for (int i = 0; i < n; ++i) {
         const cv_param_t& p = params[i];
         if (!p.name || !p.data || p.ndim < 0 || p.ndim > 4) return fail(CV_ERR_INVALID, "malformed cv_param_t entry " + std::to_string(i));
+        const size_t nl = std::strlen(p.name);
+        if (nl >= 19 && std::strcmp(p.name + nl - 19, "num_batches_tracked") == 0) continue;   // a full torch state dict may carry them
         ParamView v;
         v.data = p.data;
         for (int d = 0; d < p.ndim; ++d) v.shape.push_back(p.shape[d]);
@@ -89,7 +91,7 @@ static int impl_cv_device_count(int* count) {
 static int impl_cv_engine_create(int device, int precision, cv_engine_t** out) {
     if (!out) return finish(fail(CV_ERR_INVALID, "null out pointer"));
     *out = nullptr;
-    if (precision != CV_PREC_F32 && precision != CV_PREC_F16 && precision != CV_PREC_F16X3)
+    if (precision != CV_PREC_F32 && precision != CV_PREC_F16 && precision != CV_PREC_F16X3 && precision != CV_PREC_F16R)
         return finish(fail(CV_ERR_INVALID, "unknown precision"));
     static_assert((int)CV_PREC_F32 == (int)kF32 && (int)CV_PREC_F16 == (int)kF16 && (int)CV_PREC_F16X3 == (int)kSplit, "enum values must match");
     int count = 0;
@@ -107,7 +109,8 @@ static int impl_cv_engine_create(int device, int precision, cv_engine_t** out) {
     cv_engine* eng = new (std::nothrow) cv_engine();
     if (!eng) return finish(fail(CV_ERR_NOMEM, "out of host memory"));
     eng->impl.device = device;
-    eng->impl.dt = precision;                      // CV_PREC_* values equal cv::DType
+    eng->impl.dt = precision == CV_PREC_F16R ? (int)kF16 : precision;   // CV_PREC_F32 / F16 / F16X3 values equal cv::DType
+    eng->impl.trunk32 = precision == CV_PREC_F16R;
     Status gs = eng->impl.guard_init();
     if (!gs.ok()) { delete eng; return finish(gs); }
     *out = eng;
@@ -224,7 +227,7 @@ static int impl_cv_get_activation(cv_engine_t* eng, const char* model, const cha
     s = tmp.alloc(numel * sizeof(float), false);
     if (!s.ok()) return finish(s);
     hipError_t e = hipDeviceSynchronize();
-    if (e == hipSuccess) e = unpack_nchw_f32(eng->impl.dt, t, (float*)tmp.ptr, nullptr);
+    if (e == hipSuccess) e = unpack_nchw_f32(t.f32_only ? (int)kF32 : eng->impl.dt, t, (float*)tmp.ptr, nullptr);
     if (e == hipSuccess) e = hipMemcpy(out_host, tmp.ptr, numel * sizeof(float), hipMemcpyDeviceToHost);
     if (e != hipSuccess) return finish(hip_fail(e, "cv_get_activation"));
     return CV_OK;
@@ -469,6 +472,18 @@ static int impl_cv_profile_entry_bytes(cv_engine_t* eng, int index, double* byte
     return CV_OK;
 }
 
+static int impl_cv_profile_entry_kernel(cv_engine_t* eng, int index, char* kernel, int kernel_cap) {
+    Status s = check_engine(eng);
+    if (!s.ok()) return finish(s);
+    std::lock_guard<std::mutex> lk(eng->impl.mu);
+    if (!kernel || kernel_cap <= 0 || index < 0 || index >= (int)eng->impl.prof.size()) return finish(fail(CV_ERR_INVALID, "profile index out of range"));
+    const std::string& k = eng->impl.prof[index].kernel;
+    const size_t n = std::min(k.size(), (size_t)kernel_cap - 1);
+    std::memcpy(kernel, k.data(), n);
+    kernel[n] = 0;
+    return CV_OK;
+}
+
 static int impl_cv_engine_numeric_status(cv_engine_t* eng, void* stream) {
     Status s = check_engine(eng);
     if (!s.ok()) return finish(s);
@@ -680,6 +695,10 @@ int cv_op_outc_1x1(cv_engine_t* eng, const float* x, int n, int c, int h, int w_
 
 int cv_profile_entry_bytes(cv_engine_t* eng, int index, double* bytes) {
     return guarded("cv_profile_entry_bytes", [&]() -> int { return impl_cv_profile_entry_bytes(eng, index, bytes); });
+}
+
+int cv_profile_entry_kernel(cv_engine_t* eng, int index, char* kernel, int kernel_cap) {
+    return guarded("cv_profile_entry_kernel", [&]() -> int { return impl_cv_profile_entry_kernel(eng, index, kernel, kernel_cap); });
 }
 
 int cv_engine_numeric_status(cv_engine_t* eng, void* stream) {

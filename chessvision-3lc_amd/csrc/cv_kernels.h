@@ -33,6 +33,8 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 struct TensorRef {            // a channel slice of a PHWC tensor
     void* base;               // address of padded element (n=0, y=-1, x=-1, c=0)
+    void* base32;             // f16r engine only: the tensor's unrounded f32 twin (same geometry, float elements) or null --
+                              // residual adds read it and block outputs write it, so the ResNet trunk never rounds to f16
     int N, H, W;              // interior extent
     int Cs;                   // channel stride of the underlying buffer (elements)
     int Coff;                 // first channel of the slice
@@ -45,6 +47,7 @@ struct TensorRef {            // a channel slice of a PHWC tensor
     // exponent exp + exp_delta (the consumer folds 2^exp_delta into its weights for those input channels); 0 / 0 otherwise
     int split;
     int exp_delta;
+    int f32_only;             // f16r engine: the tensor exists as f32 only (`base` already points at the f32 buffer); 0 otherwise
 };
 
 // Implicit-GEMM convolution:  D[ch][pix] = sum_k Wt[ch][k] * X[pix][k]
@@ -58,6 +61,8 @@ struct ConvParams {
     const float* shift;       // [rows] epilogue shift  (BN beta - mean*scale, or conv bias) x 2^-out_exp
     const char* res;          // optional residual PHWC base (same pixel grid as the output), or null
     float res_mul;            // residual multiplier 2^(res_exp - out_exp): brings the shortcut tensor to the output's scale
+    int res_f32;              // f16 kernels only: `res` is the f32 twin of the shortcut tensor (float PHWC, same rCs / rCoff)
+    char* y32;                // f16 kernels only: optional second output, the unrounded f32 twin of y (same yCs / yCoff), or null
     char* y;                  // output PHWC base
     int M;                    // output pixels = N*Ho*Wo
     int Ho, Wo;               // output pixel grid per image

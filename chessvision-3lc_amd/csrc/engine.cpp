@@ -43,11 +43,31 @@ Status DeviceBuffer::upload(const void* host, size_t n) {
 }
 
 Status Activation::reserve(int cap_) {
-    cap = cap_;
-    const size_t total = bytes_per_image() * (size_t)cap;
-    if (total >= ((size_t)1 << 32))
-        return fail(1, "activation buffer >= 4 GiB: lower the chunk size (32-bit DMA offsets)");
-    return buf.alloc(total, /*zero=*/true);     // zero border, written never again
+    std::vector<Activation*> one{this};
+    return reserve_all(one, cap_);
+}
+
+Status Activation::reserve_all(const std::vector<Activation*>& acts, int cap_) {
+    std::vector<DeviceBuffer> fresh(acts.size()), fresh32(acts.size());
+    for (size_t i = 0; i < acts.size(); ++i) {
+        const Activation& a = *acts[i];
+        const size_t total = a.bytes_per_image() * (size_t)cap_;
+        if (total >= ((size_t)1 << 32))
+            return fail(1, "activation buffer >= 4 GiB: lower the chunk size (32-bit DMA offsets)");
+        if (!a.only32) CV_TRY(fresh[i].alloc(total, /*zero=*/true));   // zero border, written never again
+        if (a.want32) {
+            const size_t t32 = (size_t)(a.H + 2) * (a.W + 2) * a.C * sizeof(float) * (size_t)cap_;
+            if (t32 >= ((size_t)1 << 32)) return fail(1, "f32 trunk buffer >= 4 GiB: lower the chunk size");
+            CV_TRY(fresh32[i].alloc(t32, true));
+        }
+    }
+    // nothing can fail from here on: swap the new buffers in, the old ones are freed with `fresh`
+    for (size_t i = 0; i < acts.size(); ++i) {
+        acts[i]->buf.swap(fresh[i]);
+        acts[i]->buf32.swap(fresh32[i]);
+        acts[i]->cap = cap_;
+    }
+    return Status();
 }
 
 // ---- implicit-GEMM weight packing ----------------------------------------------------------------
@@ -392,7 +412,7 @@ Status Engine::measure(const TensorRef& t, hipStream_t s) {
     Activation* a = static_cast<Activation*>(t.owner);
     if (!a) return Status();
     CV_HIP(hipMemsetAsync(cal_word.ptr, 0, sizeof(unsigned), s));
-    CV_HIP(absmax(dt, t, reinterpret_cast<unsigned*>(cal_word.ptr), s));
+    CV_HIP(absmax(t.f32_only ? (int)kF32 : dt, t, reinterpret_cast<unsigned*>(cal_word.ptr), s));
     unsigned bits = 0;
     CV_HIP(hipMemcpyAsync(&bits, cal_word.ptr, sizeof(bits), hipMemcpyDeviceToHost, s));
     CV_HIP(hipStreamSynchronize(s));
@@ -407,14 +427,19 @@ Status Engine::measure(const TensorRef& t, hipStream_t s) {
 
 size_t Engine::workspace_bytes() const {
     size_t total = 0;
-    if (unet) for (const Activation* a : unet->acts) total += a->buf.bytes;
-    if (resnet) for (const Activation* a : resnet->acts) total += a->buf.bytes;
+    if (unet) for (const Activation* a : unet->acts) total += a->buf.bytes + a->buf32.bytes;
+    if (resnet) for (const Activation* a : resnet->acts) total += a->buf.bytes + a->buf32.bytes;
     return total;
 }
 
 Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, const TensorRef* res, bool relu,
                         hipStream_t s, const Head* head, const TensorRef* pool_out, const Fuse0* fuse0) {
     if (x.C != L.cinPad) return fail(1, L.name + ": input slice has " + std::to_string(x.C) + " channels, layer packs " + std::to_string(L.cinPad));
+    // a layer normally runs in the engine's arithmetic; the f16r engine runs the ResNet shortcut convolutions in f32 on the
+    // trunk's f32 twins (L.dt == kF32, x / y = Activation::ref32)
+    const int dt = L.dt;
+    if ((x.f32_only != 0) != (dt == kF32 && this->dt != kF32) || x.f32_only != y.f32_only)
+        return fail(1, L.name + ": layer precision and tensor storage disagree");
     const int esz = dtype_size(dt);
     if (dt == kSplit && (x.Coff % 8 || y.Coff % 8 || (res && res->Coff % 8)))
         return fail(1, L.name + ": split-f16 slices must start on an 8-channel group");
@@ -449,7 +474,10 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
         if (res->H != y.H || res->W != y.W || res->C != y.C) return fail(1, L.name + ": residual shape mismatch");
         p.res = reinterpret_cast<const char*>(res->base); p.rCs = res->Cs; p.rCoff = res->Coff;
         p.res_mul = std::ldexp(1.f, res->exp - out_exp);
+        if (trunk32 && dt == kF16 && res->base32) { p.res = reinterpret_cast<const char*>(res->base32); p.res_f32 = 1; }
+        else if (!res->base) return fail(1, L.name + ": residual tensor has no storage in this precision");
     }
+    if (trunk32 && dt == kF16 && y.base32 && !head) p.y32 = reinterpret_cast<char*>(y.base32);
     p.flag = guard_ptr();
     p.layer_id = L.layer_id;
     p.y = reinterpret_cast<char*>(y.base);
@@ -502,10 +530,18 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
         const double out_px = L.shuffle ? 4.0 * p.M : (double)p.M;
         double b = (fuse0 ? in_px * (fuse0->u8 ? 3.0 : 12.0) : in_px * L.cinPad * esz) + (double)L.rows * L.k * L.k * L.cin * esz;
         b += head ? (double)p.M * (4 + (head->mask ? 1 : 0)) : out_px * L.cout * esz;
-        if (res) b += out_px * L.cout * esz;
+        if (res) b += out_px * L.cout * (p.res_f32 ? 4 : esz);
+        if (p.y32) b += out_px * L.cout * 4;                 // f16r: the trunk's f32 twin
         if (pool_out) b += out_px / 4 * L.cout * esz;
         prof_begin(fuse0 ? "inc.double_conv.0+3 (fused)" : L.name, true,
                    ((double)L.macs_per_out_pixel() + (fuse0 ? fuse0->macs_per_pixel : 0.0)) * (double)p.M, s, b);
+        const char* tn = dt == kF32 ? "float" : dt == kF16 ? "half_t" : "split_t";
+        if (halo)
+            prof.back().kernel = std::string("conv3x3_halo_kernel<") + tn + "," + std::to_string(ct) + ",16x16" +
+                                 (Ho == 8 ? ",IMG8" : "") + (fuse0 ? ",FUSE0" : "") + (fuse_pool ? ",pool" : "") + (head ? ",head" : "") + ">";
+        else
+            prof.back().kernel = std::string("conv_igemm_kernel<") + tn + "," + std::to_string(conv_cfg_ct(cfg)) + "x" +
+                                 std::to_string(conv_cfg_pt(cfg)) + ",ring" + std::to_string(ns) + (L.shuffle ? ",shuffle" : "") + ">";
     }
     hipError_t e = halo ? conv_halo_launch(ct, dt, p, x.N, s) : conv_igemm_launch(cfg, ns, dt, p, s);
     if (profiling) prof_end(s);

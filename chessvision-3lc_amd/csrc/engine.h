@@ -8,6 +8,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "conv_igemm.h"
@@ -54,6 +55,7 @@ struct DeviceBuffer {
     ~DeviceBuffer();
     Status alloc(size_t n, bool zero);
     Status upload(const void* host, size_t n);
+    void swap(DeviceBuffer& o) { std::swap(ptr, o.ptr); std::swap(bytes, o.bytes); }
 };
 
 // a PHWC activation buffer sized for `cap` images
@@ -67,6 +69,12 @@ struct DeviceBuffer {
 // values; what still leaves the range trips the numeric guard (ConvParams::flag).  Always 0 for the f32 engine.
 struct Activation {
     DeviceBuffer buf;
+    // f16r engine: tensors of the ResNet trunk (block outputs, shortcuts, the pooled stem output) keep an unrounded f32 twin
+    // with the same geometry and the same exponent; residual adds read it and the producing epilogue writes it next to the
+    // f16 copy the next convolution consumes
+    DeviceBuffer buf32;
+    bool want32 = false;
+    bool only32 = false;                            // ... and no f16 copy at all (shortcut tensors: nothing but the residual add reads them)
     int cap = 0, H = 0, W = 0, C = 0;
     int dt = kF16;
     int exp = 0;
@@ -82,13 +90,22 @@ struct Activation {
     Activation* tie = nullptr;                      // same exp as `tie` (pooled copy of a tensor, concat halves)
     void shape(int h, int w, int c, int dt_) { H = h; W = w; C = c; dt = dt_; }
     Status reserve(int cap_);                       // (re)allocate for cap_ images, zero-filled; exp and shape stay
+    // Transactional growth of a whole workspace: every new buffer is allocated before any old one is released, so a failed
+    // hipMalloc leaves the model exactly as it was (capacity, pointers, borders) instead of half-grown with a null tensor.
+    static Status reserve_all(const std::vector<Activation*>& acts, int cap_);
     Status create(int cap_, int h, int w, int c, int dt_) { shape(h, w, c, dt_); return reserve(cap_); }
     TensorRef ref(int n, int coff = 0, int c = -1) const {
         TensorRef t;
-        t.base = buf.ptr; t.N = n; t.H = H; t.W = W; t.Cs = C; t.Coff = coff; t.C = c < 0 ? C - coff : c;
+        t.base = buf.ptr; t.base32 = buf32.ptr; t.N = n; t.H = H; t.W = W; t.Cs = C; t.Coff = coff; t.C = c < 0 ? C - coff : c;
         t.owner = const_cast<Activation*>(this);
-        t.exp = exp_of(coff); t.split = 0; t.exp_delta = 0;
+        t.exp = exp_of(coff); t.split = 0; t.exp_delta = 0; t.f32_only = 0;
         if (split_c && coff < split_c && coff + t.C > split_c) { t.split = split_c - coff; t.exp_delta = exp2 - exp; }
+        return t;
+    }
+    // the f32 twin as a tensor of its own (input / output of layers that run in f32 inside an f16r engine)
+    TensorRef ref32(int n) const {
+        TensorRef t = ref(n);
+        t.base = buf32.ptr; t.base32 = nullptr; t.f32_only = 1;
         return t;
     }
     int exp_of(int coff) const { return split_c && coff >= split_c ? exp2 : exp; }
@@ -142,6 +159,7 @@ struct ConvLayer {
 
 struct ProfileEntry {
     std::string name;
+    std::string kernel;                             // which kernel instantiation ran the launch (conv family: tile / variant tag)
     bool is_conv = false;
     double macs = 0;
     double bytes = 0;                               // algorithmic HBM bytes of the launch (inputs + outputs + weights, once each)
@@ -153,6 +171,7 @@ class Engine {
   public:
     int device = 0;
     int dt = kF16;
+    bool trunk32 = false;         // precision f16r: f16 MFMA convolutions, the ResNet residual trunk carried in f32 (Activation::buf32)
     std::mutex mu;
     int unet_chunk = 64;          // images per pass: every layer still launches >= 256 workgroups of 256x256 / 128x256
     int resnet_chunk = 16384;      // squares per pass
@@ -175,7 +194,7 @@ class Engine {
     // range calibration (see Activation): while set, every producer measures its output tensor after the launch
     bool calibrating = false;
     DeviceBuffer cal_word;
-    Status measure(const TensorRef& t, hipStream_t s);
+    Status measure(const TensorRef& t, hipStream_t s);   // t.f32_only: read as f32
     template <class Fwd> Status calibrate(const std::vector<Activation*>& acts, Fwd&& forward, hipStream_t s, const char* what);
     size_t workspace_bytes() const;
 

@@ -370,13 +370,15 @@ __global__ __launch_bounds__(256) void stem7x7_kernel(const XT* __restrict__ x, 
 // ds_read_b32, no packing.  One 16-lane pixel fragment = one pooled output row; the 9 pool-window positions are
 // computed one after the other (2.25x recompute of the tiny conv instead of staging 32x32x64 outputs in LDS) and
 // max-reduced in registers.  Out-of-range window positions contribute 0, which equals -inf padding after ReLU.
-template <typename T, typename XT>
+// SPLIT = split-f16 ARITHMETIC (hi + lo planes, three products); it is what a split_t tensor implies, and the f16r engine asks
+// for it with T = half_t: its stem computes at f32 grade and leaves the pooled result twice, as the f16 tensor layer1.0.conv1
+// consumes and as the f32 twin (dst.base32) the residual trunk starts from.
+template <typename T, typename XT, bool SPLIT = sizeof(T) == 4>
 __global__ __launch_bounds__(256) void stem_pool_mfma_kernel(const XT* __restrict__ x, int n,
                                                              const half8* __restrict__ wpk,
                                                              const float* __restrict__ scale,
                                                              const float* __restrict__ shift, float in_mul, TensorRef dst,
                                                              unsigned* flag, unsigned layer_id) {
-    constexpr bool SPLIT = sizeof(T) == 4;
     constexpr int LD = 98, ROWS = 72, PAD = 5;              // LD/2 = 49 dwords: odd rows land on the other bank half
     __shared__ __attribute__((aligned(16))) half_t plane[SPLIT ? 2 : 1][ROWS * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -476,6 +478,13 @@ __global__ __launch_bounds__(256) void stem_pool_mfma_kernel(const XT* __restric
                 int par;
                 char* d = grp_ptr<T>(dst, opix, (q * 16 + i) / Grp<T>::N, &par);
                 Grp<T>::store(d, par, best + i, bad);
+            }
+            if constexpr (__is_same(T, half_t) && SPLIT) {
+                if (dst.base32) {
+                    float* d32 = reinterpret_cast<float*>(dst.base32) + opix * dst.Cs + dst.Coff + q * 16;
+#pragma unroll
+                    for (int i = 0; i < 16; i += 4) *reinterpret_cast<f4*>(d32 + i) = f4{best[i], best[i + 1], best[i + 2], best[i + 3]};
+                }
             }
         }
     }
@@ -795,7 +804,10 @@ hipError_t stem_pool_mfma(int dt, const void* x, bool x_is_u8, int n, const void
     const dim3 g((unsigned)(n < 2048 ? n : 2048)), b(256);
     const half8* w = reinterpret_cast<const half8*>(wpk);
     const float im = pow2f(-in_exp);
-    if (dt == kF16) {
+    if (dt == kF16 && dst.base32) {                      // f16r engine: split-f16 arithmetic, f16 tensor + f32 twin out
+        if (x_is_u8) hipLaunchKernelGGL((stem_pool_mfma_kernel<half_t, uint8_t, true>), g, b, 0, s, (const uint8_t*)x, n, w, scale, shift, im, dst, flag, layer_id);
+        else hipLaunchKernelGGL((stem_pool_mfma_kernel<half_t, float, true>), g, b, 0, s, (const float*)x, n, w, scale, shift, im, dst, flag, layer_id);
+    } else if (dt == kF16) {
         if (x_is_u8) hipLaunchKernelGGL((stem_pool_mfma_kernel<half_t, uint8_t>), g, b, 0, s, (const uint8_t*)x, n, w, scale, shift, im, dst, flag, layer_id);
         else hipLaunchKernelGGL((stem_pool_mfma_kernel<half_t, float>), g, b, 0, s, (const float*)x, n, w, scale, shift, im, dst, flag, layer_id);
     } else {

@@ -15,7 +15,7 @@ namespace cv {
 
 Status build_conv_bn_public(Engine& e, ConvLayer& L, const ParamMap& pm, const std::string& conv_key,
                             const std::string& bn_key, int cout, int cin, int k, int stride, int cinPad,
-                            int64_t pixels, int out_hw);
+                            int64_t pixels, int out_hw, int layer_dt = -1);
 Status need_public(const ParamMap& pm, const std::string& key, std::vector<int64_t> shape, const float** out);
 Status bn_fold_public(const ParamMap& pm, const std::string& prefix, int c, std::vector<float>& scale, std::vector<float>& shift);
 Status reject_unknown_keys_public(const ParamMap& pm, const std::vector<std::string>& known, const char* model);
@@ -100,6 +100,7 @@ Status resnet_load(Engine& e, const ParamMap& pm) {
     }
     if (dt == kF32) { R.stem_out.shape(32, 32, 64, dt); R.acts.push_back(&R.stem_out); }   // other engines fuse stem + pool
     R.pool_out.shape(16, 16, 64, dt);
+    R.pool_out.want32 = e.trunk32;
     R.acts.push_back(&R.pool_out);
 
     const int widths[4] = {64, 128, 256, 512};
@@ -120,13 +121,20 @@ Status resnet_load(Engine& e, const ParamMap& pm) {
             B.has_down = (stride != 1 || cin != w);
             if (B.has_down) {
                 known.push_back(p + ".downsample.0.weight"); bn_keys(known, p + ".downsample.1");
-                CV_TRY(build_conv_bn_public(e, B.down, pm, p + ".downsample.0", p + ".downsample.1", w, cin, 1, stride, cin, px, res[l]));
+                // f16r: the shortcut convolution IS the trunk at the stage boundaries -- f16 products there put their rounding
+                // straight onto the skip path (CPU emulation of the arithmetic, 4096 squares: worst soft-max error 9.7e-4 with f16
+                // shortcuts, 6.5e-4 with exact ones).  It holds 1.1 % of the network's MACs: run it on the f32 MFMA, f32 twin in,
+                // f32 twin out; no f16 copy of the shortcut tensor exists.
+                CV_TRY(build_conv_bn_public(e, B.down, pm, p + ".downsample.0", p + ".downsample.1", w, cin, 1, stride, cin, px, res[l],
+                                            e.trunk32 ? (int)kF32 : -1));
                 B.sc.shape(res[l], res[l], w, dt);
+                B.sc.want32 = B.sc.only32 = e.trunk32;
                 R.acts.push_back(&B.sc);
                 macs += (int64_t)cin * w * res[l] * res[l];
             }
             B.mid.shape(res[l], res[l], w, dt);
             B.out.shape(res[l], res[l], w, dt);
+            B.out.want32 = e.trunk32;                        // f16r: the residual trunk never rounds to f16 (Activation::buf32)
             R.acts.push_back(&B.mid); R.acts.push_back(&B.out);
             macs += ((int64_t)cin * 9 * w + (int64_t)w * 9 * w) * res[l] * res[l];
             cin = w;
@@ -191,7 +199,7 @@ static Status resnet_reserve(Engine& e, int n) {
     const int want = std::min(R.max_cap, std::max(n, 1));
     if (want <= R.cap) return Status();
     CV_HIP(hipDeviceSynchronize());
-    for (Activation* a : R.acts) CV_TRY(a->reserve(want));
+    CV_TRY(Activation::reserve_all(R.acts, want));
     R.cap = want;
     const int S = want;
     R.taps.clear();
@@ -203,7 +211,7 @@ static Status resnet_reserve(Engine& e, int n) {
             const std::string p = "layer" + std::to_string(l + 1) + "." + std::to_string(bi);
             R.taps[p + ".act1"] = B.mid.ref(S);
             R.taps[p] = B.out.ref(S);
-            if (B.has_down) R.taps[p + ".downsample"] = B.sc.ref(S);
+            if (B.has_down) R.taps[p + ".downsample"] = B.sc.only32 ? B.sc.ref32(S) : B.sc.ref(S);
         }
         R.taps["layer" + std::to_string(l + 1)] = R.blocks[l * 2 + 1].out.ref(S);
     }
@@ -241,7 +249,7 @@ static Status resnet_chunk(Engine& e, const void* x, bool x_u8, int n, float* ou
         CV_TRY(end("maxpool3x3s2", maxpool3x3s2(dt, R.stem_out.ref(n), R.pool_out.ref(n), s)));
     } else {
         CV_TRY(stem_set_exp(R, dt, R.pool_out.exp, s));
-        begin("stem7x7+maxpool (mfma)", 49.0 * 64 * 1024 * n, (double)n * (4096 * in_b + 256 * 64 * esz));
+        begin("stem7x7+maxpool (mfma)", 49.0 * 64 * 1024 * n, (double)n * (4096 * in_b + 256 * 64 * (esz + (R.pool_out.want32 ? 4.0 : 0.0))));
         CV_TRY(end("stem_pool_mfma", stem_pool_mfma(dt, x, x_u8, n, R.stem_wpk.ptr, (const float*)R.stem_scale.ptr,
                                                      (const float*)R.stem_shift.ptr, kInputExp, R.pool_out.ref(n),
                                                      e.guard_ptr(), R.stem_id, s)));
@@ -252,15 +260,23 @@ static Status resnet_chunk(Engine& e, const void* x, bool x_u8, int n, float* ou
         Engine::ResNet::Block& B = R.blocks[i];
         TensorRef shortcut = cur;
         if (B.has_down) {
-            CV_TRY(e.run_conv(B.down, cur, B.sc.ref(n), nullptr, false, s));
+            if (B.sc.only32) {                                 // f16r: f32 convolution from the trunk's twin to the shortcut's
+                TensorRef in32 = cur;
+                in32.base = cur.base32; in32.base32 = nullptr; in32.f32_only = 1;
+                CV_TRY(e.run_conv(B.down, in32, B.sc.ref32(n), nullptr, false, s));
+            } else {
+                CV_TRY(e.run_conv(B.down, cur, B.sc.ref(n), nullptr, false, s));
+            }
             shortcut = B.sc.ref(n);
         }
         CV_TRY(e.run_conv(B.conv1, cur, B.mid.ref(n), nullptr, true, s));
         CV_TRY(e.run_conv(B.conv2, B.mid.ref(n), B.out.ref(n), &shortcut, true, s));
         cur = B.out.ref(n);
     }
-    begin("head_avgpool_fc", 13.0 * 512 * n, (double)n * (cur.H * cur.W * 512 * esz + 13 * 4));
-    CV_TRY(end("head_avgpool_fc", head_avgpool_fc(dt, cur, (const float*)R.fc_w.ptr, (const float*)R.fc_b.ptr, out,
+    int head_dt = dt;
+    if (cur.base32) { cur.base = cur.base32; head_dt = kF32; }   // f16r: pool the trunk's f32 twin
+    begin("head_avgpool_fc", 13.0 * 512 * n, (double)n * (cur.H * cur.W * 512 * dtype_size(head_dt) + 13 * 4));
+    CV_TRY(end("head_avgpool_fc", head_avgpool_fc(head_dt, cur, (const float*)R.fc_w.ptr, (const float*)R.fc_b.ptr, out,
                                                    softmax ? 1 : 0, e.guard_ptr(), R.head_id, s)));
     return Status();
 }

@@ -55,19 +55,19 @@ Status bn_fold_public(const ParamMap& pm, const std::string& prefix, int c, std:
 
 static Status build_conv_bn(Engine& e, ConvLayer& L, const ParamMap& pm, const std::string& conv_key,
                             const std::string& bn_key, int cout, int cin, int k, int stride, int cinPad,
-                            int64_t pixels, int out_hw = 0) {
+                            int64_t pixels, int out_hw = 0, int layer_dt = -1) {
     const float* w;
     CV_TRY(need(pm, conv_key + ".weight", {cout, cin, k, k}, &w));
     std::vector<float> sc, sh;
     CV_TRY(bn_fold(pm, bn_key, cout, sc, sh));
-    CV_TRY(L.build_conv(conv_key, e.dt, w, cout, cin, k, stride, sc.data(), sh.data(), cinPad, pixels, out_hw));
+    CV_TRY(L.build_conv(conv_key, layer_dt < 0 ? e.dt : layer_dt, w, cout, cin, k, stride, sc.data(), sh.data(), cinPad, pixels, out_hw));
     L.layer_id = e.register_layer(conv_key);
     return Status();
 }
 Status build_conv_bn_public(Engine& e, ConvLayer& L, const ParamMap& pm, const std::string& conv_key,
                             const std::string& bn_key, int cout, int cin, int k, int stride, int cinPad,
-                            int64_t pixels, int out_hw) {
-    return build_conv_bn(e, L, pm, conv_key, bn_key, cout, cin, k, stride, cinPad, pixels, out_hw);
+                            int64_t pixels, int out_hw, int layer_dt) {
+    return build_conv_bn(e, L, pm, conv_key, bn_key, cout, cin, k, stride, cinPad, pixels, out_hw, layer_dt);
 }
 
 // every key the architecture defines, so that a checkpoint of a DIFFERENT architecture (extra / renamed keys: the
@@ -316,7 +316,7 @@ static Status unet_reserve(Engine& e, int n) {
     const int want = std::min(U.max_cap, std::max(n, 1));
     if (want <= U.cap) return Status();
     CV_HIP(hipDeviceSynchronize());                  // nothing may still read the buffers about to be replaced
-    for (Activation* a : U.acts) CV_TRY(a->reserve(want));
+    CV_TRY(Activation::reserve_all(U.acts, want));
     U.cap = want;
     const int S = want;
     const int enc_c[5] = {64, 128, 256, 512, U.c5};

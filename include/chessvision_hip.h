@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define CV_ABI_VERSION 1
+#define CV_ABI_VERSION 2      /* 2: CV_PREC_F16R, CV_ERR_NUMERIC + cv_engine_numeric_status, cv_engine_set_chunk before cv_load_* only */
 
 enum cv_status {
     CV_OK = 0,
@@ -54,16 +54,24 @@ enum cv_status {
 enum cv_precision {
     CV_PREC_F32 = 0,      /* f32 activations/weights, f32-input MFMA (exact f32 products, f32 accumulate) */
     CV_PREC_F16 = 1,      /* f16 activations/weights, f16 MFMA with f32 accumulate, f32 BN/bias epilogue  */
-    CV_PREC_F16X3 = 2     /* split-f16: every activation/weight carried as hi + lo f16 (>= 22 significant bits),
+    CV_PREC_F16X3 = 2,    /* split-f16: every activation/weight carried as hi + lo f16 (>= 22 significant bits),
                              products formed as hi*hi + hi*lo + lo*hi on the f16 MFMA with f32 accumulate:
                              f32-grade results at up to 1/3 of the f16 MFMA rate (5.3x the f32 MFMA rate) */
+    CV_PREC_F16R = 3      /* f16 with an f32 residual trunk (the classifier's fp16 mode, BASELINE configs[2]): f16
+                             activations/weights and ONE f16 MFMA product per MAC, f32 accumulate, as CV_PREC_F16 -- but
+                             the ResNet-18 stem is computed at f32 grade and every tensor of the residual trunk (pooled stem
+                             output, block outputs, down-sampled shortcuts) keeps an unrounded f32 twin that the residual
+                             adds read and the block epilogues write, so f16 rounding never accumulates along the
+                             skip path; soft-max probabilities within 1e-3 of the fp32 reference.  The UNet (no
+                             residuals) runs exactly as under CV_PREC_F16. */
 };
 
 typedef struct cv_engine cv_engine_t;     /* opaque */
 
 /* One entry of a PyTorch state dict: name = state-dict key (reference key names, e.g.
  * "inc.double_conv.0.weight", "layer2.0.downsample.1.running_var", "fc.bias"); data = HOST pointer to
- * contiguous row-major float32.  Non-float entries (num_batches_tracked) may be omitted. */
+ * contiguous row-major float32.  BatchNorm "*.num_batches_tracked" entries may be omitted or passed (any shape):
+ * they are ignored. */
 typedef struct cv_param {
     const char*  name;
     const float* data;
@@ -154,6 +162,11 @@ int cv_profile_entry(cv_engine_t* eng, int index, char* name, int name_cap, floa
 
 /* Algorithmic HBM bytes (inputs + outputs + weights, once each, at the engine's storage width) of record `index`. */
 int cv_profile_entry_bytes(cv_engine_t* eng, int index, double* bytes);
+
+/* Which kernel instantiation ran record `index` (conv family: "conv3x3_halo_kernel<split_t,64,16x16>", ...; empty for the
+ * other kernels, whose record name already is the kernel).  Lets a caller rebuild the per-kernel roofline that
+ * rocprofv3 --kernel-trace reports by template name. */
+int cv_profile_entry_kernel(cv_engine_t* eng, int index, char* kernel, int kernel_cap);
 
 /* Stand-alone single-layer entry points used by the parity tests (float32 NCHW device tensors in,
  * float32 NCHW out; packing to the internal layout happens inside, on `stream`).

@@ -79,3 +79,85 @@ def test_single_process_paths_are_identity():
     assert torch.equal(cvd.all_gather_rows(x), x)
     assert list(cvd.shard_indices(7, 2, 4)) == [2, 6]
     assert cvd.count_ranks(torch.device("cpu")) == 1
+
+
+class _FakeVision:
+    """Stands in for ChessVision on a CPU-only box: 'classifies' a photo from the board index painted into its first pixel."""
+
+    def process_images(self, images, threshold=0.5, flip=False, fallback_quad=False, timings=None, **kw):
+        from chessvision.cv_types import BoardExtractionResult, ChessVisionResult, PositionResult
+
+        out = []
+        for im in images:
+            idx = int(im[0, 0, 0])
+            mask = np.full((256, 256), idx, np.uint8)
+            if idx == 3:                                   # a photo without a board
+                out.append(ChessVisionResult(BoardExtractionResult(np.zeros((256, 256), np.float32), mask, None, None), None, 0.0))
+                continue
+            probs = np.full((64, 13), 0.01, np.float32)
+            probs[np.arange(64), (np.arange(64) + idx) % 13] = 0.88
+            quad = np.arange(8, dtype=np.float32).reshape(4, 1, 2) + idx
+            pos = PositionResult(fen=f"local-{idx}", original_fen=f"local-{idx}", model_probabilities=probs, squares=None,
+                                 square_names=[], validation_fixes=[])
+            out.append(ChessVisionResult(BoardExtractionResult(np.zeros((256, 256), np.float32), mask, quad,
+                                                               np.zeros((512, 512), np.uint8)), pos, 0.0))
+        return out
+
+
+def _sharded_worker(rank: int, world: int, port: int, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    try:
+        cvd.init_process_group(backend="gloo")
+        n = 7                                              # odd: the last shard is padded for the collectives
+        photos = [np.full((4, 4, 3), i, np.uint8) for i in range(n)]
+        tm = {}
+        res = cvd.process_images_sharded(_FakeVision(), photos, timings=tm)
+        summary = []
+        for i, r in enumerate(res):
+            be, pos = r.board_extraction, r.position
+            summary.append((int(be.binary_mask[0, 0]), None if be.quadrangle is None else float(be.quadrangle[0, 0, 0]),
+                            None if pos is None else (int(pos.model_probabilities[0].argmax()), pos.fen.startswith("local"))))
+        local_only = cvd.process_images_sharded(_FakeVision(), photos, gather=False)
+        q.put((rank, summary, [r is not None for r in local_only], tm["shard_boards"], cvd.host_threads(), len(os.sched_getaffinity(0))))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_world2_process_images_sharded_returns_the_global_batch_in_order():
+    """BASELINE configs[4] plumbing: rank r processes photos r::2, probabilities / quadrangles / masks are gathered rank-major
+    and re-interleaved, remote FENs are re-derived by the native decoder -- every rank ends with all 7 results in order."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    cpus_before = len(os.sched_getaffinity(0))
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, summary, local_mask, shard_boards, threads, cpus in got:
+        assert [s[0] for s in summary] == list(range(7))                      # masks in board order
+        assert [s[1] for s in summary] == [0.0, 1.0, 2.0, None, 4.0, 5.0, 6.0]  # quadrangles; board 3 has none
+        for i, s in enumerate(summary):
+            if i == 3:
+                assert s[2] is None
+            else:
+                assert s[2][0] == i % 13                                      # probabilities of board i
+                assert s[2][1] == (i % 2 == rank)                             # own boards keep the local object, others are rebuilt
+        assert local_mask == [i % 2 == rank for i in range(7)]
+        assert shard_boards == (4 if rank == 0 else 3)
+        if cpus_before >= 2:                                                  # every rank was pinned to its half of the CPUs
+            assert cpus == cpus_before // 2 and threads == min(32, cpus)
+
+
+def test_host_threads_divide_the_cpus_among_local_ranks(monkeypatch):
+    cpus = len(os.sched_getaffinity(0))
+    monkeypatch.delenv("CV_RANK_CPUS_PINNED", raising=False)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    assert cvd.host_threads() == max(1, min(32, cpus // 8))
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "1")
+    assert cvd.host_threads(cap=4) == min(4, cpus)

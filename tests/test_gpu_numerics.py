@@ -274,3 +274,23 @@ def test_loader_accepts_exactly_the_reference_key_set(model):
     with pytest.raises(HipBackendError, match="shape"):
         load(wrong)
     eng.close()
+
+
+def test_c_abi_ignores_num_batches_tracked_entries():
+    """A C / cgo caller that marshals the FULL torch state dict passes the BatchNorm counters too: the header says they may be
+    omitted or passed; cv_load_* must ignore them instead of rejecting the dict as a foreign architecture."""
+    import ctypes
+
+    from chessvision import hip_backend, synthetic
+
+    eng = hip_backend.HipEngine(precision="f16")
+    good = synthetic.resnet18_state_dict(2)
+    table, n, keep = hip_backend._as_param_table(good)
+    counter = np.array([1234.0], np.float32)
+    extra = hip_backend._Param(b"layer1.0.bn1.num_batches_tracked", counter.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), 0,
+                               (ctypes.c_int64 * 4)(0, 0, 0, 0))
+    full = (hip_backend._Param * (n + 1))(*list(table), extra)
+    hip_backend._check(eng._lib.cv_load_resnet18(eng._h, full, n + 1))
+    out = eng.resnet18_forward(synth.squares_input(seed=3, n=8))
+    assert torch.isfinite(out).all()
+    eng.close()

@@ -18,13 +18,13 @@ with tempfile.TemporaryDirectory() as d:
     pe, pc = synthetic.save_checkpoints(d, segmenting=True)
     cv = ChessVision(board_extractor_weights=str(pe), classifier_weights=str(pc))
     images = [synthetic.board_photo(s) for s in range(n)]
-    cv.process_images(images[:96], fallback_quad=True)
+    cv.process_images(images[:96], fallback_quad=True, return_crops=False)
     for first, chunk in ((16, 64), (32, 64), (0, 64), (0, 32), (16, 128), (0, 128)):
         best = None
         for _ in range(4):
             tm = {}
             t0 = time.perf_counter()
-            cv.process_images(images, fallback_quad=True, timings=tm, first_job=first, pipeline_chunk=chunk)
+            cv.process_images(images, fallback_quad=True, timings=tm, first_job=first, pipeline_chunk=chunk, return_crops=False)
             dt = time.perf_counter() - t0
             if best is None or dt < best[0]:
                 best = (dt, tm)
