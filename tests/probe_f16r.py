@@ -1,8 +1,8 @@
-"""Developer probe for the classifier's fp16 mode (precision "f16r"): parity against the CPU oracle at BASELINE configs[2]'s
+"""(test infrastructure, not collected by pytest) Developer probe for the classifier's fp16 mode (precision "f16r"): parity against the CPU oracle at BASELINE configs[2]'s
 batch (4096 squares), on the He-normal and on the stressed weights, per-layer error growth, and the forward time at the bench's
 chunk (16384 squares) next to the f16 and f16x3 engines.  Writes JSON lines to stdout.
 
-usage: python tools/f16r_probe.py [--squares 4096] [--time-squares 16384]
+usage: python tests/probe_f16r.py [--squares 4096] [--time-squares 16384]
 """
 from __future__ import annotations
 
