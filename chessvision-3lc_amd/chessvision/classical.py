@@ -267,9 +267,13 @@ def warp_perspective(image: NDArray[np.uint8], m: NDArray[np.float64], size: tup
 
 
 def bgr_to_gray(image: NDArray[np.uint8]) -> NDArray[np.uint8]:
-    """cv2.cvtColor(BGR2GRAY) for 8-bit: (1868 B + 9617 G + 4899 R + 2^13) >> 14."""
+    """cv2.cvtColor(BGR2GRAY) for 8-bit images as OpenCV 4.x computes it (the reference pins opencv-python 4.11.0.86,
+    ``uv.lock:2663``): 15 fractional bits, ``(3735 B + 19235 G + 9798 R + 2^14) >> 15`` (``color_rgb.simd.hpp``: ``BY15``,
+    ``GY15``, ``RY15``, ``gray_shift = 15``).  OpenCV 3.x used 14 bits (1868 / 9617 / 4899, ``>> 14``), which is what rounds
+    1-2 of this package did; the two agree except for one grey level on about one pixel in twenty.  OpenCV is not installed
+    here, so the constants are restated from its source as published, not measured."""
     b, g, r = (image[..., i].astype(np.int32) for i in range(3))
-    return ((b * 1868 + g * 9617 + r * 4899 + (1 << 13)) >> 14).astype(np.uint8)
+    return ((b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15).astype(np.uint8)
 
 
 def flip_horizontal(image: NDArray[np.uint8]) -> NDArray[np.uint8]:

@@ -106,7 +106,8 @@ __global__ void extract_squares_u8_kernel(const uint8_t* __restrict__ images, in
         v = rint(v);
         bgr[c] = (int)(v < 0.0 ? 0.0 : v > 255.0 ? 255.0 : v);
     }
-    const uint8_t gray = (uint8_t)((bgr[0] * 1868 + bgr[1] * 9617 + bgr[2] * 4899 + (1 << 13)) >> 14);
+    // OpenCV 4.x 8-bit BGR2GRAY: 15 fractional bits (BY15 / GY15 / RY15, gray_shift = 15); 3.x used 1868 / 9617 / 4899 >> 14
+    const uint8_t gray = (uint8_t)((bgr[0] * 3735 + bgr[1] * 19235 + bgr[2] * 9798 + (1 << 14)) >> 15);
     if (boards) boards[idx] = gray;
     const int sq = (by >> 6) * 8 + (bx >> 6);            // a8..h8, a7.. order (reference core.py:436-439)
     squares[((size_t)img * 64 + sq) * 4096 + (size_t)(by & 63) * 64 + (bx & 63)] = gray;

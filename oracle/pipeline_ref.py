@@ -3,52 +3,70 @@
 TEST INFRASTRUCTURE (see ``oracle/__init__.py``).  The reference pipeline (``chessvision/core.py:152-195``) is
     resize INTER_AREA -> /255, HWC->CHW -> board_extractor(batch)[0] -> sigmoid > threshold -> contours -> quadrangle
     -> perspective warp -> gray -> flip -> 64 squares -> /255 -> classifier(batch) -> softmax -> argmax -> FEN + pawn rule
-and keeps the two models behind opaque callables (``core.py:53-54``).  Here those callables are ``oracle.unet_ref.UNet``
-and ``oracle.resnet_ref.ResNet18`` on torch CPU fp32, and every classical stage is the host-side numpy restatement that
-the per-image API of the package runs (``chessvision/classical.py``; OpenCV is not installed here).  The batched GPU
-path under test (``ChessVision.process_images``: device resize, fused u8 UNet entry, C++ contours, fused device warp,
-u8 classifier entry, C++ FEN) shares none of that code except the model-independent static helpers.
+and keeps the two models behind opaque callables (``core.py:53-54``).  Here it is written out stage by stage:
+
+* the two CNNs are ``oracle.unet_ref.UNet`` / ``oracle.resnet_ref.ResNet18`` on torch CPU fp32;
+* resize (integer factors), sigmoid / threshold, gray, flip, the 64-way split, soft-max, arg-max, FEN and the pawn rule are
+  the INDEPENDENT restatements of ``oracle/classical_ref.py`` -- they share no code with the product's host path
+  (``chessvision/classical.py``, ``fen.py``, ``ChessVision`` statics) nor with its device / C++ path;
+* two stages are NOT independent and are taken from the product's numpy host path: the mask -> quadrangle chain
+  (``ChessVision._find_quadrangle`` = Suzuki border following, area / box filter, Douglas-Peucker; pinned on the reference's
+  own 631 label masks against ``coordinates.json``, tests/test_contour_cpp.py) and the perspective warp
+  (``utils.extract_perspective``).  For those two the end-to-end test compares two implementations (device / C++ versus
+  numpy) of ONE reading of OpenCV; a shared misreading there is caught only by the 631-mask fixture, not here.  Non-integer
+  resize factors also fall back to the product's coverage-weighted form.
 
 ``fallback_quad`` mirrors the option of ``process_images``: boards whose mask yields no quadrangle are classified through
 the whole-image quadrangle (TR, TL, BL, BR of the 256x256 mask) so that random-init weights still exercise the classifier.
 """
 from __future__ import annotations
 
+import time
+
 import numpy as np
 import torch
 
-
-def make_oracle_chessvision(unet: torch.nn.Module, resnet: torch.nn.Module):
-    """A ``ChessVision`` whose two model objects are the oracle's torch modules, pinned to the CPU."""
-    from chessvision import ChessVision
-
-    cv = ChessVision()
-    cv.device = torch.device("cpu")
-    cv._board_extractor = unet.eval()
-    cv._classifier = resnet.eval()
-    return cv
+from . import classical_ref as cref
 
 
-def process_image(cv, image: np.ndarray, threshold: float = 0.5, flip: bool = False, fallback_quad: bool = False):
-    """``cv.process_image`` (reference order of operations); with ``fallback_quad`` a missing quadrangle is replaced by the
-    whole-image one before the warp, exactly as ``process_images`` does on the device path."""
-    from chessvision import classical, constants, utils
-    from chessvision.cv_types import BoardExtractionResult, ChessVisionResult
+def process_image(unet, resnet, image: np.ndarray, threshold: float = 0.5, flip: bool = False, fallback_quad: bool = False):
+    from chessvision import ChessVision, classical, utils                      # the two shared stages + result records only
+    from chessvision.cv_types import BoardExtractionResult, ChessVisionResult, PositionResult, ValidationFix
 
-    result = cv.process_image(image, threshold, flip)
-    if result.position is not None or not fallback_quad:
-        return result
-    ext = result.board_extraction
-    quad = np.array([[[255, 0]], [[0, 0]], [[0, 255]], [[255, 255]]], dtype=np.int32)
-    scaled = cv._scale_quadrangle(quad, (image.shape[0], image.shape[1]))
-    board = utils.extract_perspective(image, scaled, constants.BOARD_SIZE)
-    board = classical.flip_horizontal(classical.bgr_to_gray(board))
-    ext = BoardExtractionResult(board_image=board, binary_mask=ext.binary_mask, quadrangle=scaled, probabilities=ext.probabilities)
-    return ChessVisionResult(board_extraction=ext, position=cv.classify_position(board, flip),
-                             processing_time=result.processing_time)
+    t0 = time.time()
+    h, w = image.shape[:2]
+    if h % 256 == 0 and w % 256 == 0:
+        small = cref.resize_area_int(image, (256, 256))
+    else:
+        small = classical.resize_area(image, (256, 256))
+    x = torch.from_numpy(small.astype(np.float32) / np.float32(255.0)).permute(2, 0, 1)[None]   # core.py:215-216
+    logits = unet(x)[0, 0].numpy().astype(np.float32)
+    mask = cref.binary_mask(logits, threshold)
+    quad = ChessVision._find_quadrangle(mask)                                  # shared (see the module docstring)
+    if quad is None and fallback_quad:
+        quad = np.array([[[255, 0]], [[0, 0]], [[0, 255]], [[255, 255]]], dtype=np.int32)
+    if quad is None:
+        ext = BoardExtractionResult(board_image=None, binary_mask=mask, quadrangle=None, probabilities=logits)
+        return ChessVisionResult(board_extraction=ext, position=None, processing_time=time.time() - t0)
+    scaled = np.array(quad * (h / 256.0), dtype=np.float32)                     # height only, core.py:416
+    board = utils.extract_perspective(image, scaled, (512, 512))                # shared (see the module docstring)
+    board = cref.flip_lr(cref.bgr_to_gray(board))
+    squares = cref.split_squares(board)
+    batch = torch.from_numpy(squares.astype(np.float32)).permute(0, 3, 1, 2) / 255.0            # core.py:236-237
+    probs = torch.softmax(resnet(batch), dim=1).numpy()
+    names = cref.square_names(flip)
+    labels = [cref.LABELS[int(i)] for i in np.argmax(probs, axis=1)]
+    original = cref.placement(labels, names)
+    fixed, fixes = cref.pawn_rule(labels, probs, names)
+    position = PositionResult(fen=cref.placement(fixed, names), original_fen=original, model_probabilities=probs, squares=squares,
+                              square_names=names,
+                              validation_fixes=[ValidationFix(square_name=s, original_piece=o, corrected_piece=n, rule_name="no_pawns_on_ends")
+                                                for s, o, n in fixes])
+    ext = BoardExtractionResult(board_image=board, binary_mask=mask, quadrangle=scaled, probabilities=logits)
+    return ChessVisionResult(board_extraction=ext, position=position, processing_time=time.time() - t0)
 
 
 def process_images(unet, resnet, images, threshold: float = 0.5, flip: bool = False, fallback_quad: bool = False):
-    cv = make_oracle_chessvision(unet, resnet)
+    unet, resnet = unet.eval(), resnet.eval()
     with torch.no_grad():
-        return [process_image(cv, im, threshold, flip, fallback_quad) for im in images]
+        return [process_image(unet, resnet, im, threshold, flip, fallback_quad) for im in images]

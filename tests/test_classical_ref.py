@@ -1,0 +1,81 @@
+"""CPU: the product's host-side classical stages against the oracle's INDEPENDENT restatements (oracle/classical_ref.py).
+
+The end-to-end oracle (oracle/pipeline_ref.py) runs resize, sigmoid/threshold, gray, flip, the 64-way split, FEN and the pawn
+rule through oracle/classical_ref.py, which shares no code with chessvision/classical.py, chessvision/fen.py, the ChessVision
+statics, csrc/pipeline.hip or csrc/position.cpp.  Here the two host-side readings are compared directly on random data and on
+the reference's own known-answer cases, so a disagreement is found without a GPU."""
+from __future__ import annotations
+
+import numpy as np
+
+from chessvision import ChessVision, classical, constants, utils
+from chessvision.fen import board_fen
+from oracle import classical_ref as cref
+
+
+def test_label_and_square_tables_match_the_reference_constants():
+    assert cref.LABELS == constants.LABEL_NAMES                                   # reference constants.py:23
+    assert cref.square_names(False) == constants.SQUARE_NAMES_NORMAL              # constants.py:109-118
+    assert cref.square_names(True) == constants.SQUARE_NAMES_FLIPPED              # constants.py:120-129
+    assert {n for n in cref.square_names(False) if n[1] in "18"} == set(constants.INVALID_PAWN_SQUARES)
+
+
+def test_gray_flip_split_resize_agree():
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, (512, 512, 3), dtype=np.uint8)
+    assert np.array_equal(classical.bgr_to_gray(img), cref.bgr_to_gray(img))
+    every = np.stack(np.meshgrid(np.arange(0, 256, 5), np.arange(0, 256, 5), np.arange(0, 256, 5), indexing="ij"), -1).reshape(1, -1, 3).astype(np.uint8)
+    assert np.array_equal(classical.bgr_to_gray(every), cref.bgr_to_gray(every))  # a lattice over the colour cube
+    assert np.array_equal(classical.resize_area(img, (256, 256)), cref.resize_area_int(img, (256, 256)))
+    assert np.array_equal(classical.resize_area(img[:, :256], (64, 128)), cref.resize_area_int(img[:, :256], (128, 64)))
+    gray = cref.bgr_to_gray(img)
+    assert np.array_equal(classical.flip_horizontal(gray), cref.flip_lr(gray))
+    assert np.array_equal(ChessVision.extract_squares(gray), cref.split_squares(gray))
+
+
+def test_extract_squares_known_answer_of_the_reference():
+    """tests/test_chessvision.py:119-146 of the reference: square (r, c) of a board filled with r * 8 + c is constant."""
+    board = np.zeros((512, 512), np.uint8)
+    for r in range(8):
+        for c in range(8):
+            board[r * 64:(r + 1) * 64, c * 64:(c + 1) * 64] = r * 8 + c
+    sq = cref.split_squares(board)
+    assert sq.shape == (64, 64, 64, 1)
+    assert all(np.all(sq[i] == i) for i in range(64))
+
+
+def test_threshold_semantics_at_the_edge():
+    logits = np.array([[0.0, 1e-7, -1e-7, 20.0, -20.0, np.log(3.0)]], np.float32)   # sigmoid = .5, >.5, <.5, 1, 0, .75
+    for thr in (0.5, 0.75, 0.25):
+        prob = 1.0 / (1.0 + np.exp(-logits.astype(np.float32)))
+        want = utils.create_binary_mask(prob.astype(np.float32), thr)
+        assert np.array_equal(cref.binary_mask(logits, thr), want)
+
+
+def test_fen_and_pawn_rule_agree_on_random_probabilities():
+    rng = np.random.default_rng(5)
+    for trial in range(200):
+        flip = bool(trial & 1)
+        names = cref.square_names(flip)
+        probs = rng.dirichlet(np.full(13, 0.3), size=64).astype(np.float32)
+        if trial % 3 == 0:                                                        # force pawns onto the back ranks, with ties
+            for i in rng.choice(64, 6, replace=False):
+                probs[i] = 0.0
+                probs[i, 3 if trial % 2 else 9] = 0.5
+                probs[i, rng.integers(0, 13)] += 0.25
+                probs[i, rng.integers(0, 13)] += 0.25
+        labels = [cref.LABELS[int(i)] for i in probs.argmax(1)]
+        assert cref.placement(labels, names) == board_fen(labels, names)
+        mine, my_fixes = cref.pawn_rule(labels, probs, names)
+        theirs, their_fixes = ChessVision.validate_position(list(labels), probs, names)
+        assert mine == theirs
+        assert my_fixes == [(f.square_name, f.original_piece, f.corrected_piece) for f in their_fixes]
+        got = ChessVision.process_position_probabilities(probs, names, np.zeros((64, 64, 64, 1), np.uint8))
+        assert got.fen == cref.placement(mine, names) and got.original_fen == cref.placement(labels, names)
+
+
+def test_start_position_reads_as_the_standard_fen():
+    back = "rnbqkbnr"
+    labels = list(back) + ["p"] * 8 + ["f"] * 32 + ["P"] * 8 + list(back.upper())
+    assert cref.placement(labels, cref.square_names(False)) == "rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR"
+    assert cref.placement(labels[::-1], cref.square_names(True)) == "rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR"
