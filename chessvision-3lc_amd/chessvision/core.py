@@ -12,8 +12,9 @@ Deliberate deviations, all on the permissive side:
   * model ids ``""`` / ``"unet"`` / ``"hip"`` select the UNet, ``""`` / ``"resnet18"`` the ResNet-18
     (``evaluate.py:212,214`` passes ``""``); ``"yolo"`` raises ImportError -- that model family is out of scope.
   * lazy initialisation is guarded by a lock (Flask request threads share one instance, ``cv_endpoint.py:131-133``).
-  * extras: ``precision=`` kwarg (env ``CHESSVISION_HIP_PRECISION``: "f16x3" (default) | "f32" | "f16"), ``process_images`` (batched),
-    ``predict`` alias.
+  * extras: ``precision=`` kwarg (env ``CHESSVISION_HIP_PRECISION``: "f16x3" (default) | "f32" | "f16" | "f16r", or
+    "<extractor>+<classifier>", e.g. "f16x3+f16r" = f32-grade UNet with the classifier in its fp16 mode -- one engine per model),
+    ``process_images`` (batched), ``predict`` alias.
 """
 from __future__ import annotations
 
@@ -59,6 +60,7 @@ class ChessVision:
         self._classifier_model_id = classifier_model_id
         self._precision = precision or os.environ.get("CHESSVISION_HIP_PRECISION", "f16x3")
         self._engine = None
+        self._engines: dict = {}
         self._streams = None
         self._copy_pool = None
         self._init_lock = threading.RLock()
@@ -69,12 +71,19 @@ class ChessVision:
             logger.info("Models loaded successfully")
 
     # ---- model objects ---------------------------------------------------------------------------
-    def _get_engine(self):
-        if self._engine is None:
-            from .hip_backend import HipEngine          # raises when the library or the GPU is missing
+    def _get_engine(self, model: str = "unet"):
+        """The engine that runs ``model`` ("unet" | "resnet18").  One engine serves both models unless the precision names two
+        arithmetic types ("f16x3+f16r": extractor + classifier), in which case each model gets its own."""
+        from .hip_backend import HipEngine              # raises when the library or the GPU is missing
 
-            self._engine = HipEngine(self.device, precision=self._precision)
-        return self._engine
+        parts = self._precision.split("+")
+        prec = parts[0] if model == "unet" or len(parts) == 1 else parts[1]
+        with self._init_lock:
+            if prec not in self._engines:
+                self._engines[prec] = HipEngine(self.device, precision=prec)
+            if self._engine is None:
+                self._engine = self._engines[parts[0]]
+        return self._engines[prec]
 
     @property
     def board_extractor(self):
@@ -121,7 +130,7 @@ class ChessVision:
             logger.info("YOLO not available, falling back to ResNet18")
             self._classifier_model_id = "resnet18"
         weights = self._classifier_weights or constants.BEST_CLASSIFIER_WEIGHTS
-        model = utils.get_classifier_model(self._classifier_model_id or "resnet18", self._get_engine())
+        model = utils.get_classifier_model(self._classifier_model_id or "resnet18", self._get_engine("resnet18"))
         model = utils.load_model_checkpoint(model, weights, self.device)
         self._classifier_weights = weights
         model.eval()
@@ -203,7 +212,7 @@ class ChessVision:
 
         n_host = host_threads()
 
-        eng = self._get_engine()
+        eng, eng_cls = self._get_engine("unet"), self._get_engine("resnet18")
         dev = self.device
         n = len(images)
         names = constants.SQUARE_NAMES_FLIPPED if flip else constants.SQUARE_NAMES_NORMAL
@@ -318,7 +327,7 @@ class ChessVision:
                 with torch.cuda.stream(down):                # the rectified boards travel back while the classifier runs
                     down.wait_event(warped)
                     st["boards"].copy_(boards_dev, non_blocking=True)
-                probs_dev = gpu_timed("resnet_ms", lambda: eng.resnet18_forward_u8(squares_dev))
+                probs_dev = gpu_timed("resnet_ms", lambda: eng_cls.resnet18_forward_u8(squares_dev))
                 done = torch.cuda.Event()
                 done.record()
                 st["probs"] = pinned((len(found) * 64, constants.NUM_CLASSES), torch.float32)
@@ -380,6 +389,8 @@ class ChessVision:
         t_last = time.perf_counter()
         finish(cls)
         eng.check_numerics()                               # one look at the numeric guard for the whole call
+        if eng_cls is not eng:
+            eng_cls.check_numerics()
         tm["drain_s"] = time.perf_counter() - t_last       # last job: wait for its classifier, copies back, decode
 
         t0 = time.perf_counter()

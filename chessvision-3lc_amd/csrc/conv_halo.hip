@@ -170,7 +170,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
     // ---- fused producer (FUSE0) --------------------------------------------------------------------------------------
     constexpr int PW0 = 20;                                        // patch pitch (floats): image rows / cols ty*16-2 .. +17
-    float* const patch0 = reinterpret_cast<float*>(halo + HBYTES);   // [3][20][20] f32 + one zero slot (4864 B)
+    // [3][20][20] image values + one zero slot (4864 B), each ALREADY split: low half = f16(v), high half = f16(v - hi).  The split
+    // is done once per patch element here instead of once per use in the fragment builds (every element is read ~7 times per
+    // channel block): a B fragment is then eight ds_read_b32 and eight v_perm_b32, no conversions.
+    unsigned* const patch0 = reinterpret_cast<unsigned*>(halo + HBYTES);
     half8* const w0lds = reinterpret_cast<half8*>(halo + HBYTES + 4864);      // first-layer fragments of channel block 1 (4 KB)
     float* const sc0lds = reinterpret_cast<float*>(halo + HBYTES + 4864 + 4096);   // scale[64], shift[64]
     auto load_patch0 = [&]() __attribute__((always_inline)) {
@@ -189,7 +192,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 else v = reinterpret_cast<const float*>(p.f0_x)[((size_t)(n * 3 + c) * Hh + gy) * Ww + gx];
             }
             bad0 = __builtin_fmaf(v, 0.f, bad0);
-            patch0[idx] = v * p.f0_in_mul;
+            v *= p.f0_in_mul;
+            const half_t vh = (half_t)v;
+            const half_t vl = (half_t)(v - (float)vh);
+            patch0[idx] = (unsigned)__builtin_bit_cast(unsigned short, vh) | ((unsigned)__builtin_bit_cast(unsigned short, vl) << 16);
         }
         if (bad0 != bad0 && p.flag) atomicMin(p.flag, 0u);         // layer id 0 = the caller's input tensor
     };
@@ -218,18 +224,29 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             const int k = q * 8 + j, tap = k / 3, c = k - tap * 3, ky = tap / 3, kx = tap - ky * 3;
             ko[j] = k < 27 ? (c * 20 + ky) * PW0 + kx : 3 * 20 * PW0;      // relative to the halo pixel's patch origin | the zero slot
         }
-        for (int fr = wave; fr < (HR + 15) / 16; fr += NW) {
-            const int hp = fr * 16 + l15;
-            const int hpc = hp < HR ? hp : HR - 1;
-            const int hy = hpc / 18, hx = hpc - hy * 18;
-            const int pb = hy * PW0 + hx;
-            half8 bh, bl;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float v = patch0[(q * 8 + j < 27 ? pb : 0) + ko[j]];
-                bh[j] = (half_t)v;
-                bl[j] = (half_t)(v - (float)bh[j]);
+        // halo pixel of (fragment fr, lane): hp = 16 fr + l15, walked in steps of NW fragments = 64 pixels = 3 halo lines + 10 --
+        // additions instead of a divide by 18 per fragment
+        int hp = wave * 16 + l15;
+        int hy = hp / 18, hx = hp - hy * 18;
+        for (int fr = wave; fr < (HR + 15) / 16; fr += NW, hp += 16 * NW) {
+            if (fr != wave) {
+                hx += (16 * NW) % 18; hy += (16 * NW) / 18;
+                if (hx >= 18) { hx -= 18; hy += 1; }
             }
+            const int hpc = hp < HR ? hp : HR - 1;
+            if (hp >= HR) { hy = 17; hx = 17; }          // padded tail of the last fragment: recompute the last real pixel, store nothing
+            const int pb = hy * PW0 + hx;
+            unsigned w8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w8[j] = patch0[(q * 8 + j < 27 ? pb : 0) + ko[j]];
+            typedef unsigned u4 __attribute__((ext_vector_type(4)));
+            u4 uh, ul;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                uh[m] = __builtin_amdgcn_perm(w8[2 * m + 1], w8[2 * m], 0x05040100u);     // the two hi halves
+                ul[m] = __builtin_amdgcn_perm(w8[2 * m + 1], w8[2 * m], 0x07060302u);     // the two lo halves
+            }
+            const half8 bh = __builtin_bit_cast(half8, uh), bl = __builtin_bit_cast(half8, ul);
             f4 a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bh, f4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
             f4 a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bh, f4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
             a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, bh, a0, 0, 0, 0);
@@ -352,12 +369,18 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
     Frags F0, F1;
     int s = 0;
-    auto issue_prologue = [&]() __attribute__((always_inline)) {                        // first DMAs of the tile `decode` was last called for
+    auto issue_prologue_halo = [&]() __attribute__((always_inline)) {
         if (is_h && !FUSE0) issue_halo(0, 0, std::integral_constant<int, 0>{}, std::integral_constant<int, H>{});
+    };
+    auto issue_prologue_w = [&]() __attribute__((always_inline)) {
         if (is_w) {
             issue_w(0, 0); issue_w(1, 1); issue_w(2, 2);
             if (NSW == 4) issue_w(3 < nS ? 3 : nS - 1, 3);
         }
+    };
+    auto issue_prologue = [&]() __attribute__((always_inline)) {                        // first DMAs of the tile `decode` was last called for
+        issue_prologue_halo();
+        issue_prologue_w();
     };
     auto stage = [&](Frags& cur, Frags& nxt, auto j_tag, auto hb_tag, int cb) __attribute__((always_inline)) {
         constexpr int J = decltype(j_tag)::value;
@@ -581,15 +604,16 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #endif
     if (more_tiles) {                                    // next tile: halo(0) -> buffer 0, W(0..2) -> ring; lands during this epilogue
         decode(nxt_tile);
-        issue_prologue();
+        if constexpr (DBH) issue_prologue();
+        else issue_prologue_halo();                      // single halo buffer: the ring is this epilogue's staging area, the weights follow it
     }
     // Patch rows are staged RG at a time in wave-private LDS and read back so that consecutive lanes hold consecutive
-    // bytes; output addresses are derived from the pixel index.  A persistent workgroup stages in halo buffer 1, the
-    // only region the next tile's first DMAs do not write, which has room for one row per wave.
+    // bytes; output addresses are derived from the pixel index.  A persistent workgroup stages where the next tile's DMAs in
+    // flight do not write, one row per wave: double-buffered halo -> halo buffer 1 (halo(0) and the first weight stages fly);
+    // single halo buffer -> the weight ring (only the next halo flies; the weight stages are issued behind the staging).
     constexpr int RG = PERSIST ? 1 : 2;
-    static_assert(DBH || !PERSIST, "the persistent epilogue stages in the second halo buffer");
-    static_assert(FP % 2 == 0 && NW * RG * 16 * SROW <= (PERSIST ? HBYTES : NSW * WSTAGE + (DBH ? 2 : 1) * HBYTES), "staging must fit in LDS");
-    char* const stg = (PERSIST ? halo + HBYTES : smem) + wave * (RG * 16 * SROW);
+    static_assert(FP % 2 == 0 && NW * RG * 16 * SROW <= (PERSIST ? (DBH ? HBYTES : NSW * WSTAGE) : NSW * WSTAGE + (DBH ? 2 : 1) * HBYTES), "staging must fit in LDS");
+    char* const stg = (PERSIST && DBH ? halo + HBYTES : smem) + wave * (RG * 16 * SROW);
     const int slab0 = eCt * CT + wci * 64;
     T* const pbase = reinterpret_cast<T*>(p.pool_y);
     const bool relu_early = p.relu && !rbase;
@@ -750,6 +774,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #endif
     report_bad(p, bad);
     if (!more_tiles) break;
+    if constexpr (PERSIST && !DBH) {                     // every wave has read its staged rows back: the ring is free for the next tile
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        issue_prologue_w();
+    }
     tile = nxt_tile;
     }
 }
@@ -795,6 +823,17 @@ static hipError_t launch_halo(const ConvParams& p, int n_images, hipStream_t str
     // for the hidden prologue to matter; long loops lose ~1 % to the single-row staging
     static const int max_k = [] { const char* v = std::getenv("CV_HALO_PERSIST_MAXK"); return v && *v ? std::atoi(v) : 72; }();
     bool launched = false;
+    if constexpr (CT == 64 && NW == 4 && IMG == 0 && !halo_double<CT, TH>()) {
+        // the production tile, persistent (two resident workgroups per CU walk the tiles; the next tile's halo flies during the
+        // epilogue): CV_HALO_PERSIST64=1, launches of short K with many tiles only
+        static const int on64 = [] { const char* v = std::getenv("CV_HALO_PERSIST64"); return v && *v ? std::atoi(v) : 0; }();
+        static const int max_k64 = [] { const char* v = std::getenv("CV_HALO_PERSIST64_MAXK"); return v && *v ? std::atoi(v) : 36; }();
+        if (on64 && !p.head_w && !p.res && tiles >= 8 * g_halo_cus && p.nStages <= max_k64) {
+            auto kern = conv3x3_halo_kernel<T, CT, TH, WGC, NW, TPS, NSW, IMG, true, false>;
+            hipLaunchKernelGGL(kern, dim3((unsigned)(2 * g_halo_cus)), dim3(64 * NW), lds, stream, p);
+            launched = true;
+        }
+    }
     if constexpr (NW == 8) {
         if (halo_persistent<NW>() && tiles >= 4 * g_halo_cus && p.nStages <= max_k) {
             auto kern = conv3x3_halo_kernel<T, CT, TH, WGC, NW, TPS, NSW, IMG, true, true>;
@@ -819,7 +858,12 @@ static hipError_t prepare_halo() {
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<T, CT, TH, WGC, NW, TPS, NSW, IMG, false, false, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
-    if constexpr (NW == 8) {                             // the persistent variant exists for the 8-wave (double-buffered) tiles only
+    if constexpr (CT == 64 && NW == 4 && IMG == 0 && !halo_double<CT, TH>()) {
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<T, CT, TH, WGC, NW, TPS, NSW, IMG, true, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
+    if constexpr (NW == 8) {                             // persistent variants of the 8-wave (double-buffered) tiles
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<T, CT, TH, WGC, NW, TPS, NSW, IMG, true, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

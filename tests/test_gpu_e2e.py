@@ -143,3 +143,23 @@ def test_full_size_job_properties_and_sampled_oracle(cv_model):
     ref = pipeline_ref.process_images(unet, resnet, [images[i] for i in pick], fallback_quad=True)
     for i, r in zip(pick, ref):
         _compare(res[i], r, stats)
+
+
+def test_mixed_precision_pipeline_matches_the_oracle(tmp_path):
+    """precision "f16x3+f16r": f32-grade UNet, classifier in its fp16 mode (one engine per model).  Board extraction is
+    unchanged (same masks, quadrangles, boards); probabilities stay within configs[2]'s 1e-3 of the oracle pipeline and every FEN
+    whose squares are decided beyond that tolerance is identical."""
+    pe, pc = synthetic.save_checkpoints(tmp_path, segmenting=True)
+    cv = ChessVision(board_extractor_weights=str(pe), classifier_weights=str(pc), precision="f16x3+f16r")
+    assert cv._get_engine("unet").precision == "f16x3" and cv._get_engine("resnet18").precision == "f16r"
+    assert cv._get_engine("unet") is not cv._get_engine("resnet18")
+    unet, resnet = _oracle_models()
+    images = _images(16, seed0=300)
+    got = cv.process_images(images, fallback_quad=True)
+    ref = pipeline_ref.process_images(unet, resnet, images, fallback_quad=True)
+    stats = {"mask_flips_inside_tolerance": 0, "max_prob_err": 0.0, "fen_checked": 0}
+    for g, r in zip(got, ref):
+        _compare(g, r, stats)
+    assert stats["fen_checked"] >= 8 and 0 < stats["max_prob_err"] <= 1e-3, stats
+    single = cv.process_image(images[1])                    # the per-image API takes the same two engines
+    assert single.position is not None and np.abs(single.position.model_probabilities - ref[1].position.model_probabilities).max() <= 1e-3
