@@ -390,6 +390,7 @@ def rooflines(eng, x, sq, dtype, B, quiet=False):
             blk["mfma_tflops_algorithmic"] = round(fl / (ms * 1e-3) / 1e12, 1)
             blk["mfma_frac_of_dtype_peak"] = round(fl / (ms * 1e-3) / 1e12 / peak, 4)
         roof_hbm[name] = blk
+    roof["launches_by_model"] = {m: launches[m] for m in ("unet", "resnet18")}
     launches["chunks"] = chunks
     return roof, roof_hbm, launches, conv_ms, conv_n, all_ms
 

@@ -10,6 +10,8 @@
 
 namespace cv {
 
+static int env_int(const char* name, int dflt);       // experiment switches, defined below
+
 // ---- error plumbing: thread-local message, never abort (SURVEY.md section 8b "Errors") -------------
 static thread_local std::string g_err;
 void set_error(const std::string& msg) { g_err = msg; }
@@ -116,7 +118,10 @@ static void pack_rows(int dt, std::vector<char>& out, int CT, int nCt, int nStag
 static Status finish_layer(ConvLayer& L, std::vector<float>& Wk, int K, const std::vector<float>& scale,
                            const std::vector<float>& shift) {
     if (L.keep_host_weights && L.Wk0.empty()) { L.Wk0 = Wk; L.b_scale = scale; L.b_shift = shift; L.Kdim = K; }
-    const int CT = L.ct = choose_ct(L.rows, L.pixels_hint, L.halo_ok, L.halo_img8);
+    // experiment knob: channel tile of the k2 s2 transposed convolutions (64 -> the 80 KB 64x256 tile, two workgroups per CU)
+    static const int convt_ct = env_int("CV_CONVT_CT", 0);
+    const int CT = L.ct = (L.shuffle && (convt_ct == 64 || convt_ct == 128) && L.rows % convt_ct == 0)
+                              ? convt_ct : choose_ct(L.rows, L.pixels_hint, L.halo_ok, L.halo_img8);
     L.nStages = (chunks_for(L.dt, K) + 7) / 8;
     L.nCt = (L.rows + CT - 1) / CT;
     L.rowsPad = L.nCt * CT;

@@ -69,6 +69,11 @@ def test_bench_line_contract_with_rccl_world_of_one():
     roof = line["roofline"]
     assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
     assert roof["launches_per_step"] == 40 and "traffic" in roof and "traffic_source" in roof     # 21 UNet (first two convs fused) + 19 ResNet
+    dom = roof["dominant"]                                  # the instantiation a rocprofv3 kernel trace shows by template name
+    assert dom["kernel"].startswith("conv3x3_halo_kernel<split_t,64,16x16") and dom["launches_per_step"] >= 10
+    assert abs(dom["frac"] - dom["achieved"] / roof["peak"]) < 1e-3 and 0 < dom["share_of_conv_time"] <= 1
+    assert sum(k["launches"] for k in roof["by_kernel"].values()) == roof["launches_per_step"]
+    assert line["sharding"]["gathered_in_order"] is True and line["host_threads_per_rank"] >= 1
     hbm = line["roofline_hbm"]
     assert {"stem7x7+maxpool (mfma)", "head_avgpool_fc"} <= set(hbm)          # (the input packing is fused into the first conv)
     for blk in hbm.values():

@@ -17,9 +17,12 @@ rows = sorted(csv.DictReader(open(trace)), key=lambda r: int(r["Start_Timestamp"
 conv = [r for r in rows if any(t in r["Kernel_Name"] for t in ("conv_igemm_kernel", "conv3x3_halo_kernel", "inc0_mfma_kernel"))]
 line = json.loads([l for l in open(bench_json) if l.startswith("{")][-1])
 per_step = line["roofline"]["launches_per_step"]
-# order of conv launches in the process: calibration ... | warm-up | timed region | the event-timed profiling pass (1 step)
-timed = conv[-(steps + 1) * per_step:-per_step]
-prof = conv[-per_step:]
+# order of conv launches in the process: calibration ... | warm-up | timed region | then, per model (UNet, ResNet-18), one un-timed
+# pass followed by the event-timed profiling pass (bench.py: rooflines())
+timed = conv[-(steps + 2) * per_step:-2 * per_step]
+tail = conv[-2 * per_step:]
+n_unet = line["roofline"]["launches_by_model"]["unet"]
+prof = tail[n_unet:2 * n_unet] + tail[2 * n_unet + (per_step - n_unet):]
 dur = lambda rs: sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rs) / 1e6
 by_kernel = {}
 for r in timed:
