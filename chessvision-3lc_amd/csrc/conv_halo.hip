@@ -225,48 +225,75 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
             ko[j] = k < 27 ? (c * 20 + ky) * PW0 + kx : 3 * 20 * PW0;      // relative to the halo pixel's patch origin | the zero slot
         }
         // halo pixel of (fragment fr, lane): hp = 16 fr + l15, walked in steps of NW fragments = 64 pixels = 3 halo lines + 10 --
-        // additions instead of a divide by 18 per fragment
+        // additions instead of a divide by 18 per fragment.  A wave owns fragments wave, wave + NW, ... (5 or 6 of the 21); they are
+        // produced THREE at a time, phase by phase (addresses | 24 patch reads | 18 MFMAs in six independent chains | BN, ReLU, hi/lo
+        // split | stores): one fragment at a time every phase waited out the latency of the one before it (LDS read -> dependent
+        // MFMAs -> conversions), on an issue port the partner workgroup's MFMA stream already half fills (in-kernel stamps, r03: the
+        // two productions took 38 % of the tile's life).
+        constexpr int NF = (HR + 15) / 16, U = 3;
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
         int hp = wave * 16 + l15;
         int hy = hp / 18, hx = hp - hy * 18;
-        for (int fr = wave; fr < (HR + 15) / 16; fr += NW, hp += 16 * NW) {
-            if (fr != wave) {
+        for (int fr0 = wave; fr0 < NF; fr0 += U * NW) {
+            int hyu[U], hxu[U], hpu[U];
+            unsigned w8[U][8];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                hpu[u] = hp;
+                const bool tail = hp >= HR;              // padded tail of the last fragment / slots past the last fragment: nothing is stored
+                hyu[u] = tail ? 17 : hy; hxu[u] = tail ? 17 : hx;
+                const int pb = hyu[u] * PW0 + hxu[u];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) w8[u][j] = patch0[(q * 8 + j < 27 ? pb : 0) + ko[j]];
+                hp += 16 * NW;
                 hx += (16 * NW) % 18; hy += (16 * NW) / 18;
                 if (hx >= 18) { hx -= 18; hy += 1; }
             }
-            const int hpc = hp < HR ? hp : HR - 1;
-            if (hp >= HR) { hy = 17; hx = 17; }          // padded tail of the last fragment: recompute the last real pixel, store nothing
-            const int pb = hy * PW0 + hx;
-            unsigned w8[8];
+            f4 a0[U], a1[U];
+            half8 bh[U], bl[U];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) w8[j] = patch0[(q * 8 + j < 27 ? pb : 0) + ko[j]];
-            typedef unsigned u4 __attribute__((ext_vector_type(4)));
-            u4 uh, ul;
+            for (int u = 0; u < U; ++u) {
+                u4 uh, ul;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                uh[m] = __builtin_amdgcn_perm(w8[2 * m + 1], w8[2 * m], 0x05040100u);     // the two hi halves
-                ul[m] = __builtin_amdgcn_perm(w8[2 * m + 1], w8[2 * m], 0x07060302u);     // the two lo halves
+                for (int m = 0; m < 4; ++m) {
+                    uh[m] = __builtin_amdgcn_perm(w8[u][2 * m + 1], w8[u][2 * m], 0x05040100u);     // the two hi halves
+                    ul[m] = __builtin_amdgcn_perm(w8[u][2 * m + 1], w8[u][2 * m], 0x07060302u);     // the two lo halves
+                }
+                bh[u] = __builtin_bit_cast(half8, uh); bl[u] = __builtin_bit_cast(half8, ul);
             }
-            const half8 bh = __builtin_bit_cast(half8, uh), bl = __builtin_bit_cast(half8, ul);
-            f4 a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bh, f4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            f4 a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bh, f4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, bh, a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, bh, a1, 0, 0, 0);
-            a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bl, a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bl, a1, 0, 0, 0);
-            const int iy = ty * TH - 1 + hy, ix = tx * 16 - 1 + hx;
-            const bool inside = iy >= 0 && iy < p.xHp - 2 && ix >= 0 && ix < p.xWp - 2;
-            half8 hi8, lo8;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float v = (j < 4 ? a0[j] : a1[j - 4]) * sc0[j] + sh0[j];
-                v = inside ? __builtin_fmaxf(v, 0.f) : 0.f;
-                hi8[j] = (half_t)v;
-                lo8[j] = (half_t)(v - (float)hi8[j]);
+            for (int u = 0; u < U; ++u) {
+                a0[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bh[u], f4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                a1[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bh[u], f4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
             }
-            if (hp < HR) {
-                char* row = halo + hpc * 128;
-                *reinterpret_cast<half8*>(row + (((2 * q + (q & 1)) ^ (hx & 7)) << 4)) = hi8;
-                *reinterpret_cast<half8*>(row + (((2 * q + 1 - (q & 1)) ^ (hx & 7)) << 4)) = lo8;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                a0[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, bh[u], a0[u], 0, 0, 0);
+                a1[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, bh[u], a1[u], 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                a0[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bl[u], a0[u], 0, 0, 0);
+                a1[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bl[u], a1[u], 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int iy = ty * TH - 1 + hyu[u], ix = tx * 16 - 1 + hxu[u];
+                // unsigned compares: one test per coordinate, no short-circuit branches
+                const bool inside = ((unsigned)iy < (unsigned)(p.xHp - 2)) & ((unsigned)ix < (unsigned)(p.xWp - 2));
+                half8 hi8, lo8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float v = (j < 4 ? a0[u][j] : a1[u][j - 4]) * sc0[j] + sh0[j];
+                    v = inside ? __builtin_fmaxf(v, 0.f) : 0.f;
+                    hi8[j] = (half_t)v;
+                    lo8[j] = (half_t)(v - (float)hi8[j]);
+                }
+                if (hpu[u] < HR) {
+                    char* row = halo + hpu[u] * 128;
+                    *reinterpret_cast<half8*>(row + (((2 * q + (q & 1)) ^ (hxu[u] & 7)) << 4)) = hi8;
+                    *reinterpret_cast<half8*>(row + (((2 * q + 1 - (q & 1)) ^ (hxu[u] & 7)) << 4)) = lo8;
+                }
             }
         }
     };
