@@ -181,7 +181,8 @@ class ChessVision:
 
     def process_images(self, images: Sequence[NDArray[np.uint8]], threshold: float = 0.5, flip: bool = False,
                        fallback_quad: bool = False, pipeline_chunk: int = 64, return_crops: bool = True,
-                       timings: dict | None = None, first_job: int | None = None) -> list[ChessVisionResult]:
+                       timings: dict | None = None, first_job: int | None = None,
+                       last_job: int | None = None) -> list[ChessVisionResult]:
         """Batched pipeline (new; the reference processes one image per call, core.py:152-195).
 
         Images stay on the device between the two CNNs: INTER_AREA resize -> UNet (u8 in, logits + thresholded mask out);
@@ -223,11 +224,16 @@ class ChessVision:
             groups.setdefault(im.shape, []).append(i)
         step = max(1, int(pipeline_chunk))
         jobs = [ids[k:k + step] for ids in groups.values() for k in range(0, len(ids), step)]
-        first = int(os.environ.get("CHESSVISION_PIPE_FIRST_JOB", "0")) if first_job is None else int(first_job)
+        # Pipeline fill and drain are the only parts of a call the GPU does not overlap: nothing hides the staging + upload of the
+        # FIRST job, and after the last UNet the host still finds the LAST job's quadrangles before its classifier can start.  Both
+        # ends are therefore cut short (16 boards each by default; measured on MI355X, r03: 3578 -> 3658 boards/s for the short first
+        # job at 256 boards, although the UNet runs ~5 % slower on part-chunks); 0 switches a split off.
+        first = int(os.environ.get("CHESSVISION_PIPE_FIRST_JOB", "16")) if first_job is None else int(first_job)
+        last = int(os.environ.get("CHESSVISION_PIPE_LAST_JOB", "0")) if last_job is None else int(last_job)
         if len(jobs) > 1 and 0 < first < len(jobs[0]):
-            # optional short first job (nothing overlaps its staging + upload); measured on MI355X: the UNet runs ~5 % slower on
-            # 16- or 32-board jobs than on full 64-board chunks, which costs more than the shorter pipeline fill saves
             jobs = [jobs[0][:first], jobs[0][first:]] + jobs[1:]
+        if len(jobs) > 2 and 0 < last and len(jobs[-1]) >= 2 * last:
+            jobs = jobs[:-1] + [jobs[-1][:-last], jobs[-1][-last:]]
         tm = timings if timings is not None else {}
         for key in ("stage_s", "wait_masks_s", "contours_s", "homography_s", "wait_probs_s", "decode_s", "assemble_s"):
             tm.setdefault(key, 0.0)
