@@ -59,6 +59,11 @@ def pin_rank_cpus() -> list[int] | None:
     return mine
 
 
+def _forced() -> bool:
+    """CV_FORCE_DIST=1: run the collectives even in a world of one (how the RCCL code path is exercised on a one-GPU box)."""
+    return os.environ.get("CV_FORCE_DIST", "0") == "1"
+
+
 def backend_name() -> str | None:
     return dist.get_backend() if dist.is_initialized() else None
 
@@ -66,7 +71,9 @@ def backend_name() -> str | None:
 def _coll_device(device: torch.device) -> torch.device:
     """Where collective buffers live: the GPU under RCCL, host memory under gloo (two ranks may then share ONE GPU, which RCCL
     refuses -- CV_DIST_BACKEND=gloo is how the N > 1 code path is exercised on a one-GPU box)."""
-    return device if backend_name() == "nccl" else torch.device("cpu")
+    if backend_name() == "nccl":                          # RCCL moves device memory only: host tensors are staged through this rank's GPU
+        return device if device.type == "cuda" else torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
 
 
 def init_process_group(backend: str | None = None) -> tuple[int, int, torch.device]:
@@ -85,8 +92,7 @@ def init_process_group(backend: str | None = None) -> tuple[int, int, torch.devi
         local = local % max(1, n_dev)
         torch.cuda.set_device(local)
     device = torch.device("cuda", local) if use_gpu else torch.device("cpu")
-    force = os.environ.get("CV_FORCE_DIST", "0") == "1"          # exercise the RCCL path on one GPU (tests)
-    if (world > 1 or force) and not dist.is_initialized():
+    if (world > 1 or _forced()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -151,7 +157,7 @@ def broadcast_state_dict(state: Mapping[str, np.ndarray] | None, spec: Sequence[
 
 def all_gather_rows(local: torch.Tensor) -> torch.Tensor:
     """Concatenate equally-shaped per-rank result tensors along dim 0, rank-major."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not _forced()):
         return local
     cdev = _coll_device(local.device)
     mine = local.contiguous().to(cdev)
@@ -240,7 +246,7 @@ def process_images_sharded(cv, images: Sequence, threshold: float = 0.5, flip: b
     results: list = [None] * n
     for i, r in zip(mine, local):
         results[i] = r
-    if not gather or world == 1:
+    if not gather or (world == 1 and not _forced()):
         tm["gather_s"] = 0.0
         return results
 
