@@ -294,3 +294,29 @@ def test_c_abi_ignores_num_batches_tracked_entries():
     out = eng.resnet18_forward(synth.squares_input(seed=3, n=8))
     assert torch.isfinite(out).all()
     eng.close()
+
+
+def test_f16r_workspace_growth_keeps_the_f32_twins_consistent():
+    """The f16r engine's trunk tensors exist twice (f16 copy + f32 twin); growing the elastic workspace re-allocates both and the
+    shortcut-only tensors have no f16 copy at all.  Same squares before and after a growth, and inside a larger batch: same logits."""
+    from chessvision.hip_backend import HipEngine
+
+    net = synth.make_resnet(seed=2)
+    eng = HipEngine(precision="f16r", resnet_chunk=512)
+    eng.load_resnet18(net.state_dict())
+    small = synth.squares_input(seed=9, n=64)
+    a = eng.resnet18_forward(small).cpu()
+    ws = eng.workspace_bytes()
+    big = synth.squares_input(seed=10, n=700)               # grows to the 512-square chunk, then a 188-square tail chunk
+    big[:64] = small
+    b = eng.resnet18_forward(big).cpu()
+    assert eng.workspace_bytes() > ws
+    assert torch.equal(a, b[:64])
+    assert torch.equal(a, eng.resnet18_forward(small).cpu())
+    sc = eng.activation("resnet18", "layer2.0.downsample")  # f32-only tensor, read through its twin
+    with torch.no_grad():
+        x = net.maxpool(net.act1(net.bn1(net.conv1(small))))
+        x = net.layer1(x)
+        ref_sc = net.layer2[0].downsample(x)
+    assert sc.shape == tuple(ref_sc.shape) and float(np.abs(sc - ref_sc.numpy()).max()) <= 2e-2
+    eng.close()
