@@ -1,0 +1,125 @@
+/* consumer.c -- a plain C program against include/chessvision_hip.h: what a cgo / JNI / C++ host of the reference's hot path
+ * would do, with no Python in the call path.  Built by the tests with gcc (tests/test_c_abi_consumer.py):
+ *
+ *   consumer host                      host-only entry points (no GPU): ABI version, mask -> quadrangle, probabilities -> FEN
+ *   consumer gpu <blob> <squares.bin>  load a ResNet-18 state dict from a flat blob, classify squares on device 0 through
+ *                                      cv_resnet18_forward_u8, print the 13 probabilities of every square
+ *
+ * blob format (written by the test): int32 n_params, then per parameter: int32 name_len, name bytes, int32 ndim,
+ * int64 shape[4], float32 data.  squares.bin: int32 n, then n x 64 x 64 uint8.
+ * Device memory comes from the HIP runtime's C API (the reference-side host owns its buffers; the library never frees them). */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "chessvision_hip.h"
+
+#ifdef WITH_GPU
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+#endif
+
+#define CHECK(call)                                                                      \
+    do {                                                                                 \
+        int rc_ = (call);                                                                \
+        if (rc_ != CV_OK) { fprintf(stderr, "%s -> %d: %s\n", #call, rc_, cv_last_error()); return 1; } \
+    } while (0)
+
+static int host_mode(void) {
+    printf("abi %d\n", cv_abi_version());
+    /* a 256x256 mask with one bright convex quadrilateral */
+    static uint8_t mask[256 * 256];
+    for (int y = 60; y < 200; ++y)
+        for (int x = 50 + (y - 60) / 10; x < 210 - (y - 60) / 14; ++x) mask[y * 256 + x] = 255;
+    int32_t quad[8];
+    int found = 0;
+    CHECK(cv_find_quadrangle(mask, 256, 256, quad, &found));
+    printf("quad %d", found);
+    for (int i = 0; i < 8; ++i) printf(" %d", quad[i]);
+    printf("\n");
+    /* the start position as one-hot probabilities, a8..h1; then a pawn forced onto a8 with a rook as runner-up */
+    const char* order = "BKNPQRbknpqrf";
+    const char* board = "rnbqkbnrppppppppffffffffffffffffffffffffffffffffPPPPPPPPRNBQKBNR";
+    static float probs[2 * 64 * 13];
+    for (int b = 0; b < 2; ++b)
+        for (int s = 0; s < 64; ++s) probs[(b * 64 + s) * 13 + (int)(strchr(order, board[s]) - order)] = 1.0f;
+    float* a8 = probs + 64 * 13;
+    memset(a8, 0, 13 * sizeof(float));
+    a8[9] = 0.6f; a8[11] = 0.3f; a8[12] = 0.1f;          /* 'p' 0.6, 'r' 0.3, empty 0.1 */
+    char fen[2 * 72], orig[2 * 72];
+    int8_t labels[2 * 64];
+    int32_t fixes[2 * 16 * 4], n_fixes = 0;
+    CHECK(cv_decode_positions(probs, 2, 0, fen, orig, labels, fixes, &n_fixes));
+    printf("fen0 %s\nfen1 %s\norig1 %s\nfixes %d", fen, fen + 72, orig + 72, (int)n_fixes);
+    for (int i = 0; i < n_fixes * 4; ++i) printf(" %d", (int)fixes[i]);
+    printf("\n");
+    /* error path: status + message, never an abort */
+    int rc = cv_find_quadrangle(NULL, 256, 256, quad, &found);
+    printf("null_mask rc=%d msg=%s\n", rc, cv_last_error());
+    return 0;
+}
+
+#ifdef WITH_GPU
+static int gpu_mode(const char* blob_path, const char* squares_path) {
+    FILE* f = fopen(blob_path, "rb");
+    if (!f) { perror(blob_path); return 1; }
+    int32_t n_params = 0;
+    if (fread(&n_params, 4, 1, f) != 1) return 1;
+    cv_param_t* table = (cv_param_t*)calloc((size_t)n_params, sizeof(cv_param_t));
+    for (int i = 0; i < n_params; ++i) {
+        int32_t len = 0, ndim = 0;
+        if (fread(&len, 4, 1, f) != 1) return 1;
+        char* name = (char*)calloc((size_t)len + 1, 1);
+        if (fread(name, 1, (size_t)len, f) != (size_t)len || fread(&ndim, 4, 1, f) != 1) return 1;
+        if (fread(table[i].shape, 8, 4, f) != 4) return 1;
+        size_t numel = 1;
+        for (int d = 0; d < ndim; ++d) numel *= (size_t)table[i].shape[d];
+        float* data = (float*)malloc(numel * sizeof(float));
+        if (fread(data, sizeof(float), numel, f) != numel) return 1;
+        table[i].name = name; table[i].data = data; table[i].ndim = ndim;
+    }
+    fclose(f);
+    f = fopen(squares_path, "rb");
+    if (!f) { perror(squares_path); return 1; }
+    int32_t n = 0;
+    if (fread(&n, 4, 1, f) != 1) return 1;
+    uint8_t* squares = (uint8_t*)malloc((size_t)n * 4096);
+    if (fread(squares, 4096, (size_t)n, f) != (size_t)n) return 1;
+    fclose(f);
+
+    cv_engine_t* eng = NULL;
+    CHECK(cv_engine_create(0, CV_PREC_F16X3, &eng));
+    CHECK(cv_load_resnet18(eng, table, n_params));
+    uint8_t* d_sq = NULL;
+    float* d_probs = NULL;
+    if (hipMalloc((void**)&d_sq, (size_t)n * 4096) != hipSuccess || hipMalloc((void**)&d_probs, (size_t)n * 13 * sizeof(float)) != hipSuccess) return 1;
+    if (hipMemcpy(d_sq, squares, (size_t)n * 4096, hipMemcpyHostToDevice) != hipSuccess) return 1;
+    CHECK(cv_resnet18_forward_u8(eng, d_sq, n, d_probs, NULL));               /* NULL = the default stream */
+    CHECK(cv_engine_numeric_status(eng, NULL));                               /* synchronises; names a layer on overflow */
+    float* probs = (float*)malloc((size_t)n * 13 * sizeof(float));
+    if (hipMemcpy(probs, d_probs, (size_t)n * 13 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    for (int i = 0; i < n; ++i) {
+        printf("probs");
+        for (int c = 0; c < 13; ++c) printf(" %.9g", probs[i * 13 + c]);
+        printf("\n");
+    }
+    size_t ws = 0;
+    CHECK(cv_engine_workspace_bytes(eng, &ws));
+    printf("workspace %zu\n", ws);
+    int rc = cv_unet_forward(eng, NULL, 1, NULL, NULL);                       /* model not loaded: a status, not a crash */
+    printf("unet_not_loaded rc=%d msg=%s\n", rc, cv_last_error());
+    (void)hipFree(d_sq); (void)hipFree(d_probs);
+    CHECK(cv_engine_destroy(eng));
+    return 0;
+}
+#endif
+
+int main(int argc, char** argv) {
+    if (argc >= 2 && strcmp(argv[1], "host") == 0) return host_mode();
+#ifdef WITH_GPU
+    if (argc >= 4 && strcmp(argv[1], "gpu") == 0) return gpu_mode(argv[2], argv[3]);
+#endif
+    fprintf(stderr, "usage: consumer host | consumer gpu <state.blob> <squares.bin>\n");
+    return 2;
+}
