@@ -245,31 +245,41 @@ __global__ void maxpool3x3s2_kernel(TensorRef src, TensorRef dst) {
     Grp<T>::store(d, par, m);
 }
 
-// torch upsample_bilinear2d, align_corners=True: src = dst * (in-1)/(out-1); weights (1-l, l) in f32
+// torch upsample_bilinear2d, align_corners=True: src = dst * (in-1)/(out-1); weights (1-l, l) in f32.
+// Grid = (row segments, output rows, images): the row's source lines and vertical weights are wave-uniform and a thread finds its
+// (column, channel group) with one 32-bit division (r03: the flat one-thread-per-element form decoded its index with three 64-bit
+// divisions -- ~150 instructions around five 32-byte memory operations; a row-per-workgroup loop was slower still: fewer loads in flight).
 template <typename T>
-__global__ void upsample_bilinear2x_kernel(TensorRef src, TensorRef dst, float mul, unsigned* flag, unsigned layer_id) {
+__global__ __launch_bounds__(256) void upsample_bilinear2x_kernel(TensorRef src, TensorRef dst, float mul, unsigned* flag, unsigned layer_id) {
     constexpr int GN = Grp<T>::N;
-    const PG p = decode_pg<T>(dst);
-    if (!p.live) return;
+    const int y = blockIdx.y, n = blockIdx.z;
+    const unsigned groups = (unsigned)(dst.C / GN);
     const float sy = dst.H > 1 ? (float)(src.H - 1) / (float)(dst.H - 1) : 0.f;
     const float sx = dst.W > 1 ? (float)(src.W - 1) / (float)(dst.W - 1) : 0.f;
-    const float fy = sy * (float)p.y, fx = sx * (float)p.x;
-    const int y0 = (int)fy, x0 = (int)fx;
-    const int y1 = y0 + (y0 < src.H - 1 ? 1 : 0), x1 = x0 + (x0 < src.W - 1 ? 1 : 0);
-    const float ly1 = fy - (float)y0, lx1 = fx - (float)x0;
-    const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
-    float v00[GN], v01[GN], v10[GN], v11[GN], o[GN];
-    int par;
-    Grp<T>::load(grp_ptr<T>(src, pix_index(src, p.n, y0, x0), p.g, &par), par, v00);
-    Grp<T>::load(grp_ptr<T>(src, pix_index(src, p.n, y0, x1), p.g, &par), par, v01);
-    Grp<T>::load(grp_ptr<T>(src, pix_index(src, p.n, y1, x0), p.g, &par), par, v10);
-    Grp<T>::load(grp_ptr<T>(src, pix_index(src, p.n, y1, x1), p.g, &par), par, v11);
-#pragma unroll
-    for (int j = 0; j < GN; ++j)
-        o[j] = (ly0 * (lx0 * v00[j] + lx1 * v01[j]) + ly1 * (lx0 * v10[j] + lx1 * v11[j])) * mul;   // mul = 2^k: exact
-    char* d = grp_ptr<T>(dst, pix_index(dst, p.n, p.y, p.x), p.g, &par);
+    const float fy = sy * (float)y;
+    const int y0 = (int)fy;
+    const int y1 = y0 + (y0 < src.H - 1 ? 1 : 0);
+    const float ly1 = fy - (float)y0, ly0 = 1.f - ly1;
+    const size_t row0 = pix_index(src, n, y0, 0), row1 = pix_index(src, n, y1, 0), orow = pix_index(dst, n, y, 0);
     float bad = 0.f;
-    Grp<T>::store(d, par, o, bad);
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (unsigned)dst.W * groups) {
+        const unsigned x = idx / groups, g = idx - x * groups;
+        const float fx = sx * (float)x;
+        const int x0 = (int)fx;
+        const int x1 = x0 + (x0 < src.W - 1 ? 1 : 0);
+        const float lx1 = fx - (float)x0, lx0 = 1.f - lx1;
+        float v00[GN], v01[GN], v10[GN], v11[GN], o[GN];
+        int par;
+        Grp<T>::load(grp_ptr<T>(src, row0 + x0, g, &par), par, v00);
+        Grp<T>::load(grp_ptr<T>(src, row0 + x1, g, &par), par, v01);
+        Grp<T>::load(grp_ptr<T>(src, row1 + x0, g, &par), par, v10);
+        Grp<T>::load(grp_ptr<T>(src, row1 + x1, g, &par), par, v11);
+#pragma unroll
+        for (int j = 0; j < GN; ++j)
+            o[j] = (ly0 * (lx0 * v00[j] + lx1 * v01[j]) + ly1 * (lx0 * v10[j] + lx1 * v11[j])) * mul;   // mul = 2^k: exact
+        Grp<T>::store(grp_ptr<T>(dst, orow + x, g, &par), par, o, bad);
+    }
     report_bad(flag, layer_id, bad);
 }
 
@@ -774,8 +784,12 @@ hipError_t maxpool3x3s2(int dt, const TensorRef& src, const TensorRef& dst, hipS
 }
 hipError_t upsample_bilinear2x(int dt, const TensorRef& src, const TensorRef& dst, unsigned* flag, unsigned layer_id,
                                hipStream_t s) {
-    CV_DISPATCH(upsample_bilinear2x_kernel, (size_t)dst.N * dst.H * dst.W * (dst.C / dtype_group(dt)), src, dst,
-                pow2f(src.exp - dst.exp), flag, layer_id);
+    const dim3 g_((unsigned)((dst.W * (dst.C / dtype_group(dt)) + 255) / 256), (unsigned)dst.H, (unsigned)dst.N), b_(256);
+    const float mul = pow2f(src.exp - dst.exp);
+    if (dt == kF16) hipLaunchKernelGGL(upsample_bilinear2x_kernel<half_t>, g_, b_, 0, s, src, dst, mul, flag, layer_id);
+    else if (dt == kSplit) hipLaunchKernelGGL(upsample_bilinear2x_kernel<split_t>, g_, b_, 0, s, src, dst, mul, flag, layer_id);
+    else hipLaunchKernelGGL(upsample_bilinear2x_kernel<float>, g_, b_, 0, s, src, dst, mul, flag, layer_id);
+    return hipGetLastError();
 }
 hipError_t outc_1x1(int dt, const TensorRef& src, const float* w, const float* bias, float* logits,
                     uint8_t* mask, float threshold, unsigned* flag, unsigned layer_id, hipStream_t s) {
