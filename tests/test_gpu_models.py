@@ -95,7 +95,7 @@ def test_unet_forward_matches_oracle(prec, bilinear):
 RESNET_TAPS = ["act1", "maxpool", "layer1.0", "layer1", "layer2.0", "layer2", "layer3", "layer4"]
 
 
-@pytest.mark.parametrize("prec", ["f32", "f16", "f16x3"])
+@pytest.mark.parametrize("prec", ["f32", "f16", "f16x3", "f16r"])
 def test_resnet18_forward_matches_oracle(prec):
     from chessvision.hip_backend import HipEngine
 

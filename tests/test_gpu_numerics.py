@@ -71,7 +71,7 @@ def test_unet_with_stressed_ranges_matches_oracle(prec, bilinear):
     assert torch.equal((out > 0)[away], (ref > 0)[away])
 
 
-@pytest.mark.parametrize("prec", ["f16x3", "f32", "f16"])
+@pytest.mark.parametrize("prec", ["f16x3", "f32", "f16", "f16r"])
 def test_resnet_with_stressed_ranges_matches_oracle(prec):
     from chessvision.hip_backend import HipEngine
 
@@ -85,7 +85,7 @@ def test_resnet_with_stressed_ranges_matches_oracle(prec):
     out = eng.resnet18_forward(sq).cpu()
     eng.close()
     err = float((out - ref).abs().max())
-    if prec == "f16":                                     # 11-bit storage: the rounding floor, but no overflow, no NaN
+    if prec in ("f16", "f16r"):                           # 11-bit products: the rounding floor, but no overflow, no NaN
         assert torch.isfinite(out).all()
         assert err <= 5e-3 * max(1.0, float(ref.abs().max())), err
     else:
