@@ -40,8 +40,12 @@ namespace cv {
 // 27 -> one MFMA k-step) from a 20 x 20 x 3 patch of the caller's image -- UNet inc.double_conv.0 fused into inc.double_conv.3.
 // The 64-channel full-resolution tensor between the two convs (1.07 GB per 64 images, written once and read 1.27x) never
 // exists; the recompute is the 18^2/16^2 halo overlap of a layer that holds 0.2 % of the network's MACs.
+#ifndef CV_HALO_TH8_SINGLE
+#define CV_HALO_TH8_SINGLE 0      // experiment (with -DCV_HALO_TH64=8): 8 x 16 patch with ONE halo buffer = 47 KB -> THREE workgroups per CU
+#endif
+constexpr int halo_waves_per_eu(int ct, int th, bool dbh) { return (CV_HALO_TH8_SINGLE && ct == 64 && th == 8 && !dbh) ? 3 : 2; }
 template <typename T, int CT, int TH, int WGC, int NW, int TPS, int NSW, int IMG, bool PERSIST, bool DBH = true, bool FUSE0 = false>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_halo_kernel(const ConvParams p) {
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(halo_waves_per_eu(CT, TH, DBH), halo_waves_per_eu(CT, TH, DBH)))) void conv3x3_halo_kernel(const ConvParams p) {
     static_assert(!FUSE0 || (!DBH && !PERSIST && IMG == 0 && CT == 64 && NW == 4 && __is_same(T, split_t)), "fused producer: split-f16 64-channel single-halo tile");
     static_assert(TPS == 1 && (NSW == 3 || NSW == 4), "stage shape");
     constexpr int SPC = 9 / TPS;                        // stages per channel block
@@ -811,7 +815,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
 // ---- host-side launch -------------------------------------------------------------------------------------
 // the 64-channel tile over a 16 x 16 patch keeps a single halo buffer (see the kernel: DBH)
-template <int CT, int TH> static constexpr bool halo_double() { return !(CT == 64 && TH == 16); }
+template <int CT, int TH> static constexpr bool halo_double() { return !(CT == 64 && (TH == 16 || (TH == 8 && CV_HALO_TH8_SINGLE))); }
 
 template <int CT, int TH, int NW, int TPS, int NSW, int IMG>
 static constexpr size_t halo_lds() {
