@@ -234,35 +234,32 @@ def get_perspective_transforms(src: NDArray[np.float32], dst: NDArray[np.float32
 
 
 def warp_perspective(image: NDArray[np.uint8], m: NDArray[np.float64], size: tuple[int, int]) -> NDArray[np.uint8]:
-    """dst(x, y) = bilinear(src, M^-1 (x, y, 1)), constant-zero border; source coordinates are snapped to 1/32
-    pixel like OpenCV's fixed-point remap (INTER_BITS = 5)."""
+    """cv2.warpPerspective(image, M, size) with its defaults (INTER_LINEAR, BORDER_CONSTANT 0) in OpenCV's fixed-point form
+    (``imgwarp.cpp``): source coordinates in 1/32 pixel (``INTER_BITS = 5``: X = round(X0 * (32 / W0))), integer bilinear weights
+    (32-a)(32-b)*32 ... a*b*32 that sum to 2^15 (``INTER_REMAP_COEF_BITS``), pixel = (sum + 2^14) >> 15, i.e. round half UP.
+    (Rounds 1-2 of this package blended in floating point and rounded ties to even: one grey level apart on ~0.5 % of the pixels.)"""
     w_out, h_out = size
     inv = np.linalg.inv(m)
     xs, ys = np.meshgrid(np.arange(w_out, dtype=np.float64), np.arange(h_out, dtype=np.float64))
     den = inv[2, 0] * xs + inv[2, 1] * ys + inv[2, 2]
-    den = np.where(den == 0, 1e-12, den)
-    sx = (inv[0, 0] * xs + inv[0, 1] * ys + inv[0, 2]) / den
-    sy = (inv[1, 0] * xs + inv[1, 1] * ys + inv[1, 2]) / den
-    sx = np.rint(sx * 32.0) / 32.0
-    sy = np.rint(sy * 32.0) / 32.0
-    x0, y0 = np.floor(sx).astype(np.int64), np.floor(sy).astype(np.int64)
-    fx, fy = sx - x0, sy - y0
+    scale = np.divide(32.0, den, out=np.zeros_like(den), where=den != 0)
+    lim = (-2.0 ** 31, 2.0 ** 31 - 1)
+    xi = np.rint(np.clip((inv[0, 0] * xs + inv[0, 1] * ys + inv[0, 2]) * scale, *lim)).astype(np.int64)
+    yi = np.rint(np.clip((inv[1, 0] * xs + inv[1, 1] * ys + inv[1, 2]) * scale, *lim)).astype(np.int64)
+    x0, y0 = xi >> 5, yi >> 5
+    ax, ay = (xi & 31)[..., None], (yi & 31)[..., None]
     img = image if image.ndim == 3 else image[:, :, None]
     h, w, c = img.shape
-    padded = np.zeros((h + 2, w + 2, c), dtype=np.float64)
+    padded = np.zeros((h + 2, w + 2, c), dtype=np.int64)
     padded[1:-1, 1:-1] = img
 
     def tap(yy, xx):
-        yy = np.clip(yy + 1, 0, h + 1)
-        xx = np.clip(xx + 1, 0, w + 1)
-        return padded[yy, xx]
+        ok = (yy >= -1) & (yy <= h) & (xx >= -1) & (xx <= w)                    # the zero frame itself is "outside"
+        return padded[np.clip(yy + 1, 0, h + 1), np.clip(xx + 1, 0, w + 1)] * ok[..., None]
 
-    inside = (x0 >= -1) & (x0 < w) & (y0 >= -1) & (y0 < h)
-    fx, fy = fx[..., None], fy[..., None]
-    val = ((1 - fy) * ((1 - fx) * tap(y0, x0) + fx * tap(y0, x0 + 1)) +
-           fy * ((1 - fx) * tap(y0 + 1, x0) + fx * tap(y0 + 1, x0 + 1)))
-    val = np.where(inside[..., None], val, 0.0)
-    out = np.clip(np.rint(val), 0, 255).astype(np.uint8)
+    acc = ((32 - ax) * (32 - ay) * 32 * tap(y0, x0) + ax * (32 - ay) * 32 * tap(y0, x0 + 1) +
+           (32 - ax) * ay * 32 * tap(y0 + 1, x0) + ax * ay * 32 * tap(y0 + 1, x0 + 1))
+    out = ((acc + (1 << 14)) >> 15).astype(np.uint8)
     return out if image.ndim == 3 else out[:, :, 0]
 
 

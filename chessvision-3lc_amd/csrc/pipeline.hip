@@ -81,30 +81,33 @@ __global__ void extract_squares_u8_kernel(const uint8_t* __restrict__ images, in
     const int img = (int)(idx / ((size_t)B * B));
     const double* m = inv + (size_t)img * 9;
     const double xs = (double)(B - 1 - bx), ys = (double)by;       // undo cv2.flip(board, 1)
-    double den = m[6] * xs + m[7] * ys + m[8];
-    if (den == 0.0) den = 1e-12;
-    double sx = (m[0] * xs + m[1] * ys + m[2]) / den;
-    double sy = (m[3] * xs + m[4] * ys + m[5]) / den;
-    sx = rint(sx * 32.0) / 32.0;                          // OpenCV remap: INTER_BITS = 5
-    sy = rint(sy * 32.0) / 32.0;
-    const double x0f = floor(sx), y0f = floor(sy);
-    const long long x0 = (long long)x0f, y0 = (long long)y0f;
-    const double fx = sx - x0f, fy = sy - y0f;
+    // cv2.warpPerspective, INTER_LINEAR, BORDER_CONSTANT(0), in OpenCV's fixed-point form (imgwarp.cpp): source coordinates in 1/32
+    // pixel (INTER_BITS = 5; X = round(X0 * (32 / W0)), ties to even), integer bilinear weights (32-a)(32-b)*32 ... a*b*32 that sum to
+    // 2^15 (INTER_REMAP_COEF_BITS), pixel = (sum + 2^14) >> 15: round half UP.  (Rounds 1-2 blended in double and rounded ties to even:
+    // one grey level apart on ~0.5 % of the pixels.)
+    const double den = m[6] * xs + m[7] * ys + m[8];
+    const double scale = den != 0.0 ? 32.0 / den : 0.0;
+    double fxs = (m[0] * xs + m[1] * ys + m[2]) * scale;
+    double fys = (m[3] * xs + m[4] * ys + m[5]) * scale;
+    fxs = fxs < -2147483648.0 ? -2147483648.0 : fxs > 2147483647.0 ? 2147483647.0 : fxs;
+    fys = fys < -2147483648.0 ? -2147483648.0 : fys > 2147483647.0 ? 2147483647.0 : fys;
+    const long long xi = (long long)rint(fxs), yi = (long long)rint(fys);
+    const long long x0 = xi >> 5, y0 = yi >> 5;
+    const int ax = (int)(xi & 31), ay = (int)(yi & 31);
+    const int w00 = (32 - ax) * (32 - ay) * 32, w01 = ax * (32 - ay) * 32, w10 = (32 - ax) * ay * 32, w11 = ax * ay * 32;
     const bool inside = x0 >= -1 && x0 < w && y0 >= -1 && y0 < h;
     const uint8_t* s = images + (size_t)img * h * w * 3;
     int bgr[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        double v = 0.0;
+        int acc = 0;
         if (inside) {
-            auto tap = [&](long long yy, long long xx) -> double {
-                return (yy >= 0 && yy < h && xx >= 0 && xx < w) ? (double)s[((size_t)yy * w + xx) * 3 + c] : 0.0;
+            auto tap = [&](long long yy, long long xx) -> int {
+                return (yy >= 0 && yy < h && xx >= 0 && xx < w) ? (int)s[((size_t)yy * w + xx) * 3 + c] : 0;
             };
-            v = (1 - fy) * ((1 - fx) * tap(y0, x0) + fx * tap(y0, x0 + 1)) +
-                fy * ((1 - fx) * tap(y0 + 1, x0) + fx * tap(y0 + 1, x0 + 1));
+            acc = w00 * tap(y0, x0) + w01 * tap(y0, x0 + 1) + w10 * tap(y0 + 1, x0) + w11 * tap(y0 + 1, x0 + 1);
         }
-        v = rint(v);
-        bgr[c] = (int)(v < 0.0 ? 0.0 : v > 255.0 ? 255.0 : v);
+        bgr[c] = (acc + (1 << 14)) >> 15;
     }
     // OpenCV 4.x 8-bit BGR2GRAY: 15 fractional bits (BY15 / GY15 / RY15, gray_shift = 15); 3.x used 1868 / 9617 / 4899 >> 14
     const uint8_t gray = (uint8_t)((bgr[0] * 3735 + bgr[1] * 19235 + bgr[2] * 9798 + (1 << 14)) >> 15);

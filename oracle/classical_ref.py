@@ -14,9 +14,11 @@ Deliberately the slow, literal form (loops and float64) -- small inputs only.
     argmax -> python-chess board_fen    core.py:326-349                             placement
     pawn rule                           core.py:453-469, constants.py:88-106        pawn_rule
 
-NOT restated independently (the end-to-end oracle takes them from the product's numpy host path and says so): the contour
-chain (findContours / contourArea / boundingRect / arcLength / approxPolyDP -- pinned instead on the reference's own 631
-label masks, tests/test_contour_cpp.py) and the perspective warp (getPerspectiveTransform / warpPerspective).
+    getPerspectiveTransform + warpPerspective   utils.py:115-132                    perspective_matrix, warp_perspective
+
+NOT restated independently (the end-to-end oracle takes it from the product's numpy host path and says so): the contour chain
+(findContours / contourArea / boundingRect / arcLength / approxPolyDP -- pinned instead on the reference's own 631 label masks,
+tests/test_contour_cpp.py).
 """
 from __future__ import annotations
 
@@ -121,3 +123,80 @@ def pawn_rule(labels: list[str], probs: np.ndarray, names: list[str]):
                 fixes.append((name, lab, LABELS[idx]))
                 break
     return out, fixes
+
+
+def perspective_matrix(src: np.ndarray, dst: np.ndarray) -> np.ndarray:
+    """cv2.getPerspectiveTransform: the 3x3 map with m33 = 1 taking four ``src`` points onto ``dst``.  OpenCV sets up the 8x8 system
+    [x y 1 0 0 0 -xu -yu; 0 0 0 x y 1 -xv -yv] h = [u; v] and solves it in double precision; here by Gaussian elimination with
+    partial pivoting, written out (no library solver shared with the product)."""
+    s4 = np.asarray(src, np.float64).reshape(4, 2)
+    d4 = np.asarray(dst, np.float64).reshape(4, 2)
+    a = [[0.0] * 9 for _ in range(8)]
+    for i in range(4):
+        x, y = s4[i]
+        u, v = d4[i]
+        a[2 * i] = [x, y, 1.0, 0.0, 0.0, 0.0, -x * u, -y * u, u]
+        a[2 * i + 1] = [0.0, 0.0, 0.0, x, y, 1.0, -x * v, -y * v, v]
+    for col in range(8):
+        piv = max(range(col, 8), key=lambda r: abs(a[r][col]))
+        a[col], a[piv] = a[piv], a[col]
+        for r in range(col + 1, 8):
+            f = a[r][col] / a[col][col]
+            for c in range(col, 9):
+                a[r][c] -= f * a[col][c]
+    h = [0.0] * 8
+    for r in range(7, -1, -1):
+        h[r] = (a[r][8] - sum(a[r][c] * h[c] for c in range(r + 1, 8))) / a[r][r]
+    return np.array(h + [1.0], np.float64).reshape(3, 3)
+
+
+def _invert3(m: np.ndarray) -> np.ndarray:
+    (a, b, c), (d, e, f), (g, h, i) = m
+    det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g)
+    adj = np.array([[e * i - f * h, c * h - b * i, b * f - c * e],
+                    [f * g - d * i, a * i - c * g, c * d - a * f],
+                    [d * h - e * g, b * g - a * h, a * e - b * d]], np.float64)
+    return adj / det
+
+
+def warp_perspective(image: np.ndarray, m: np.ndarray, size: tuple[int, int]) -> np.ndarray:
+    """cv2.warpPerspective(image, M, (w, h)) with its defaults (INTER_LINEAR, BORDER_CONSTANT 0), in OpenCV's fixed-point form:
+    the inverse map gives source coordinates in 1/32 pixel (``INTER_BITS = 5``: X = round(32 * X0 / W0)), the four bilinear weights
+    are the integers (32-a)(32-b)*32 ... a*b*32 (``INTER_REMAP_COEF_BITS = 15``: they sum to 2^15 exactly) and the pixel is
+    ``(sum(w * p) + 2^14) >> 15`` -- round half UP, where a float blend rounds ties to even.  Taps outside the image read 0."""
+    w_out, h_out = size
+    inv = _invert3(np.asarray(m, np.float64))
+    img = image if image.ndim == 3 else image[:, :, None]
+    h, w, ch = img.shape
+    ys, xs = np.mgrid[0:h_out, 0:w_out].astype(np.float64)
+    x0 = inv[0, 0] * xs + inv[0, 1] * ys + inv[0, 2]
+    y0 = inv[1, 0] * xs + inv[1, 1] * ys + inv[1, 2]
+    w0 = inv[2, 0] * xs + inv[2, 1] * ys + inv[2, 2]
+    scale = np.where(w0 != 0, 32.0 / np.where(w0 != 0, w0, 1.0), 0.0)
+    fx = np.clip(x0 * scale, -2.0 ** 31, 2.0 ** 31 - 1)
+    fy = np.clip(y0 * scale, -2.0 ** 31, 2.0 ** 31 - 1)
+    xi = np.rint(fx).astype(np.int64)                        # saturate_cast<int>(double): round to nearest, ties to even
+    yi = np.rint(fy).astype(np.int64)
+    sx, sy, ax, ay = xi >> 5, yi >> 5, xi & 31, yi & 31
+    pad = np.zeros((h + 2, w + 2, ch), np.int64)
+    pad[1:h + 1, 1:w + 1] = img
+
+    def tap(yy, xx):
+        ok = (yy >= 0) & (yy < h) & (xx >= 0) & (xx < w)
+        return pad[np.clip(yy + 1, 0, h + 1), np.clip(xx + 1, 0, w + 1)] * ok[..., None]
+
+    w00 = ((32 - ax) * (32 - ay) * 32)[..., None]
+    w01 = (ax * (32 - ay) * 32)[..., None]
+    w10 = ((32 - ax) * ay * 32)[..., None]
+    w11 = (ax * ay * 32)[..., None]
+    acc = w00 * tap(sy, sx) + w01 * tap(sy, sx + 1) + w10 * tap(sy + 1, sx) + w11 * tap(sy + 1, sx + 1)
+    out = ((acc + (1 << 14)) >> 15).astype(np.uint8)
+    return out if image.ndim == 3 else out[:, :, 0]
+
+
+def extract_board(image: np.ndarray, quad: np.ndarray, size: tuple[int, int] = (512, 512)) -> np.ndarray:
+    """``utils.extract_perspective`` of the reference (utils.py:115-132): quadrangle (TR, TL, BL, BR order as the reference's
+    ``_rotate_quadrangle`` leaves it) -> destination corners ((0,0), (w,0), (w,h), (0,h)) -> warp."""
+    w, h = size
+    dest = np.array(((0, 0), (w, 0), (w, h), (0, h)), np.float64)
+    return warp_perspective(image, perspective_matrix(np.asarray(quad, np.float64).reshape(4, 2), dest), size)

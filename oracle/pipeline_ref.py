@@ -6,15 +6,15 @@ TEST INFRASTRUCTURE (see ``oracle/__init__.py``).  The reference pipeline (``che
 and keeps the two models behind opaque callables (``core.py:53-54``).  Here it is written out stage by stage:
 
 * the two CNNs are ``oracle.unet_ref.UNet`` / ``oracle.resnet_ref.ResNet18`` on torch CPU fp32;
-* resize (integer factors), sigmoid / threshold, gray, flip, the 64-way split, soft-max, arg-max, FEN and the pawn rule are
-  the INDEPENDENT restatements of ``oracle/classical_ref.py`` -- they share no code with the product's host path
+* resize (integer factors), sigmoid / threshold, the perspective matrix and warp (OpenCV's fixed-point form: 1/32-pixel
+  coordinates, integer weights, round half up), gray, flip, the 64-way split, soft-max, arg-max, FEN and the pawn rule are the
+  INDEPENDENT restatements of ``oracle/classical_ref.py`` -- they share no code with the product's host path
   (``chessvision/classical.py``, ``fen.py``, ``ChessVision`` statics) nor with its device / C++ path;
-* two stages are NOT independent and are taken from the product's numpy host path: the mask -> quadrangle chain
+* ONE stage is not independent and is taken from the product's numpy host path: the mask -> quadrangle chain
   (``ChessVision._find_quadrangle`` = Suzuki border following, area / box filter, Douglas-Peucker; pinned on the reference's
-  own 631 label masks against ``coordinates.json``, tests/test_contour_cpp.py) and the perspective warp
-  (``utils.extract_perspective``).  For those two the end-to-end test compares two implementations (device / C++ versus
-  numpy) of ONE reading of OpenCV; a shared misreading there is caught only by the 631-mask fixture, not here.  Non-integer
-  resize factors also fall back to the product's coverage-weighted form.
+  own 631 label masks against ``coordinates.json``, tests/test_contour_cpp.py).  For it the end-to-end test compares two
+  implementations (C++ versus numpy) of ONE reading of OpenCV; a shared misreading there is caught only by the 631-mask
+  fixture, not here.  Non-integer resize factors also fall back to the product's coverage-weighted form.
 
 ``fallback_quad`` mirrors the option of ``process_images``: boards whose mask yields no quadrangle are classified through
 the whole-image quadrangle (TR, TL, BL, BR of the 256x256 mask) so that random-init weights still exercise the classifier.
@@ -30,8 +30,8 @@ from . import classical_ref as cref
 
 
 def process_image(unet, resnet, image: np.ndarray, threshold: float = 0.5, flip: bool = False, fallback_quad: bool = False):
-    from chessvision import ChessVision, classical, utils                      # the two shared stages + result records only
-    from chessvision.cv_types import BoardExtractionResult, ChessVisionResult, PositionResult, ValidationFix
+    from chessvision import ChessVision, classical                             # the shared contour stage + result records only
+    from chessvision.cv_types import BoardExtractionResult, ChessVisionResult
 
     t0 = time.time()
     h, w = image.shape[:2]
@@ -49,21 +49,31 @@ def process_image(unet, resnet, image: np.ndarray, threshold: float = 0.5, flip:
         ext = BoardExtractionResult(board_image=None, binary_mask=mask, quadrangle=None, probabilities=logits)
         return ChessVisionResult(board_extraction=ext, position=None, processing_time=time.time() - t0)
     scaled = np.array(quad * (h / 256.0), dtype=np.float32)                     # height only, core.py:416
-    board = utils.extract_perspective(image, scaled, (512, 512))                # shared (see the module docstring)
-    board = cref.flip_lr(cref.bgr_to_gray(board))
+    board = cref.flip_lr(cref.bgr_to_gray(cref.extract_board(image, scaled, (512, 512))))
+    position = classify_board(resnet, board, flip)
+    ext = BoardExtractionResult(board_image=board, binary_mask=mask, quadrangle=scaled, probabilities=logits)
+    return ChessVisionResult(board_extraction=ext, position=position, processing_time=time.time() - t0)
+
+
+def classify_board(resnet, board: np.ndarray, flip: bool = False):
+    """The second half of the chain on a GIVEN rectified board (reference ``classify_position``, core.py:225-249, and
+    ``process_position_probabilities``, core.py:309-355): split, /255, classifier, soft-max, arg-max, FEN, pawn rule.  The
+    end-to-end tests call it on the board the device produced when that board differs from the oracle's by warp-coordinate ties,
+    so that the classifier stage is judged on identical inputs."""
+    from chessvision.cv_types import PositionResult, ValidationFix
+
     squares = cref.split_squares(board)
     batch = torch.from_numpy(squares.astype(np.float32)).permute(0, 3, 1, 2) / 255.0            # core.py:236-237
-    probs = torch.softmax(resnet(batch), dim=1).numpy()
+    with torch.no_grad():
+        probs = torch.softmax(resnet(batch), dim=1).numpy()
     names = cref.square_names(flip)
     labels = [cref.LABELS[int(i)] for i in np.argmax(probs, axis=1)]
     original = cref.placement(labels, names)
     fixed, fixes = cref.pawn_rule(labels, probs, names)
-    position = PositionResult(fen=cref.placement(fixed, names), original_fen=original, model_probabilities=probs, squares=squares,
-                              square_names=names,
-                              validation_fixes=[ValidationFix(square_name=s, original_piece=o, corrected_piece=n, rule_name="no_pawns_on_ends")
-                                                for s, o, n in fixes])
-    ext = BoardExtractionResult(board_image=board, binary_mask=mask, quadrangle=scaled, probabilities=logits)
-    return ChessVisionResult(board_extraction=ext, position=position, processing_time=time.time() - t0)
+    return PositionResult(fen=cref.placement(fixed, names), original_fen=original, model_probabilities=probs, squares=squares,
+                          square_names=names,
+                          validation_fixes=[ValidationFix(square_name=s, original_piece=o, corrected_piece=n, rule_name="no_pawns_on_ends")
+                                            for s, o, n in fixes])
 
 
 def process_images(unet, resnet, images, threshold: float = 0.5, flip: bool = False, fallback_quad: bool = False):

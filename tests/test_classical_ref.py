@@ -79,3 +79,34 @@ def test_start_position_reads_as_the_standard_fen():
     labels = list(back) + ["p"] * 8 + ["f"] * 32 + ["P"] * 8 + list(back.upper())
     assert cref.placement(labels, cref.square_names(False)) == "rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR"
     assert cref.placement(labels[::-1], cref.square_names(True)) == "rnbqkbnr/pppppppp/8/8/8/8/PPPPPPPP/RNBQKBNR"
+
+
+def test_perspective_matrix_and_warp_agree_with_the_product():
+    """Two readings of getPerspectiveTransform + warpPerspective: the product blends in floating point after snapping the source
+    coordinates to 1/32 pixel ... until round 3; both now use OpenCV's integer weights and round-half-up, written independently
+    (matrix by library solve / inverse here, by hand-written elimination / adjugate there).  Same matrix to 1e-9; same image except
+    where the last bit of the inverse moves a coordinate across a 1/64-pixel boundary (< 1e-4 of the pixels)."""
+    rng = np.random.default_rng(21)
+    img = rng.integers(0, 256, (384, 512, 3), dtype=np.uint8)
+    smooth = np.clip(np.add.outer(np.arange(384), np.arange(512))[..., None] * np.array([0.2, 0.25, 0.3]) , 0, 255).astype(np.uint8)
+    dest = np.array(((0, 0), (512, 0), (512, 512), (0, 512)), np.float32)
+    for trial in range(6):
+        quad = np.array([[430, 40], [60, 55], [45, 340], [470, 350]], np.float32) + rng.uniform(-25, 25, (4, 2)).astype(np.float32)
+        m_prod = classical.get_perspective_transform(quad, dest)
+        m_ref = cref.perspective_matrix(quad, dest)
+        assert np.abs(m_prod - m_ref).max() <= 1e-9 * max(1.0, np.abs(m_ref).max())
+        for src in (img, smooth):
+            a = utils.extract_perspective(src, quad.reshape(4, 1, 2), (512, 512))
+            b = cref.extract_board(src, quad, (512, 512))
+            diff = np.abs(a.astype(int) - b.astype(int))
+            assert diff.max() <= 8, diff.max()
+            assert (diff > 0).mean() <= 1e-4, float((diff > 0).mean())      # matrix inverses differ in the last bit: a coordinate may land on the other side of a 1/64 boundary
+    # a quadrangle reaching outside the image: constant-zero border on both sides
+    quad = np.array([[540, -20], [-30, 10], [-10, 400], [530, 390]], np.float32)
+    a = utils.extract_perspective(img, quad.reshape(4, 1, 2), (512, 512))
+    b = cref.extract_board(img, quad, (512, 512))
+    diff = np.abs(a.astype(int) - b.astype(int))
+    # the two matrix inverses differ in the last bit, so a coordinate may round to the neighbouring 1/32-pixel step: on noise that is
+    # up to 255 / 32 grey levels, on a handful of pixels
+    assert diff.max() <= 8 and (diff > 0).mean() <= 1e-4, (diff.max(), float((diff > 0).mean()))
+    assert (b[:4, :4] == 0).all() and (a[:4, :4] == 0).all()
