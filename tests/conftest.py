@@ -35,6 +35,18 @@ def pytest_collection_modifyitems(config, items):
                 item.add_marker(skip)
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _native_library():
+    """Several CPU tests call host-only entry points of the C-ABI library (contours, FEN decoding, the plain-C consumer): build it
+    once per session when the tree has none yet (a fresh checkout; the GPU box receives the built file with the snapshot)."""
+    lib = PKG_ROOT / "lib" / "libchessvision_hip.so"
+    if not lib.exists():
+        import __graft_entry__ as ge
+
+        ge.build()
+    yield
+
+
 @pytest.fixture(scope="session")
 def engines():
     """{'f32' | 'f16' | 'f16x3': HipEngine} with small chunks (tests use small batches)."""
