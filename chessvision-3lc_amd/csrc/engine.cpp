@@ -543,7 +543,8 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
         const char* tn = dt == kF32 ? "float" : dt == kF16 ? "half_t" : "split_t";
         if (halo)
             prof.back().kernel = std::string("conv3x3_halo_kernel<") + tn + "," + std::to_string(ct) + ",16x16" +
-                                 (Ho == 8 ? ",IMG8" : "") + (fuse0 ? ",FUSE0" : "") + (fuse_pool ? ",pool" : "") + (head ? ",head" : "") + ">";
+                                 (Ho == 8 ? ",IMG8" : "") + (fuse0 ? ",FUSE0" : "") + ">";   // template parameters only: a fused pool / 1x1 head is
+                                                                                              // a run-time option of the same instantiation
         else
             prof.back().kernel = std::string("conv_igemm_kernel<") + tn + "," + std::to_string(conv_cfg_ct(cfg)) + "x" +
                                  std::to_string(conv_cfg_pt(cfg)) + ",ring" + std::to_string(ns) + (L.shuffle ? ",shuffle" : "") + ">";
