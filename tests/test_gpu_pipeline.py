@@ -143,3 +143,45 @@ def test_batched_api_with_mixed_sizes_and_missing_boards(tmp_path_factory):
         assert np.array_equal(a.board_extraction.quadrangle, b.board_extraction.quadrangle)
         assert np.abs(a.position.model_probabilities - b.position.model_probabilities).max() <= 2e-2
         assert b.position.squares.shape == (64, 64, 64, 1)
+
+
+def test_concurrent_request_threads_share_one_lazy_instance(tmp_path_factory):
+    """The reference's Flask app keeps ONE global ChessVision(lazy_load=...) and serves requests from several threads
+    (app/computeroot/cv_endpoint.py:131-133) with no lock of its own.  Eight threads hit a still-lazy instance at once: the models
+    are initialised exactly once, the forwards serialise on the engine's mutex, and every thread gets the result the sequential
+    call gives."""
+    import threading
+
+    d = tmp_path_factory.mktemp("weights_threads")
+    pe, pc = synthetic.save_checkpoints(d, segmenting=True)
+    images = [synthetic.board_photo(900 + k) for k in range(8)]
+    ref_cv = ChessVision(board_extractor_weights=str(pe), classifier_weights=str(pc))
+    want = [ref_cv.process_image(im) for im in images]
+
+    cv = ChessVision(board_extractor_weights=str(pe), classifier_weights=str(pc))      # lazy: nothing loaded yet
+    assert cv._board_extractor is None and cv._classifier is None
+    got, errors = [None] * 8, []
+    start = threading.Barrier(8)
+
+    def worker(k):
+        try:
+            start.wait()
+            for _ in range(3):                                  # a few rounds so that forwards really interleave
+                got[k] = cv.process_image(images[k])
+        except Exception as exc:                                # noqa: BLE001
+            errors.append(repr(exc))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    assert len(cv._engines) == 1                                # one engine, created once
+    for g, w in zip(got, want):
+        assert np.array_equal(g.board_extraction.binary_mask, w.board_extraction.binary_mask)
+        assert np.array_equal(g.board_extraction.probabilities, w.board_extraction.probabilities)
+        assert (g.position is None) == (w.position is None)
+        if w.position is not None:
+            assert g.position.fen == w.position.fen
+            assert np.array_equal(g.position.model_probabilities, w.position.model_probabilities)
