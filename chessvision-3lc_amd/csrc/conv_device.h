@@ -132,14 +132,21 @@ template <int N> struct OutVec<split_t, N> {
 #pragma unroll
         for (int i = 0; i < N; i += 8) {
             const int par = ((ch0 + i) >> 3) & 1;
-            half8 hi, lo;
+            // three vector instructions per PAIR of values for the hi/lo split (cv_kernels.h: split_pair) and the numeric guard on the
+            // packed hi pair (hi * 0 is NaN for +-inf and NaN): ~2 instructions per stored value instead of ~4.5
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            typedef unsigned u4 __attribute__((ext_vector_type(4)));
+            u4 hu, lu;
+            h2 g2 = {(half_t)0.f, (half_t)0.f};
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                hi[j] = (half_t)v[i + j];
-                const float back = (float)hi[j];
-                bad = __builtin_fmaf(back, 0.f, bad);   // +-inf (|v| beyond the f16 range) and NaN turn `bad` into NaN
-                lo[j] = (half_t)(v[i + j] - back);
+            for (int j = 0; j < 8; j += 2) {
+                unsigned hp, lp;
+                split_pair(v[i + j], v[i + j + 1], hp, lp);
+                g2 = __builtin_elementwise_fma(__builtin_bit_cast(h2, hp), h2{(half_t)0.f, (half_t)0.f}, g2);
+                hu[j / 2] = hp; lu[j / 2] = lp;
             }
+            bad = __builtin_fmaf((float)g2[0] + (float)g2[1], 0.f, bad);
+            const half8 hi = __builtin_bit_cast(half8, hu), lo = __builtin_bit_cast(half8, lu);
             *reinterpret_cast<half8*>(p + i * 4 + (par ? 16 : 0)) = hi;
             *reinterpret_cast<half8*>(p + i * 4 + (par ? 0 : 16)) = lo;
         }
@@ -148,13 +155,15 @@ template <int N> struct OutVec<split_t, N> {
     // hold the same eight values share one store instruction (fused max-pool: both pixels of a pair hold the maximum).
     static __device__ __forceinline__ void store_half(split_t* dst, int ch0, const float* v, bool want_hi) {
         const int par = (ch0 >> 3) & 1;                  // even group: [hi, lo]; odd group: [lo, hi]
-        half8 o;
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        u4 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const half_t hi = (half_t)v[j];
-            o[j] = want_hi ? hi : (half_t)(v[j] - (float)hi);
+        for (int j = 0; j < 8; j += 2) {
+            unsigned hp, lp;
+            split_pair(v[j], v[j + 1], hp, lp);
+            o[j / 2] = want_hi ? hp : lp;
         }
-        *reinterpret_cast<half8*>(reinterpret_cast<char*>(dst) + ((want_hi ? par : par ^ 1) ? 16 : 0)) = o;
+        *reinterpret_cast<u4*>(reinterpret_cast<char*>(dst) + ((want_hi ? par : par ^ 1) ? 16 : 0)) = o;
     }
     static constexpr int kRawChunks = N / 4;
     static __device__ __forceinline__ void fetch(const split_t* src, f4* raw) {

@@ -285,18 +285,21 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(halo_wa
                 const int iy = ty * TH - 1 + hyu[u], ix = tx * 16 - 1 + hxu[u];
                 // unsigned compares: one test per coordinate, no short-circuit branches
                 const bool inside = ((unsigned)iy < (unsigned)(p.xHp - 2)) & ((unsigned)ix < (unsigned)(p.xWp - 2));
-                half8 hi8, lo8;
+                u4 hi8, lo8;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    float v = (j < 4 ? a0[u][j] : a1[u][j - 4]) * sc0[j] + sh0[j];
-                    v = inside ? __builtin_fmaxf(v, 0.f) : 0.f;
-                    hi8[j] = (half_t)v;
-                    lo8[j] = (half_t)(v - (float)hi8[j]);
+                for (int j = 0; j < 8; j += 2) {
+                    float v0 = (j < 4 ? a0[u][j] : a1[u][j - 4]) * sc0[j] + sh0[j];
+                    float v1 = (j < 4 ? a0[u][j + 1] : a1[u][j - 3]) * sc0[j + 1] + sh0[j + 1];
+                    v0 = inside ? __builtin_fmaxf(v0, 0.f) : 0.f;
+                    v1 = inside ? __builtin_fmaxf(v1, 0.f) : 0.f;
+                    unsigned hp, lp;
+                    split_pair(v0, v1, hp, lp);
+                    hi8[j / 2] = hp; lo8[j / 2] = lp;
                 }
                 if (hpu[u] < HR) {
                     char* row = halo + hpu[u] * 128;
-                    *reinterpret_cast<half8*>(row + (((2 * q + (q & 1)) ^ (hxu[u] & 7)) << 4)) = hi8;
-                    *reinterpret_cast<half8*>(row + (((2 * q + 1 - (q & 1)) ^ (hxu[u] & 7)) << 4)) = lo8;
+                    *reinterpret_cast<u4*>(row + (((2 * q + (q & 1)) ^ (hxu[u] & 7)) << 4)) = hi8;
+                    *reinterpret_cast<u4*>(row + (((2 * q + 1 - (q & 1)) ^ (hxu[u] & 7)) << 4)) = lo8;
                 }
             }
         }

@@ -31,6 +31,22 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
+// Split-f16 conversion of a PAIR of f32 values in three vector instructions: hi pair = v_cvt_pk_f16_f32(v0, v1); each lo =
+// f16(v - hi) as ONE mixed-precision FMA (v_fma_mixlo / mixhi_f16: fma(f16 hi, -1, f32 v) rounded to f16 -- v - hi is exact in f32,
+// so the single rounding equals the convert-back / subtract / convert chain the compiler emits for the C expression, which costs
+// ~3 more instructions per value; r03_tuning.md steps 20-21).  hp / lp = the packed f16 pairs (element 0 in the low half).
+__device__ __forceinline__ void split_pair(float v0, float v1, unsigned& hp, unsigned& lp) {
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    const h2_t h = {(_Float16)v0, (_Float16)v1};
+    hp = __builtin_bit_cast(unsigned, h);
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lp) : "v"(hp), "v"(v0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lp) : "v"(hp), "v"(v1));
+#else
+    lp = 0;                                           // host pass of the single-source compile: never executed
+#endif
+}
+
 struct TensorRef {            // a channel slice of a PHWC tensor
     void* base;               // address of padded element (n=0, y=-1, x=-1, c=0)
     void* base32;             // f16r engine only: the tensor's unrounded f32 twin (same geometry, float elements) or null --

@@ -61,11 +61,16 @@ template <> struct Grp<split_t> {              // [hi x8][lo x8] for even groups
         for (int j = 0; j < 8; ++j) v[j] = (float)hi[j] + (float)lo[j];
     }
     static __device__ __forceinline__ void store(char* p, int parity, const float* v) {
-        half8 hi, lo;
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        u4 hi, lo;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { hi[j] = (half_t)v[j]; lo[j] = (half_t)(v[j] - (float)hi[j]); }
-        *reinterpret_cast<half8*>(p + (parity ? 16 : 0)) = hi;
-        *reinterpret_cast<half8*>(p + (parity ? 0 : 16)) = lo;
+        for (int j = 0; j < 8; j += 2) {
+            unsigned hp, lp;
+            split_pair(v[j], v[j + 1], hp, lp);             // cv_kernels.h: three vector instructions per pair
+            hi[j / 2] = hp; lo[j / 2] = lp;
+        }
+        *reinterpret_cast<u4*>(p + (parity ? 16 : 0)) = hi;
+        *reinterpret_cast<u4*>(p + (parity ? 0 : 16)) = lo;
     }
     static __device__ __forceinline__ void store(char* p, int parity, const float* v, float& bad) {
 #pragma unroll
