@@ -131,13 +131,11 @@ def cpu_baseline(x_cpu, sq_cpu, gpu_logits, gpu_cls, e2e_images=None, budget_s: 
             ref = pipeline_ref.process_images(seg.eval(), resnet, e2e_images, fallback_quad=True)
             fens = []
             for k, r in enumerate(ref):
-                pos, ties = r.position, False
+                # byte work is bit-exact (round 4: OpenCV's order of operations on host, device and in the oracle): a device board
+                # that differs from the oracle's is REPORTED as a mismatch, never re-classified
                 dev = e2e_results[k].board_extraction.board_image if e2e_results is not None else None
-                if dev is not None and not (dev == r.board_extraction.board_image).all():
-                    # the oracle's independent warp may resolve 1/32-pixel coordinate ties the other way (tests/test_gpu_e2e.py):
-                    # the classifier stage is then checked on the board the device produced
-                    pos, ties = pipeline_ref.classify_board(resnet, dev), True
-                fens.append((pos.fen, pos.original_fen, pos.model_probabilities, ties))
+                same = dev is not None and dev.shape == r.board_extraction.board_image.shape and bool((dev == r.board_extraction.board_image).all())
+                fens.append((r.position.fen, r.position.original_fen, r.position.model_probabilities, not same))
         torch.set_num_threads(default_threads)
     base = {"value": round(done / dt, 3), "unit": "boards/sec", "cores": best, "kind": "port",
             "sample": f"{done} boards, reference-style loop (UNet b=1 + ResNet-18 b=64 per board), torch {torch.__version__} CPU fp32 "
@@ -548,7 +546,7 @@ def main():
                 mism = sum((r.position.fen, r.position.original_fen) != (f[0], f[1]) for r, f in zip(e2e_res, ref_fens))
                 perr = max(float(np.abs(r.position.model_probabilities - f[2]).max()) for r, f in zip(e2e_res, ref_fens))
                 e2e_block.update({"fen_checked": len(ref_fens), "fen_mismatches": mism, "prob_max_abs_err_vs_oracle": perr,
-                                  "boards_with_warp_coordinate_ties": sum(bool(f[3]) for f in ref_fens)})
+                                  "board_byte_mismatches_vs_oracle": sum(bool(f[3]) for f in ref_fens)})
             result["pipeline_e2e"] = e2e_block
     if world == 1 and not args.no_extras:
         # the other arithmetic types and the other checkpoint variant, XS steps after XW warm-ups each, with their own roofline and parity

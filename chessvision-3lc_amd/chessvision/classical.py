@@ -202,51 +202,87 @@ def approx_poly_dp(contour: NDArray[np.int32], epsilon: float) -> NDArray[np.int
 
 
 # ---- perspective (cv2.getPerspectiveTransform + cv2.warpPerspective, utils.py:131-132) -----------------
+# The last bit of the matrices decides which way a source coordinate that is an exact .5 tie in 1/32 pixels rounds, so these three
+# functions follow the arithmetic OpenCV 4.x publishes operation by operation (IEEE double, no fused multiply-add); the native
+# product path (csrc/homography.cpp, csrc/pipeline.hip) and the independent oracle (oracle/classical_ref.py) do the same and the
+# tests require all of them to agree bit for bit.
 def get_perspective_transform(src: NDArray[np.float32], dst: NDArray[np.float32]) -> NDArray[np.float64]:
-    """3x3 homography mapping the four ``src`` points onto ``dst`` (h33 = 1)."""
-    src = np.asarray(src, dtype=np.float64).reshape(4, 2)
-    dst = np.asarray(dst, dtype=np.float64).reshape(4, 2)
-    a = np.zeros((8, 8))
-    b = np.zeros(8)
-    for i, ((x, y), (u, v)) in enumerate(zip(src, dst)):
-        a[i] = [x, y, 1, 0, 0, 0, -x * u, -y * u]
-        a[i + 4] = [0, 0, 0, x, y, 1, -x * v, -y * v]
-        b[i], b[i + 4] = u, v
-    h = np.linalg.solve(a, b)
-    return np.append(h, 1.0).reshape(3, 3)
+    """3x3 homography mapping the four ``src`` points onto ``dst`` (h33 = 1), as cv2.getPerspectiveTransform computes it: rows i
+    and i + 4 of an 8x8 system (the -x*u products in float32: Point2f operands), ``solve(.., DECOMP_LU)`` = OpenCV's own LUImpl at
+    this size -- partial pivoting on the first largest magnitude, ``alpha = A[j][i] * (-1 / A[i][i])``, back substitution
+    ``s -= A[i][k] * x[k]``, ``x[i] = s / A[i][i]``.  Degenerate points give the zero matrix."""
+    s4 = np.asarray(src, dtype=np.float32).reshape(4, 2)
+    d4 = np.asarray(dst, dtype=np.float32).reshape(4, 2)
+    x, y, u, v = s4[:, 0], s4[:, 1], d4[:, 0], d4[:, 1]
+    a = np.zeros((8, 8), dtype=np.float64)
+    b = np.concatenate([u, v]).astype(np.float64)
+    a[:4, 0] = a[4:, 3] = x
+    a[:4, 1] = a[4:, 4] = y
+    a[:4, 2] = a[4:, 5] = 1.0
+    a[:4, 6], a[:4, 7], a[4:, 6], a[4:, 7] = -x * u, -y * u, -x * v, -y * v        # float32 products, widened on assignment
+    for i in range(8):
+        k = i + int(np.argmax(np.abs(a[i:, i])))                                   # argmax keeps the FIRST maximum, as `>` does
+        if abs(a[k, i]) < np.finfo(np.float64).eps * 100:
+            return np.zeros((3, 3), dtype=np.float64)
+        if k != i:
+            a[[i, k], i:] = a[[k, i], i:]
+            b[[i, k]] = b[[k, i]]
+        d = -1.0 / a[i, i]
+        alpha = a[i + 1:, i] * d
+        a[i + 1:, i + 1:] += alpha[:, None] * a[i, i + 1:][None, :]
+        b[i + 1:] += alpha * b[i]
+    for i in range(7, -1, -1):
+        acc = b[i]
+        for k in range(i + 1, 8):
+            acc -= a[i, k] * b[k]
+        b[i] = acc / a[i, i]
+    return np.append(b, 1.0).reshape(3, 3)
 
 
 def get_perspective_transforms(src: NDArray[np.float32], dst: NDArray[np.float32]) -> NDArray[np.float64]:
-    """``get_perspective_transform`` for N quadrangles at once: src (N,4,2) -> (N,3,3).  One batched LAPACK solve of the
-    same 8x8 systems, so every matrix equals the per-quadrangle result bit for bit."""
-    src = np.asarray(src, dtype=np.float64).reshape(-1, 4, 2)
-    dst = np.asarray(dst, dtype=np.float64).reshape(4, 2)
-    n = src.shape[0]
-    x, y = src[:, :, 0], src[:, :, 1]
-    u, v = dst[None, :, 0], dst[None, :, 1]
-    one, zero = np.ones_like(x), np.zeros_like(x)
-    a = np.empty((n, 8, 8))
-    a[:, :4] = np.stack([x, y, one, zero, zero, zero, -x * u, -y * u], axis=-1)
-    a[:, 4:] = np.stack([zero, zero, zero, x, y, one, -x * v, -y * v], axis=-1)
-    b = np.concatenate([np.broadcast_to(u, (n, 4)), np.broadcast_to(v, (n, 4))], axis=1)
-    h = np.linalg.solve(a, b[..., None])[..., 0]
-    return np.concatenate([h, np.ones((n, 1))], axis=1).reshape(n, 3, 3)
+    """``get_perspective_transform`` for N quadrangles: src (N,4,2) -> (N,3,3) (the batched pipeline uses the native
+    ``hip_backend.board_homographies`` instead; this is its readable checker)."""
+    src = np.asarray(src, dtype=np.float32).reshape(-1, 4, 2)
+    return np.stack([get_perspective_transform(q, dst) for q in src]) if len(src) else np.zeros((0, 3, 3))
+
+
+def invert3(m: NDArray[np.float64]) -> NDArray[np.float64]:
+    """cv::invert of a 3x3 double matrix (what cv2.warpPerspective applies to its argument): cofactors times the reciprocal of the
+    determinant expanded along the first row; zeros when the determinant is 0."""
+    (a, b, c), (d, e, f), (g, h, i) = np.asarray(m, dtype=np.float64).tolist()
+    det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g)
+    if det == 0.0:
+        return np.zeros((3, 3), dtype=np.float64)
+    r = 1.0 / det
+    return np.array([[(e * i - f * h) * r, (c * h - b * i) * r, (b * f - c * e) * r],
+                     [(f * g - d * i) * r, (a * i - c * g) * r, (c * d - a * f) * r],
+                     [(d * h - e * g) * r, (b * g - a * h) * r, (a * e - b * d) * r]], dtype=np.float64)
 
 
 def warp_perspective(image: NDArray[np.uint8], m: NDArray[np.float64], size: tuple[int, int]) -> NDArray[np.uint8]:
     """cv2.warpPerspective(image, M, size) with its defaults (INTER_LINEAR, BORDER_CONSTANT 0) in OpenCV's fixed-point form
-    (``imgwarp.cpp``): source coordinates in 1/32 pixel (``INTER_BITS = 5``: X = round(X0 * (32 / W0))), integer bilinear weights
-    (32-a)(32-b)*32 ... a*b*32 that sum to 2^15 (``INTER_REMAP_COEF_BITS``), pixel = (sum + 2^14) >> 15, i.e. round half UP.
-    (Rounds 1-2 of this package blended in floating point and rounded ties to even: one grey level apart on ~0.5 % of the pixels.)"""
+    (``imgwarp.cpp``: WarpPerspectiveInvoker + remapBilinear).  The destination is walked in blocks of min(128, w) columns; with
+    ``blk`` the block's first column and ``x1`` the column inside it: X0 = M0*blk + M1*y + M2, W = W0 + M6*x1, W = 32 / W (0 if
+    W == 0), X = round_half_even(clamp((X0 + M0*x1) * W)) -- source coordinates in 1/32 pixel (``INTER_BITS = 5``); the integer
+    pixel X >> 5 saturates to int16; integer bilinear weights (32-a)(32-b)*32 ... a*b*32 that sum to 2^15
+    (``INTER_REMAP_COEF_BITS``), pixel = (sum + 2^14) >> 15, i.e. round half UP; taps outside the image read 0."""
     w_out, h_out = size
-    inv = np.linalg.inv(m)
-    xs, ys = np.meshgrid(np.arange(w_out, dtype=np.float64), np.arange(h_out, dtype=np.float64))
-    den = inv[2, 0] * xs + inv[2, 1] * ys + inv[2, 2]
-    scale = np.divide(32.0, den, out=np.zeros_like(den), where=den != 0)
-    lim = (-2.0 ** 31, 2.0 ** 31 - 1)
-    xi = np.rint(np.clip((inv[0, 0] * xs + inv[0, 1] * ys + inv[0, 2]) * scale, *lim)).astype(np.int64)
-    yi = np.rint(np.clip((inv[1, 0] * xs + inv[1, 1] * ys + inv[1, 2]) * scale, *lim)).astype(np.int64)
-    x0, y0 = xi >> 5, yi >> 5
+    inv = invert3(m)
+    bw = min(128, w_out)
+    cols = np.arange(w_out)
+    blk = ((cols // bw) * bw).astype(np.float64)[None, :]
+    x1 = (cols % bw).astype(np.float64)[None, :]
+    ys = np.arange(h_out, dtype=np.float64)[:, None]
+    with np.errstate(all="ignore"):
+        x0 = (inv[0, 0] * blk + inv[0, 1] * ys) + inv[0, 2]
+        y0 = (inv[1, 0] * blk + inv[1, 1] * ys) + inv[1, 2]
+        w0 = (inv[2, 0] * blk + inv[2, 1] * ys) + inv[2, 2]
+        den = w0 + inv[2, 0] * x1
+        scale = np.divide(32.0, den, out=np.zeros_like(den), where=den != 0)
+        lim = (-2.0 ** 31, 2.0 ** 31 - 1)
+        xi = np.rint(np.clip((x0 + inv[0, 0] * x1) * scale, *lim)).astype(np.int64)
+        yi = np.rint(np.clip((y0 + inv[1, 0] * x1) * scale, *lim)).astype(np.int64)
+    px, py = np.clip(xi >> 5, -32768, 32767), np.clip(yi >> 5, -32768, 32767)
     ax, ay = (xi & 31)[..., None], (yi & 31)[..., None]
     img = image if image.ndim == 3 else image[:, :, None]
     h, w, c = img.shape
@@ -257,8 +293,8 @@ def warp_perspective(image: NDArray[np.uint8], m: NDArray[np.float64], size: tup
         ok = (yy >= -1) & (yy <= h) & (xx >= -1) & (xx <= w)                    # the zero frame itself is "outside"
         return padded[np.clip(yy + 1, 0, h + 1), np.clip(xx + 1, 0, w + 1)] * ok[..., None]
 
-    acc = ((32 - ax) * (32 - ay) * 32 * tap(y0, x0) + ax * (32 - ay) * 32 * tap(y0, x0 + 1) +
-           (32 - ax) * ay * 32 * tap(y0 + 1, x0) + ax * ay * 32 * tap(y0 + 1, x0 + 1))
+    acc = ((32 - ax) * (32 - ay) * 32 * tap(py, px) + ax * (32 - ay) * 32 * tap(py, px + 1) +
+           (32 - ax) * ay * 32 * tap(py + 1, px) + ax * ay * 32 * tap(py + 1, px + 1))
     out = ((acc + (1 << 14)) >> 15).astype(np.uint8)
     return out if image.ndim == 3 else out[:, :, 0]
 

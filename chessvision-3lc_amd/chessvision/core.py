@@ -3,8 +3,15 @@
 Mirrors the public surface of the reference's ``chessvision/core.py`` (constructor kwargs, attributes read by
 ``scripts/eval/evaluate.py:357-358`` and ``tests/test_chessvision.py:29-42``, the two model properties, the three
 pipeline methods and the static helpers) so the Flask endpoint and the evaluation script run unchanged.  The
-model objects behind ``board_extractor`` / ``classifier`` are ``HipBoardExtractor`` / ``HipPieceClassifier``;
-the classical stages in between run on the host (``classical.py``) exactly where the reference runs OpenCV.
+model objects behind ``board_extractor`` / ``classifier`` are ``HipBoardExtractor`` / ``HipPieceClassifier``.
+
+``process_image`` / ``predict`` / ``extract_board`` / ``classify_position`` -- the API the reference's callers use
+(``app/computeroot/cv_endpoint.py:159``, ``scripts/eval/evaluate.py:270``) -- run the SAME native stages as the batched
+``process_images``: device INTER_AREA resize -> ``cv_unet_forward_u8`` (sigmoid / threshold mask on device) -> C++ contours
+(``cv_find_quadrangle``) -> OpenCV-order homography (``cv_board_homographies``) -> fused device warp + gray + flip + split
+(``cv_extract_squares_u8_dev``) -> ``cv_resnet18_forward_u8`` (soft-max on device) -> ``cv_decode_positions``.  The numpy
+restatements in ``classical.py`` and the static helpers below remain as the readable checker (and serve model objects that are
+not HIP models, e.g. a test double plugged into ``_board_extractor``).
 
 Deliberate deviations, all on the permissive side:
   * ``board_extractor_weights=None`` resolves to ``constants.BEST_EXTRACTOR_WEIGHTS`` at load time (the reference
@@ -36,6 +43,7 @@ logger = logging.getLogger(__name__)
 
 _UNET_IDS = (None, "", "unet", "hip")
 _RESNET_IDS = ("", "resnet18", "hip")
+_PRECISION_NAMES = ("f16x3", "split", "f32", "fp32", "float32", "f16", "fp16", "float16", "f16r")
 
 
 class ChessVision:
@@ -59,11 +67,16 @@ class ChessVision:
         self._classifier_weights = classifier_weights
         self._classifier_model_id = classifier_model_id
         self._precision = precision or os.environ.get("CHESSVISION_HIP_PRECISION", "f16x3")
-        self._engine = None
+        parts = self._precision.split("+")
+        if not 1 <= len(parts) <= 2 or any(p not in _PRECISION_NAMES for p in parts):
+            raise ValueError(f"precision must be one of {sorted(_PRECISION_NAMES)} or '<extractor>+<classifier>', got {self._precision!r}")
         self._engines: dict = {}
         self._streams = None
         self._copy_pool = None
         self._init_lock = threading.RLock()
+        self._native_lock = threading.Lock()            # the single-image path shares its staging buffers between request threads
+        self._stage: dict = {}
+        self._last_board = None                         # (board array of the last native extraction, its squares on the device)
         if not lazy_load:
             logger.info("Eager loading models...")
             self._initialize_board_extractor()
@@ -81,8 +94,6 @@ class ChessVision:
         with self._init_lock:
             if prec not in self._engines:
                 self._engines[prec] = HipEngine(self.device, precision=prec)
-            if self._engine is None:
-                self._engine = self._engines[parts[0]]
         return self._engines[prec]
 
     @property
@@ -139,7 +150,7 @@ class ChessVision:
 
     # ---- pipeline -----------------------------------------------------------------------------------
     def process_image(self, image: NDArray[np.uint8], threshold: float = 0.5, flip: bool = False) -> ChessVisionResult:
-        """Raw BGR image -> board extraction -> (if a board was found) position."""
+        """Raw BGR image -> board extraction -> (if a board was found) position (reference core.py:152-195)."""
         assert isinstance(image, np.ndarray), "Image must be a numpy array"
         assert image.dtype == np.uint8, "Image must be uint8"
         assert len(image.shape) == 3, "Image must be 3-dimensional (H,W,C)"
@@ -159,25 +170,116 @@ class ChessVision:
 
     predict = process_image                                  # name used by BASELINE.json's north_star
 
+    def _native(self, model) -> bool:
+        from .hip_backend import _HipModel
+        return isinstance(model, _HipModel)
+
     def extract_board(self, image: NDArray[np.uint8], threshold: float = 0.5) -> BoardExtractionResult:
+        """Reference core.py:197-223 + 252-307.  With the HIP extractor plugged in every stage runs natively (see the module
+        docstring); any other model object gets the reference's literal tensor path and the numpy stages."""
+        model = self.board_extractor
+        if self._native(model) and image.ndim == 3 and image.shape[2] == 3 and image.dtype == np.uint8:
+            return self._extract_board_native(model.engine, image, threshold)
         comp_image = classical.resize_area(image, constants.INPUT_SIZE)
         batch = torch.Tensor(np.array([comp_image])) / 255           # (1,256,256,3) float32, channels as given
         batch = batch.permute(0, 3, 1, 2).to(self.device)
         with torch.no_grad():
-            logits = self.board_extractor(batch)[0].squeeze().cpu().numpy()
+            logits = model(batch)[0].squeeze().cpu().numpy()
         return self.process_board_extraction_logits(logits, image, threshold)
 
     def classify_position(self, board_image: NDArray[np.uint8], flip: bool = False) -> PositionResult:
+        """Reference core.py:225-249 + 309-355."""
+        model = self.classifier
+        if self._native(model) and board_image.dtype == np.uint8 and board_image.shape == (constants.BOARD_SIZE[1], constants.BOARD_SIZE[0]):
+            return self._classify_position_native(model.engine, board_image, flip)
         squares = self.extract_squares(board_image)
         square_names = constants.SQUARE_NAMES_FLIPPED if flip else constants.SQUARE_NAMES_NORMAL
         batch = torch.Tensor(squares).permute(0, 3, 1, 2).to(self.device)
         batch /= 255.0
         with torch.no_grad():
-            predictions = self.classifier(batch)
+            predictions = model(batch)
             probabilities = torch.softmax(predictions, dim=1)
             probabilities_np = probabilities.detach().cpu().numpy()
         return self.process_position_probabilities(probabilities=probabilities_np, square_names=square_names,
                                                    square_crops=squares)
+
+    # ---- the native single-image path -----------------------------------------------------------------
+    def _staging(self, shape=None):
+        """Page-locked staging buffers of the single-image path: mask, logits, board, squares, probabilities, homography (shared),
+        and one image buffer per image shape seen (a server sees few distinct camera formats)."""
+        st = self._stage.get("common")
+        pin = lambda s, d: torch.empty(s, dtype=d, pin_memory=True)          # noqa: E731
+        if st is None:
+            st = self._stage["common"] = {
+                "mask": pin((256, 256), torch.uint8), "logits": pin((256, 256), torch.float32),
+                "board": pin((constants.BOARD_SIZE[1], constants.BOARD_SIZE[0]), torch.uint8),
+                "probs": pin((64, constants.NUM_CLASSES), torch.float32), "inv": pin((1, 9), torch.float64),
+                "squares": pin((64, 64, 64), torch.uint8), "images": {}}
+        if shape is not None and shape not in st["images"]:
+            if len(st["images"]) >= 4:
+                st["images"].clear()
+            st["images"][shape] = pin(shape, torch.uint8)
+        return st
+
+    def _extract_board_native(self, eng, image: NDArray[np.uint8], threshold: float, fallback_quad: bool = False) -> BoardExtractionResult:
+        from .hip_backend import board_homographies, find_quadrangle
+
+        dev = self.device
+        with self._native_lock, torch.no_grad():
+            st = self._staging(tuple(image.shape))
+            staged = st["images"][tuple(image.shape)]
+            np.copyto(staged.numpy(), image)
+            img_dev = staged.to(dev, non_blocking=True)[None]
+            small = eng.resize_area_u8(img_dev, (constants.INPUT_SIZE[1], constants.INPUT_SIZE[0]))
+            logits_dev, mask_dev = eng.unet_forward_u8(small, threshold=threshold, want_mask=True)
+            st["mask"].copy_(mask_dev[0], non_blocking=True)                 # the contour stage waits for the mask only
+            have_mask = torch.cuda.Event()
+            have_mask.record()
+            st["logits"].copy_(logits_dev[0, 0], non_blocking=True)
+            have_mask.synchronize()
+            binary_mask = st["mask"].numpy().copy()
+            quadrangle = find_quadrangle(binary_mask)
+            if quadrangle is None and fallback_quad:
+                quadrangle = np.array([[[255, 0]], [[0, 0]], [[0, 255]], [[255, 255]]], dtype=np.int32)   # TR, TL, BL, BR
+            if quadrangle is None:
+                logger.info("Failed to extract board from image")
+                eng.check_numerics()                                          # synchronises: the logits have landed
+                return BoardExtractionResult(board_image=None, binary_mask=binary_mask, quadrangle=None,
+                                             probabilities=st["logits"].numpy().copy())
+            scaled = self._scale_quadrangle(quadrangle, (image.shape[0], image.shape[1]))
+            st["inv"].numpy()[:] = board_homographies(scaled.reshape(1, 4, 2), constants.BOARD_SIZE).reshape(1, 9)
+            squares_dev, board_dev = eng.extract_squares_u8(img_dev, st["inv"])
+            st["board"].copy_(board_dev[0], non_blocking=True)
+            eng.check_numerics()                                              # synchronises the stream: logits and board have landed
+            board = st["board"].numpy().copy()
+            self._last_board = (board, squares_dev)                           # process_image classifies exactly this board next
+            return BoardExtractionResult(board_image=board, binary_mask=binary_mask, quadrangle=scaled,
+                                         probabilities=st["logits"].numpy().copy())
+
+    def _classify_position_native(self, eng, board_image: NDArray[np.uint8], flip: bool) -> PositionResult:
+        from .hip_backend import decode_positions
+
+        names = constants.SQUARE_NAMES_FLIPPED if flip else constants.SQUARE_NAMES_NORMAL
+        squares = self.extract_squares(board_image)
+        with self._native_lock, torch.no_grad():
+            last = self._last_board
+            if last is not None and last[0] is board_image:                   # the board this instance just rectified: its squares
+                squares_dev = last[1]                                         # are still on the device
+            else:
+                st = self._staging()
+                np.copyto(st["squares"].numpy(), squares[..., 0])
+                squares_dev = st["squares"].to(self.device, non_blocking=True)
+            self._last_board = None
+            probs_dev = eng.resnet18_forward_u8(squares_dev)
+            st = self._staging()
+            st["probs"].copy_(probs_dev, non_blocking=True)
+            eng.check_numerics()                                              # synchronises
+            probs = st["probs"].numpy().copy()
+        fens, origs, _, fixes = decode_positions(probs[None], flip)
+        fix_list = [ValidationFix(square_name=names[sq], original_piece=constants.LABEL_NAMES[old],
+                                  corrected_piece=constants.LABEL_NAMES[new], rule_name="no_pawns_on_ends") for _, sq, old, new in fixes]
+        return PositionResult(fen=fens[0], original_fen=origs[0], model_probabilities=probs, squares=squares, square_names=names,
+                              validation_fixes=fix_list)
 
     def process_images(self, images: Sequence[NDArray[np.uint8]], threshold: float = 0.5, flip: bool = False,
                        fallback_quad: bool = False, pipeline_chunk: int = 64, return_crops: bool = True,
@@ -209,7 +311,7 @@ class ChessVision:
         from concurrent.futures import ThreadPoolExecutor
 
         from .distributed import host_threads
-        from .hip_backend import decode_positions, find_quadrangles
+        from .hip_backend import board_homographies, decode_positions, find_quadrangles
 
         n_host = host_threads()
 
@@ -218,7 +320,6 @@ class ChessVision:
         n = len(images)
         names = constants.SQUARE_NAMES_FLIPPED if flip else constants.SQUARE_NAMES_NORMAL
         w, h = constants.BOARD_SIZE
-        dest = np.array(((0, 0), (w, 0), (w, h), (0, h)), np.float32)
         groups: dict[tuple, list[int]] = {}
         for i, im in enumerate(images):
             groups.setdefault(im.shape, []).append(i)
@@ -323,7 +424,7 @@ class ChessVision:
             found = [k for k in range(len(ids)) if quads[k] is not None]
             st["found"] = found
             if found:
-                inv = np.linalg.inv(classical.get_perspective_transforms(np.stack([quads[k].reshape(4, 2) for k in found]), dest))
+                inv = board_homographies(np.stack([quads[k].reshape(4, 2) for k in found]), constants.BOARD_SIZE)
                 clock("homography_s", t0)
                 src = st["batch"] if len(found) == len(ids) else st["batch"][torch.as_tensor(found, device=dev)]
                 squares_dev, boards_dev = gpu_timed("warp_ms", lambda: eng.extract_squares_u8(src, inv))

@@ -88,6 +88,7 @@ SYMBOLS = [
     ("cv_get_activation_exponent", _i, [_vp, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(_i)]),
     ("cv_profile_entry_bytes", _i, [_vp, _i, ctypes.POINTER(ctypes.c_double)]),
     ("cv_profile_entry_kernel", _i, [_vp, _i, ctypes.c_char_p, _i]),
+    ("cv_board_homographies", _i, [_fp, _i, _i, _i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     ("cv_decode_positions", _i, [_fp, _i, _i, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int8),
                                  ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
 ]
@@ -184,6 +185,23 @@ def find_quadrangles(masks: np.ndarray, n_threads: int = 0) -> list:
                                        quads.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
                                        found.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), int(n_threads)))
     return [quads[i].reshape(4, 1, 2).copy() if found[i] else None for i in range(n)]
+
+
+def board_homographies(quads: np.ndarray, out_size=(512, 512), want_forward: bool = False):
+    """(N,4,2) float32 quadrangles (source-image pixels, the reference's TR, TL, BL, BR order) -> (N,3,3) float64 INVERSE
+    matrices (board pixel -> source pixel) of the warp ``utils.extract_perspective`` performs (reference utils.py:115-132), computed
+    in OpenCV's order of operations by csrc/homography.cpp; with ``want_forward`` also the getPerspectiveTransform matrices.
+    Bit-identical to ``classical.invert3(classical.get_perspective_transform(q, dest))``.  Needs neither a GPU nor an engine."""
+    lib = load_library()
+    q = np.ascontiguousarray(quads, dtype=np.float32).reshape(-1, 8)
+    n = q.shape[0]
+    inv = np.zeros((n, 3, 3), dtype=np.float64)
+    fwd = np.zeros((n, 3, 3), dtype=np.float64) if want_forward else None
+    dp = ctypes.POINTER(ctypes.c_double)
+    if n:
+        _check(lib.cv_board_homographies(q.ctypes.data_as(_fp), n, int(out_size[0]), int(out_size[1]),
+                                         fwd.ctypes.data_as(dp) if want_forward else None, inv.ctypes.data_as(dp)))
+    return (inv, fwd) if want_forward else inv
 
 
 def decode_positions(probabilities: np.ndarray, flip: bool = False):
@@ -351,7 +369,12 @@ class HipEngine:
         n, h, w, _ = images.shape
         # the matrices travel through a pinned staging tensor on the current stream; nothing here blocks the host, so the
         # next job's UNet (already queued on this stream) does not hold the classifier of this job back
-        inv = torch.from_numpy(np.ascontiguousarray(inverse_maps, dtype=np.float64).reshape(n, 9)).pin_memory()
+        if isinstance(inverse_maps, torch.Tensor):           # already staged by the caller (page-locked, float64, n x 9)
+            if inverse_maps.dtype != torch.float64 or inverse_maps.numel() != n * 9:
+                raise HipBackendError("extract_squares_u8 expects n x 9 float64 matrices")
+            inv = inverse_maps
+        else:
+            inv = torch.from_numpy(np.ascontiguousarray(inverse_maps, dtype=np.float64).reshape(n, 9)).pin_memory()
         inv_dev = inv.to(self.device, non_blocking=True)
         squares = torch.empty((n * 64, 64, 64), dtype=torch.uint8, device=self.device)
         boards = torch.empty((n, 512, 512), dtype=torch.uint8, device=self.device) if want_boards else None

@@ -56,13 +56,25 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvParams p)
     const unsigned nwg = gridDim.x, bid = blockIdx.x;
     const unsigned xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
     const unsigned lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
-    const int ctTile = lid % p.nCt;
-    const int ptTile = lid / p.nCt;
-    const int nS = p.nStages;
+    // split-K launches: the pixel tiles of one (channel tile, K split) are neighbours -- they stream the SAME weight slab (the large
+    // operand of the deep layers these launches serve) and, after the XCD remap above, through the same L2
+    int ctTile, ptTile, sBase = 0, nS = p.nStages;
+    if (p.ksplit > 1) {
+        const int nPt = (p.M + PT - 1) / PT;
+        ptTile = lid % nPt;
+        const int t = lid / nPt;
+        ctTile = t % p.nCt;
+        const int ks = t / p.nCt;
+        sBase = ks * p.kper;
+        nS = min(p.kper, p.nStages - sBase);
+    } else {
+        ctTile = lid % p.nCt;
+        ptTile = lid / p.nCt;
+    }
     const int HoWo = p.Ho * p.Wo;
 
     if constexpr (!SEP)
-        for (int i = tid; i < nS * 8; i += 64 * NW) koffs[i] = p.koff[i];
+        for (int i = tid; i < nS * 8; i += 64 * NW) koffs[i] = p.koff[sBase * 8 + i];
 
     // DMA source of this lane's activation rows: row r of the pixel tile <-> output pixel ptTile*PT + r
     unsigned xoff[LX];
@@ -78,7 +90,7 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvParams p)
                   (unsigned)sizeof(T);
     }
     const int myChunk = (lane & 7) ^ (lane >> 3);      // logical K chunk this lane fetches (swizzled)
-    const char* wsrc = p.w + (size_t)ctTile * nS * (CT * 128) + wave * 1024 + lane * 16;
+    const char* wsrc = p.w + ((size_t)ctTile * p.nStages + sBase) * (CT * 128) + wave * 1024 + lane * 16;
     __syncthreads();                                    // koffs visible
 
     auto issue = [&](int s, int buf) {
@@ -92,7 +104,7 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvParams p)
             // constant address space => s_load through the scalar cache (a VGPR load here would make the compiler
             // drain vmcnt, i.e. the whole DMA ring, every stage)
             typedef const __attribute__((address_space(4))) int* cptr_t;
-            ko = reinterpret_cast<cptr_t>(reinterpret_cast<uintptr_t>(p.kbase))[s] + myChunk * 16;
+            ko = reinterpret_cast<cptr_t>(reinterpret_cast<uintptr_t>(p.kbase))[sBase + s] + myChunk * 16;
         } else {
             ko = koffs[s * 8 + myChunk];
         }
@@ -269,6 +281,20 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvParams p)
     // ---- epilogue: BN affine (+ residual) (+ ReLU), convert, 16-B NHWC stores -------------------------
     constexpr int NV = 4 * FC;                          // consecutive channels held by this lane
     const int row0 = ctTile * CT + wci * WCT + q * NV;  // first GEMM row (== channel, by host permutation)
+    if (p.ksplit > 1) {
+        // split-K: raw accumulators -> partial[split][pixel][channel]; a lane's 16 channels are 64 contiguous bytes, the four
+        // lane groups of a pixel cover 256.  conv_splitk_reduce_kernel finishes the layer.
+        float* const part = p.partial + (size_t)(sBase / p.kper) * p.M * p.prow + row0;
+#pragma unroll
+        for (int g = 0; g < FP; ++g) {
+            const int pix = ptTile * PT + wpi * WPT + g * 16 + l15;
+            if (pix < p.M) {
+#pragma unroll
+                for (int f = 0; f < FC; ++f) *reinterpret_cast<f4*>(part + (size_t)pix * p.prow + f * 4) = acc[f][g];
+            }
+        }
+        return;
+    }
     float sc[NV], sh[NV];
 #pragma unroll
     for (int i = 0; i < NV; i += 4) {
@@ -398,14 +424,83 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvParams p)
     report_bad(p, bad);
 }
 
+// ---- split-K second pass: sum the splits in order, then the same epilogue as above -----------------------------------
+// One lane = 8 consecutive channels of one output pixel (one 16 / 32-byte store unit).  Deterministic: the summation order is the
+// split index, whatever order the first pass's workgroups finished in.
+template <typename T>
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParams p) {
+    constexpr int UN = 8;
+    const int upp = p.rows / UN;                          // units per pixel (rows is a multiple of 16)
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)p.M * upp) return;
+    const int pix = (int)(idx / upp), cu = (int)(idx - (long long)pix * upp);
+    const int row = cu * UN;
+    float w[UN];
+    {
+        const float* src = p.partial + (size_t)pix * p.prow + row;
+        const size_t sstride = (size_t)p.M * p.prow;
+        f4 a = *reinterpret_cast<const f4*>(src), b = *reinterpret_cast<const f4*>(src + 4);
+        for (int ks = 1; ks < p.ksplit; ++ks) {
+            a += *reinterpret_cast<const f4*>(src + ks * sstride);
+            b += *reinterpret_cast<const f4*>(src + ks * sstride + 4);
+        }
+        const f4 sa = *reinterpret_cast<const f4*>(p.scale + row), sb = *reinterpret_cast<const f4*>(p.scale + row + 4);
+        const f4 ha = *reinterpret_cast<const f4*>(p.shift + row), hb = *reinterpret_cast<const f4*>(p.shift + row + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { w[j] = a[j] * sa[j] + ha[j]; w[4 + j] = b[j] * sb[j] + hb[j]; }
+    }
+    const int HoWo = p.Ho * p.Wo;
+    const int n = pix / HoWo;
+    const int rem = pix - n * HoWo;
+    const int oy = rem / p.Wo;
+    const int ox = rem - oy * p.Wo;
+    unsigned ob = p.shuffle ? (unsigned)((n * p.yHp + 2 * oy + 1) * p.yWp + 2 * ox + 1) : (unsigned)((n * p.yHp + oy + 1) * p.yWp + ox + 1);
+    int co = row;
+    if (p.shuffle) {                                     // rows are (dy, dx, co): k2 s2 transposed conv
+        const int grp = row / p.Cout;
+        co = row - grp * p.Cout;
+        ob += (unsigned)((grp >> 1) * p.yWp + (grp & 1));
+    }
+    T* const ybase = reinterpret_cast<T*>(p.y);
+    const T* const rbase = reinterpret_cast<const T*>(p.res);
+    if (rbase) {
+        bool done = false;
+        if constexpr (__is_same(T, half_t)) {
+            if (p.res_f32) {
+                f4 raw[2];
+                trunk32_fetch(reinterpret_cast<const float*>(p.res) + (size_t)ob * p.rCs + p.rCoff + co, raw);
+                trunk32_add_raw(raw, w, p.res_mul);
+                done = true;
+            }
+        }
+        if (!done) OutVec<T, UN>::add(rbase + (size_t)ob * p.rCs + p.rCoff + co, p.rCoff + co, w, p.res_mul);
+    }
+    if (p.relu) {
+#pragma unroll
+        for (int j = 0; j < UN; ++j) w[j] = w[j] > 0.f ? w[j] : 0.f;
+    }
+    float bad = 0.f;
+    OutVec<T, UN>::store(ybase + (size_t)ob * p.yCs + p.yCoff + co, p.yCoff + co, w, bad);
+    if constexpr (__is_same(T, half_t)) {
+        if (p.y32) trunk32_store(reinterpret_cast<float*>(p.y32) + (size_t)ob * p.yCs + p.yCoff + co, w);
+    }
+    report_bad(p, bad);
+}
+
 // ---- host-side launch -------------------------------------------------------------------------------
 template <typename T, int CT, int PT, int WGC, int NS, int NW, bool SEP>
 static hipError_t launch_one(const ConvParams& p, hipStream_t stream) {
-    const size_t lds = (size_t)NS * (CT + PT) * 128 + (SEP ? 0 : (((size_t)p.nStages * 8 * 4 + 15) & ~(size_t)15));
+    const int stages = p.ksplit > 1 ? p.kper : p.nStages;    // the offset table in LDS covers one split only
+    const size_t lds = (size_t)NS * (CT + PT) * 128 + (SEP ? 0 : (((size_t)stages * 8 * 4 + 15) & ~(size_t)15));
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const int nPt = (p.M + PT - 1) / PT;
+    const int splits = p.ksplit > 1 ? p.ksplit : 1;
     auto kern = conv_igemm_kernel<T, CT, PT, WGC, NS, NW, SEP>;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(nPt * p.nCt)), dim3(64 * NW), lds, stream, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nPt * p.nCt * splits)), dim3(64 * NW), lds, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || splits == 1) return e;
+    const long long units = (long long)p.M * (p.rows / 8);
+    hipLaunchKernelGGL(conv_splitk_reduce_kernel<T>, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 

@@ -19,6 +19,7 @@ bool find_quadrangle(const uint8_t* mask, int h, int w, int32_t quad[8]);
 hipError_t resize_area_u8(const uint8_t* src, int n, int h, int w, int c, uint8_t* dst, int oh, int ow, hipStream_t s);
 hipError_t extract_squares_u8(const uint8_t* images, int n, int h, int w, const double* inv, uint8_t* squares,
                               uint8_t* boards, hipStream_t s);
+void board_homographies(const float* quads, int n, int out_w, int out_h, double* forward, double* inverse);
 }  // namespace cv
 
 using namespace cv;
@@ -61,9 +62,11 @@ Status to_map(const cv_param_t* params, int n, ParamMap& pm) {
     if (n < 0 || (n > 0 && !params)) return fail(CV_ERR_INVALID, "null parameter table");
     for (int i = 0; i < n; ++i) {
         const cv_param_t& p = params[i];
-        if (!p.name || !p.data || p.ndim < 0 || p.ndim > 4) return fail(CV_ERR_INVALID, "malformed cv_param_t entry " + std::to_string(i));
+        if (!p.name) return fail(CV_ERR_INVALID, "malformed cv_param_t entry " + std::to_string(i) + " (null name)");
         const size_t nl = std::strlen(p.name);
         if (nl >= 19 && std::strcmp(p.name + nl - 19, "num_batches_tracked") == 0) continue;   // a full torch state dict may carry them
+                                                                                              // (int64 scalars: data / shape are not looked at)
+        if (!p.data || p.ndim < 0 || p.ndim > 4) return fail(CV_ERR_INVALID, std::string("malformed cv_param_t entry '") + p.name + "'");
         ParamView v;
         v.data = p.data;
         for (int d = 0; d < p.ndim; ++d) v.shape.push_back(p.shape[d]);
@@ -450,6 +453,7 @@ static int impl_cv_extract_squares_u8(cv_engine_t* eng, const uint8_t* images, i
     if (!s.ok()) return finish(s);
     if (!images || !inv_host || !squares || n <= 0 || h <= 0 || w_ <= 0)
         return finish(fail(CV_ERR_INVALID, "cv_extract_squares_u8: bad argument"));
+    if (((uintptr_t)squares & 3) || ((uintptr_t)boards & 3)) return finish(fail(CV_ERR_INVALID, "cv_extract_squares_u8: outputs must be 4-byte aligned"));
     std::lock_guard<std::mutex> lk(eng->impl.mu);
     DeviceGuard g(eng->impl.device);
     Engine& e = eng->impl;
@@ -460,6 +464,13 @@ static int impl_cv_extract_squares_u8(cv_engine_t* eng, const uint8_t* images, i
     if (err == hipSuccess) err = extract_squares_u8(images, n, h, w_, (const double*)e.scratch.ptr, squares, boards, st);
     if (err == hipSuccess) err = hipStreamSynchronize(st);       // inv_host may be reused by the caller; scratch by the next call
     if (err != hipSuccess) return finish(hip_fail(err, "extract_squares_u8"));
+    return CV_OK;
+}
+
+static int impl_cv_board_homographies(const float* quads, int n, int out_w, int out_h, double* forward, double* inverse) {
+    if (n < 0 || out_w <= 0 || out_h <= 0 || (n > 0 && (!quads || (!forward && !inverse))))
+        return finish(fail(CV_ERR_INVALID, "cv_board_homographies: bad argument"));
+    board_homographies(quads, n, out_w, out_h, forward, inverse);
     return CV_OK;
 }
 
@@ -529,6 +540,8 @@ static int impl_cv_extract_squares_u8_dev(cv_engine_t* eng, const uint8_t* image
     if (!s.ok()) return finish(s);
     if (!images || !inv_dev || !squares || n <= 0 || h <= 0 || w_ <= 0)
         return finish(fail(CV_ERR_INVALID, "cv_extract_squares_u8_dev: bad argument"));
+    if (((uintptr_t)squares & 3) || ((uintptr_t)boards & 3) || ((uintptr_t)inv_dev & 7))
+        return finish(fail(CV_ERR_INVALID, "cv_extract_squares_u8_dev: outputs must be 4-byte aligned, matrices 8-byte aligned"));
     DeviceGuard g(eng->impl.device);
     hipError_t err = extract_squares_u8(images, n, h, w_, inv_dev, squares, boards, (hipStream_t)stream);
     if (err != hipSuccess) return finish(hip_fail(err, "extract_squares_u8"));
@@ -680,6 +693,10 @@ int cv_resize_area_u8(cv_engine_t* eng, const uint8_t* src, int n, int h, int w_
 int cv_extract_squares_u8(cv_engine_t* eng, const uint8_t* images, int n, int h, int w_, const double* inv_host,
                           uint8_t* squares, uint8_t* boards, void* stream) {
     return guarded("cv_extract_squares_u8", [&]() -> int { return impl_cv_extract_squares_u8(eng, images, n, h, w_, inv_host, squares, boards, stream); });
+}
+
+int cv_board_homographies(const float* quads, int n, int out_w, int out_h, double* forward, double* inverse) {
+    return guarded("cv_board_homographies", [&]() -> int { return impl_cv_board_homographies(quads, n, out_w, out_h, forward, inverse); });
 }
 
 int cv_selftest_mfma(cv_engine_t* eng, float* max_err_f16, float* max_err_f32) {

@@ -121,6 +121,13 @@ struct ConvParams {
     float f0_in_mul;          // 2^-in_exp applied to the image values
     int f0_u8;
     unsigned long long* stamp;   // diagnostic builds (-DCV_STAMP=1) only: per-workgroup cycle stamps, else null
+    // split-K (conv_igemm.hip; small launches: single boards, the 64-square classifier batch): the K stages are dealt to `ksplit`
+    // workgroups per output tile, `kper` stages each; every workgroup writes its raw f32 accumulators to
+    // partial[split][pixel][prow channels] and conv_splitk_reduce_kernel sums the splits IN ORDER (deterministic) and runs the
+    // epilogue (BN affine, residual, ReLU, conversion, stores).  ksplit <= 1 / partial == null: off.
+    float* partial;
+    int ksplit, kper;
+    int prow;                 // channels per pixel row of `partial` (= padded GEMM rows)
 };
 
 }  // namespace cv

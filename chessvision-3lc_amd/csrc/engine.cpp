@@ -310,6 +310,14 @@ static int env_int(const char* name, int dflt) {
 struct Knobs {
     int halo = env_int("CV_HALO", 1), ct256 = env_int("CV_CT256", 1), ct256_min_blocks = env_int("CV_CT256_MIN_BLOCKS", 256);
     int n64 = env_int("CV_N64", 1), sep = env_int("CV_CONV_SEP", 1), fuse_pool = env_int("CV_FUSE_POOL", 1);
+    // split-K for launches that cannot fill the chip (single boards, the 64-square classifier batch; r04_tuning.md):
+    //   splitk            0 = off
+    //   splitk_max_tiles  launches with at least this many output tiles run unsplit
+    //   splitk_target     workgroups aimed for (2 per CU)
+    //   splitk_min_stages K stages (128 bytes of K per row) every split keeps at least
+    int splitk = env_int("CV_SPLITK", 1), splitk_max_tiles = env_int("CV_SPLITK_MAX_TILES", 192);
+    int splitk_target = env_int("CV_SPLITK_TARGET", 512), splitk_min_stages = env_int("CV_SPLITK_MIN_STAGES", 4);
+    int splitk_force = env_int("CV_SPLITK_FORCE", 0);   // tests: this many splits on every launch that can take them
 };
 static const Knobs& knobs() {
     static const Knobs k;
@@ -503,9 +511,34 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
     const int ns = choose_ns(cfg, dt, L.rows, p.M, L.nStages);
     p.nCt = (L.rows + conv_cfg_ct(cfg) - 1) / conv_cfg_ct(cfg);
     // 3x3 / stride-1 layers whose patch grid divides the image keep the input patch in LDS across the nine taps
-    const bool halo = L.k == 3 && L.stride == 1 && !L.shuffle && kbase != nullptr && L.nStages % 9 == 0 &&
-                      knobs().halo && conv_halo_supported(ct, Ho, Wo) &&
-                      blocks_for(L.rows, p.M, ct, 256) >= 128;        // single boards: 128x128 tiles give more workgroups
+    bool halo = L.k == 3 && L.stride == 1 && !L.shuffle && kbase != nullptr && L.nStages % 9 == 0 &&
+                knobs().halo && conv_halo_supported(ct, Ho, Wo) &&
+                blocks_for(L.rows, p.M, ct, 256) >= 128;              // single boards: 128x128 tiles give more workgroups
+    // Split-K: a launch with fewer output tiles than CUs leaves most of the chip idle while every workgroup walks a long K loop
+    // alone (UNet B=1 down4: 16 tiles x 288 stages; ResNet-18 layer4 at 64 squares: 8 tiles x 144 stages).  Such launches deal their
+    // K stages to several workgroups per tile (generic kernel) and a second pass sums the f32 partials in split order.
+    if (knobs().splitk && !head && !fuse0 && !calibrating) {
+        const int64_t tiles_igemm = blocks_for(L.rows, p.M, conv_cfg_ct(cfg), conv_cfg_pt(cfg));
+        const int64_t tiles_now = halo ? blocks_for(L.rows, p.M, ct, 256) : tiles_igemm;
+        int want = 1;
+        if (knobs().splitk_force > 1) want = knobs().splitk_force;
+        else if (tiles_now < knobs().splitk_max_tiles) want = (int)((knobs().splitk_target + tiles_igemm / 2) / tiles_igemm);
+        want = std::min(want, L.nStages / std::max(1, knobs().splitk_min_stages));
+        while (want > 1 && (size_t)want * (size_t)p.M * (size_t)p.nCt * conv_cfg_ct(cfg) * sizeof(float) > ((size_t)256 << 20)) --want;
+        if (want > 1) {
+            const int kper = (L.nStages + want - 1) / want;
+            p.ksplit = (L.nStages + kper - 1) / kper;                 // every split non-empty
+            p.kper = kper;
+            p.prow = p.nCt * conv_cfg_ct(cfg);
+            const size_t need = (size_t)p.ksplit * (size_t)p.M * (size_t)p.prow * sizeof(float);
+            if (splitk_ws.bytes < need) {
+                CV_HIP(hipStreamSynchronize(s));                      // earlier launches may still read the old buffer
+                CV_TRY(splitk_ws.alloc(std::max(need, (size_t)32 << 20), false));
+            }
+            p.partial = reinterpret_cast<float*>(splitk_ws.ptr);
+            if (p.ksplit > 1) halo = false; else { p.ksplit = 0; p.partial = nullptr; }
+        }
+    }
     if (fuse0) {
         if (!halo || !conv_halo_can_fuse_first_layer(ct, dt)) { Status ns; ns.code = kNotFused; return ns; }   // caller runs the layers apart
         p.f0_x = fuse0->x; p.f0_u8 = fuse0->u8 ? 1 : 0; p.f0_w = fuse0->w; p.f0_scale = fuse0->scale; p.f0_shift = fuse0->shift;
@@ -547,7 +580,8 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
                                                                                               // a run-time option of the same instantiation
         else
             prof.back().kernel = std::string("conv_igemm_kernel<") + tn + "," + std::to_string(conv_cfg_ct(cfg)) + "x" +
-                                 std::to_string(conv_cfg_pt(cfg)) + ",ring" + std::to_string(ns) + (L.shuffle ? ",shuffle" : "") + ">";
+                                 std::to_string(conv_cfg_pt(cfg)) + ",ring" + std::to_string(ns) + (L.shuffle ? ",shuffle" : "") +
+                                 (p.ksplit > 1 ? ",splitK" + std::to_string(p.ksplit) : std::string()) + ">";
     }
     hipError_t e = halo ? conv_halo_launch(ct, dt, p, x.N, s) : conv_igemm_launch(cfg, ns, dt, p, s);
     if (profiling) prof_end(s);

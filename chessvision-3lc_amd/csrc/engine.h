@@ -182,6 +182,7 @@ class Engine {
     std::unique_ptr<ResNet> resnet;
 
     DeviceBuffer scratch;                               // small per-call parameter blocks (homographies)
+    DeviceBuffer splitk_ws;                             // f32 partial sums of split-K conv launches (grown on demand)
 
     // numeric guard: one device word, 0xffffffff = clean, else the lowest id of a layer that stored a non-finite value
     DeviceBuffer guard;

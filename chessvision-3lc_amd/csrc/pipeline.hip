@@ -4,17 +4,62 @@
 //   extract_squares_u8 cv2.warpPerspective(image, M, (512,512)) -> cvtColor(BGR2GRAY) -> flip(.., 1) ->
 //                      ChessVision.extract_squares                                        reference utils.py:131-132,
 //                                                                                         core.py:298-300, 419-439
-// Both are HBM-bound byte kernels (one lane per output pixel, coalesced u8 stores); they exist so the batched pipeline
-// keeps the image on the device between the two CNNs instead of making two host round trips per board.  Arithmetic
-// mirrors chessvision/classical.py (the host restatement the tests use as checker): integer box mean for integer shrink
-// factors; double-precision homography + 1/32-pixel snapped bilinear taps + round-half-even; the 14-bit fixed-point
-// gray conversion of OpenCV.
+// Both are HBM-bound byte kernels; they exist so that the image stays on the device between the two CNNs.  Byte work is
+// bit-exact against chessvision/classical.py (the host restatement) AND oracle/classical_ref.py (the independent one): integer
+// box mean with round-half-up for integer shrink factors; the warp follows OpenCV's WarpPerspectiveInvoker operation by
+// operation (block-start + in-block-column association of the double-precision homography, 1/32-pixel coordinates rounded
+// half-even, int16-saturated integer pixel, integer bilinear weights summing to 2^15, round half UP), then the 15-bit fixed-point
+// gray conversion of OpenCV 4.x.
+//
+// Vectorisation (round 4): a lane owns FOUR horizontally adjacent output pixels and writes them with one 32-bit store per
+// output tensor; the warp fetches a tap pair (6 bytes of BGR BGR) with one unaligned 64-bit load per source row instead of six
+// byte loads; workgroups walk 64 x 16 output tiles = one square-aligned patch whose source footprint (a ~64 x 16 pixel
+// parallelogram, 3-4 KB) stays in the CU's vector cache across the tile's rows.  The 2x2 box mean of the 512 -> 256 resize reads
+// two 24-byte row segments per lane and writes 12 bytes.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace cv {
 
+typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+
 // ---- INTER_AREA resize -------------------------------------------------------------------------------------
+// fast path of the pipeline: 3 channels, shrink factor exactly 2 in both directions, output width a multiple of 4.
+// One lane = 4 output pixels: sums 2 rows x 8 source pixels (24 bytes per row, 8-byte aligned), (sum + 2) >> 2.
+__global__ __launch_bounds__(256) void resize_area_2x2c3_kernel(const uint8_t* __restrict__ src, int n, int h, int w,
+                                                                uint8_t* __restrict__ dst) {
+    const int oh = h >> 1, ow = w >> 1, qw = ow >> 2;                 // qw = 4-pixel groups per output row
+    const size_t total = (size_t)n * oh * qw;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int gx = (int)(idx % qw);
+    const size_t r = idx / qw;
+    const int oy = (int)(r % oh);
+    const size_t img = r / oh;
+    const uint8_t* s0 = src + ((img * h + (size_t)2 * oy) * w + (size_t)8 * gx) * 3;
+    const uint8_t* s1 = s0 + (size_t)w * 3;
+    uint32_t a[6], b[6];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const u32x2 va = *reinterpret_cast<const u32x2*>(s0 + 8 * i);
+        const u32x2 vb = *reinterpret_cast<const u32x2*>(s1 + 8 * i);
+        a[2 * i] = va[0]; a[2 * i + 1] = va[1]; b[2 * i] = vb[0]; b[2 * i + 1] = vb[1];
+    }
+    auto byte_of = [](const uint32_t* v, int k) -> uint32_t { return (v[k >> 2] >> ((k & 3) * 8)) & 0xffu; };
+    uint32_t out[3] = {0u, 0u, 0u};
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {                                      // output byte k = pixel k/3, channel k%3
+        const int p = k / 3, c = k % 3;
+        const uint32_t sum = byte_of(a, 6 * p + c) + byte_of(a, 6 * p + 3 + c) + byte_of(b, 6 * p + c) + byte_of(b, 6 * p + 3 + c);
+        out[k >> 2] |= ((sum + 2u) >> 2) << ((k & 3) * 8);
+    }
+    uint8_t* d = dst + ((img * oh + oy) * (size_t)ow + (size_t)4 * gx) * 3;
+    *reinterpret_cast<u32x3*>(d) = u32x3{out[0], out[1], out[2]};        // 12 bytes, 4-byte aligned
+}
+
 __global__ void resize_area_u8_kernel(const uint8_t* __restrict__ src, int n, int h, int w, int c,
                                       uint8_t* __restrict__ dst, int oh, int ow) {
 #pragma clang fp contract(off)                          // keep mul/add unfused: matches the numpy checker bit for bit
@@ -65,67 +110,108 @@ __global__ void resize_area_u8_kernel(const uint8_t* __restrict__ src, int n, in
 }
 
 // ---- warp + gray + flip + 64-way split --------------------------------------------------------------------
-// inv: per board the 3x3 map from board pixels (x, y, 1) to source pixels, row-major doubles (host side inverts the
-// reference's getPerspectiveTransform matrix).  One lane per pixel of the 512x512 board; writes the classifier's
-// (64 squares, 64, 64) u8 layout directly, and optionally the flipped gray board itself.
-__global__ void extract_squares_u8_kernel(const uint8_t* __restrict__ images, int n, int h, int w,
-                                          const double* __restrict__ inv, uint8_t* __restrict__ squares,
-                                          uint8_t* __restrict__ boards) {
+// inv: per board the 3x3 map from board pixels (x, y, 1) to source pixels, row-major doubles = cv::invert of the
+// getPerspectiveTransform matrix, computed on the host in OpenCV's order of operations (csrc/homography.cpp).
+// Workgroup = 64 x 16 pixels of the FLIPPED board (what the classifier sees) = a quarter of one square's rows; wave w owns rows
+// 4w .. 4w+3, lane l the pixels 4*(l%16) .. +3 of row l/16.  Writes the classifier's (64 squares, 64, 64) u8 layout directly,
+// and optionally the flipped gray board itself.
+__global__ __launch_bounds__(256) void extract_squares_u8_kernel(const uint8_t* __restrict__ images, int n, int h, int w,
+                                                                 const double* __restrict__ inv, uint8_t* __restrict__ squares,
+                                                                 uint8_t* __restrict__ boards) {
 #pragma clang fp contract(off)
     constexpr int B = 512;
-    const size_t total = (size_t)n * B * B;
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int bx = (int)(idx % B);                       // pixel of the FLIPPED board (what the classifier sees)
-    const int by = (int)((idx / B) % B);
-    const int img = (int)(idx / ((size_t)B * B));
+    const int img = blockIdx.z;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bx0 = blockIdx.x * 64 + (lane & 15) * 4;                  // first of this lane's 4 pixels (flipped board)
+    const int by = blockIdx.y * 16 + wave * 4 + (lane >> 4);
     const double* m = inv + (size_t)img * 9;
-    const double xs = (double)(B - 1 - bx), ys = (double)by;       // undo cv2.flip(board, 1)
-    // cv2.warpPerspective, INTER_LINEAR, BORDER_CONSTANT(0), in OpenCV's fixed-point form (imgwarp.cpp): source coordinates in 1/32
-    // pixel (INTER_BITS = 5; X = round(X0 * (32 / W0)), ties to even), integer bilinear weights (32-a)(32-b)*32 ... a*b*32 that sum to
-    // 2^15 (INTER_REMAP_COEF_BITS), pixel = (sum + 2^14) >> 15: round half UP.  (Rounds 1-2 blended in double and rounded ties to even:
-    // one grey level apart on ~0.5 % of the pixels.)
-    const double den = m[6] * xs + m[7] * ys + m[8];
-    const double scale = den != 0.0 ? 32.0 / den : 0.0;
-    double fxs = (m[0] * xs + m[1] * ys + m[2]) * scale;
-    double fys = (m[3] * xs + m[4] * ys + m[5]) * scale;
-    fxs = fxs < -2147483648.0 ? -2147483648.0 : fxs > 2147483647.0 ? 2147483647.0 : fxs;
-    fys = fys < -2147483648.0 ? -2147483648.0 : fys > 2147483647.0 ? 2147483647.0 : fys;
-    const long long xi = (long long)rint(fxs), yi = (long long)rint(fys);
-    const long long x0 = xi >> 5, y0 = yi >> 5;
-    const int ax = (int)(xi & 31), ay = (int)(yi & 31);
-    const int w00 = (32 - ax) * (32 - ay) * 32, w01 = ax * (32 - ay) * 32, w10 = (32 - ax) * ay * 32, w11 = ax * ay * 32;
-    const bool inside = x0 >= -1 && x0 < w && y0 >= -1 && y0 < h;
+    const double m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3], m4 = m[4], m5 = m[5], m6 = m[6], m7 = m[7], m8 = m[8];
+    // cv2.flip(board, 1) undone: flipped pixel bx is warp-space column xs = 511 - bx.  The lane's four columns xs = xs3 .. xs3+3
+    // (xs3 = 508 - bx0, a multiple of 4) lie in ONE 128-column block of OpenCV's walk, whose start column enters the arithmetic:
+    //   X0 = M0*blk + M1*y + M2;  W = W0 + M6*x1;  W = W ? 32/W : 0;  X = round((X0 + M0*x1) * W)   (x1 = column inside the block)
+    const int xs3 = B - 4 - bx0;
+    const double blk = (double)(xs3 & ~127), ys = (double)by;
+    const double X0 = (m0 * blk + m1 * ys) + m2;
+    const double Y0 = (m3 * blk + m4 * ys) + m5;
+    const double W0 = (m6 * blk + m7 * ys) + m8;
     const uint8_t* s = images + (size_t)img * h * w * 3;
-    int bgr[3];
+    const unsigned row_bytes = (unsigned)w * 3u;
+    uint32_t packed = 0;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        int acc = 0;
-        if (inside) {
-            auto tap = [&](long long yy, long long xx) -> int {
-                return (yy >= 0 && yy < h && xx >= 0 && xx < w) ? (int)s[((size_t)yy * w + xx) * 3 + c] : 0;
-            };
-            acc = w00 * tap(y0, x0) + w01 * tap(y0, x0 + 1) + w10 * tap(y0 + 1, x0) + w11 * tap(y0 + 1, x0 + 1);
+    for (int j = 0; j < 4; ++j) {                                       // flipped pixel bx0 + j  <->  column xs3 + 3 - j
+        const double x1 = (double)((xs3 & 127) + 3 - j);
+        double W = W0 + m6 * x1;
+        W = W != 0.0 ? 32.0 / W : 0.0;
+        const double fxs = (X0 + m0 * x1) * W;
+        const double fys = (Y0 + m3 * x1) * W;
+        // saturate_cast<int>(clamp(f, INT_MIN, INT_MAX)): nearest-even, then the conversion itself saturates at both ends
+        const int xi = (int)rint(fxs), yi = (int)rint(fys);
+        const int x0 = xi >> 5, y0 = yi >> 5;                           // (the CV_16SC2 map saturates to int16: only far outside any image)
+        const unsigned wx1 = (unsigned)(xi & 31), wy1 = (unsigned)(yi & 31), wx0 = 32u - wx1, wy0 = 32u - wy1;
+        // Separable form of OpenCV's integer blend: with h_r = wx0 * p(r, x0) + wx1 * p(r, x0 + 1),
+        //   (w00 p00 + w01 p01 + w10 p10 + w11 p11 + 2^14) >> 15  ==  (wy0 h_0 + wy1 h_1 + 512) >> 10     (w_ij = 32 wy_i wx_j: exact)
+        unsigned bb, gg, rr;
+        if ((unsigned)x0 < (unsigned)(w - 2) && (unsigned)y0 < (unsigned)(h - 1)) {
+            // interior: both taps of a row are 6 consecutive bytes B0 G0 R0 B1 G1 R1; one unaligned 64-bit load per row (stays inside
+            // the row), the horizontal blends as byte dot products (v_dot4_u32_u8) straight on the loaded words
+            const unsigned off = (unsigned)(y0 * w + x0) * 3u;
+            const uint64_t t = *reinterpret_cast<const u64_unaligned*>(s + off);
+            const uint64_t u = *reinterpret_cast<const u64_unaligned*>(s + off + row_bytes);
+            const unsigned tlo = (unsigned)t, thi = (unsigned)(t >> 32), ulo = (unsigned)u, uhi = (unsigned)(u >> 32);
+            const unsigned WB = wx0 | (wx1 << 24), WG0 = wx0 << 8, WR0 = wx0 << 16, WG1 = wx1, WR1 = wx1 << 8;
+            const unsigned hB0 = __builtin_amdgcn_udot4(tlo, WB, 0u, false);
+            const unsigned hG0 = __builtin_amdgcn_udot4(thi, WG1, __builtin_amdgcn_udot4(tlo, WG0, 0u, false), false);
+            const unsigned hR0 = __builtin_amdgcn_udot4(thi, WR1, __builtin_amdgcn_udot4(tlo, WR0, 0u, false), false);
+            const unsigned hB1 = __builtin_amdgcn_udot4(ulo, WB, 0u, false);
+            const unsigned hG1 = __builtin_amdgcn_udot4(uhi, WG1, __builtin_amdgcn_udot4(ulo, WG0, 0u, false), false);
+            const unsigned hR1 = __builtin_amdgcn_udot4(uhi, WR1, __builtin_amdgcn_udot4(ulo, WR0, 0u, false), false);
+            bb = (wy0 * hB0 + (wy1 * hB1 + 512u)) >> 10;
+            gg = (wy0 * hG0 + (wy1 * hG1 + 512u)) >> 10;
+            rr = (wy0 * hR0 + (wy1 * hR1 + 512u)) >> 10;
+        } else {
+            const int cx = x0 < -32768 ? -32768 : x0 > 32767 ? 32767 : x0;            // the map is CV_16SC2
+            const int cy = y0 < -32768 ? -32768 : y0 > 32767 ? 32767 : y0;
+            bb = gg = rr = 0u;
+            if (cx >= -1 && cy >= -1 && cx < w && cy < h) {             // frame: BORDER_CONSTANT(0) per tap
+                unsigned v[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    auto tap = [&](int yy, int xx) -> unsigned {
+                        return (yy >= 0 && yy < h && xx >= 0 && xx < w) ? (unsigned)s[((size_t)yy * w + xx) * 3 + c] : 0u;
+                    };
+                    v[c] = (wy0 * (wx0 * tap(cy, cx) + wx1 * tap(cy, cx + 1)) + (wy1 * (wx0 * tap(cy + 1, cx) + wx1 * tap(cy + 1, cx + 1)) + 512u)) >> 10;
+                }
+                bb = v[0]; gg = v[1]; rr = v[2];
+            }
         }
-        bgr[c] = (acc + (1 << 14)) >> 15;
+        // OpenCV 4.x 8-bit BGR2GRAY: 15 fractional bits (BY15 / GY15 / RY15, gray_shift = 15); 3.x used 1868 / 9617 / 4899 >> 14
+        const uint32_t gray = (bb * 3735u + gg * 19235u + (rr * 9798u + (1u << 14))) >> 15;
+        packed |= gray << (8 * j);
     }
-    // OpenCV 4.x 8-bit BGR2GRAY: 15 fractional bits (BY15 / GY15 / RY15, gray_shift = 15); 3.x used 1868 / 9617 / 4899 >> 14
-    const uint8_t gray = (uint8_t)((bgr[0] * 3735 + bgr[1] * 19235 + bgr[2] * 9798 + (1 << 14)) >> 15);
-    if (boards) boards[idx] = gray;
-    const int sq = (by >> 6) * 8 + (bx >> 6);            // a8..h8, a7.. order (reference core.py:436-439)
-    squares[((size_t)img * 64 + sq) * 4096 + (size_t)(by & 63) * 64 + (bx & 63)] = gray;
+    if (boards) *reinterpret_cast<uint32_t*>(boards + ((size_t)img * B + by) * B + bx0) = packed;
+    const int sq = (by >> 6) * 8 + (bx0 >> 6);            // a8..h8, a7.. order (reference core.py:436-439)
+    *reinterpret_cast<uint32_t*>(squares + ((size_t)img * 64 + sq) * 4096 + (size_t)(by & 63) * 64 + (bx0 & 63)) = packed;
 }
 
 hipError_t resize_area_u8(const uint8_t* src, int n, int h, int w, int c, uint8_t* dst, int oh, int ow, hipStream_t s) {
+    if (c == 3 && h == 2 * oh && w == 2 * ow && ow % 4 == 0 && ((uintptr_t)src & 7) == 0 && ((uintptr_t)dst & 3) == 0) {
+        const size_t total = (size_t)n * oh * (ow / 4);
+        hipLaunchKernelGGL(resize_area_2x2c3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, n, h, w, dst);
+        return hipGetLastError();
+    }
     const size_t total = (size_t)n * oh * ow * c;
     hipLaunchKernelGGL(resize_area_u8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, n, h, w, c, dst, oh, ow);
     return hipGetLastError();
 }
 hipError_t extract_squares_u8(const uint8_t* images, int n, int h, int w, const double* inv, uint8_t* squares,
                               uint8_t* boards, hipStream_t s) {
-    const size_t total = (size_t)n * 512 * 512;
-    hipLaunchKernelGGL(extract_squares_u8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, images, n, h, w, inv,
-                       squares, boards);
+    // grid.z = boards: jobs of the pipeline carry <= a few hundred boards (65535 is the limit)
+    for (int off = 0; off < n; off += 32768) {
+        const int cnt = n - off < 32768 ? n - off : 32768;
+        hipLaunchKernelGGL(extract_squares_u8_kernel, dim3(8, 32, (unsigned)cnt), dim3(256), 0, s,
+                           images + (size_t)off * h * w * 3, cnt, h, w, inv + (size_t)off * 9, squares + (size_t)off * 64 * 4096,
+                           boards ? boards + (size_t)off * 512 * 512 : nullptr);
+    }
     return hipGetLastError();
 }
 

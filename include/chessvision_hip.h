@@ -203,10 +203,20 @@ int cv_find_quadrangles(const uint8_t* masks, int n, int h, int w, int32_t* quad
 int cv_resize_area_u8(cv_engine_t* eng, const uint8_t* src, int n, int h, int w, int channels, uint8_t* dst,
                       int out_h, int out_w, void* stream);
 
+/* Quadrangles -> the matrices of the board warp, host side, in OpenCV's order of operations (utils.extract_perspective,
+ * utils.py:115-132: cv2.getPerspectiveTransform(approx, dest) with dest = (0,0), (w,0), (w,h), (0,h); cv2.warpPerspective then
+ * inverts the matrix).  quads: n x 4 x (x, y) float32 source-image pixels in the reference's vertex order (TR, TL, BL, BR);
+ * forward (nullable): n x 9 doubles, row-major, m[8] = 1; inverse (nullable): n x 9 doubles = cv::invert(forward) = the map from
+ * board pixels to source pixels that cv_extract_squares_u8 consumes.  Degenerate quadrangles give all-zero matrices (OpenCV's
+ * behaviour: every board pixel then reads source pixel (0,0)).  Needs no GPU and no engine. */
+int cv_board_homographies(const float* quads, int n, int out_w, int out_h, double* forward, double* inverse);
+
 /* Per board: perspective warp to 512x512 (bilinear, zero border) + BGR->gray + horizontal flip + split into 64 squares
  * (utils.py:131-132, core.py:298-300, 419-439), fused.  images: DEVICE (n,h,w,3) uint8 BGR; inv_host: HOST n x 9
  * doubles = inverse of the getPerspectiveTransform matrix (board pixel -> source pixel); squares: DEVICE (n*64,64,64)
  * uint8 in a8..h1 order = the input of cv_resnet18_forward_u8; boards (nullable): DEVICE (n,512,512) uint8 gray board.
+ * Byte-exact against cv2's fixed-point arithmetic as restated in oracle/classical_ref.py (1/32-pixel coordinates in
+ * WarpPerspectiveInvoker's block order, integer bilinear weights, round half up, 15-bit gray).  Output pointers 4-byte aligned.
  * Synchronises `stream` before returning. */
 int cv_extract_squares_u8(cv_engine_t* eng, const uint8_t* images, int n, int h, int w, const double* inv_host,
                           uint8_t* squares, uint8_t* boards, void* stream);

@@ -126,58 +126,93 @@ def pawn_rule(labels: list[str], probs: np.ndarray, names: list[str]):
 
 
 def perspective_matrix(src: np.ndarray, dst: np.ndarray) -> np.ndarray:
-    """cv2.getPerspectiveTransform: the 3x3 map with m33 = 1 taking four ``src`` points onto ``dst``.  OpenCV sets up the 8x8 system
-    [x y 1 0 0 0 -xu -yu; 0 0 0 x y 1 -xv -yv] h = [u; v] and solves it in double precision; here by Gaussian elimination with
-    partial pivoting, written out (no library solver shared with the product)."""
-    s4 = np.asarray(src, np.float64).reshape(4, 2)
-    d4 = np.asarray(dst, np.float64).reshape(4, 2)
-    a = [[0.0] * 9 for _ in range(8)]
+    """cv2.getPerspectiveTransform (imgproc/src/imgwarp.cpp): the 3x3 map with m33 = 1 taking four ``src`` points onto ``dst``.
+    OpenCV fills rows i and i + 4 of an 8x8 system with [x y 1 0 0 0 -xu -yu] / [0 0 0 x y 1 -xv -yv] and calls
+    ``solve(A, B, X, DECOMP_LU)``; below the LAPACK size threshold that is its own ``LUImpl`` (core/src/matrix_decomp.cpp): partial
+    pivoting on the FIRST largest magnitude, elimination with ``alpha = A[j][i] * (-1 / A[i][i])`` and ``A[j][k] += alpha * A[i][k]``,
+    back substitution ``s -= A[i][k] * x[k]``, ``x[i] = s / A[i][i]``.  The ORDER OF OPERATIONS is part of the result (the last bit of
+    the matrix decides 1/32-pixel ties in the warp), so it is followed literally, in scalar Python floats (IEEE double, no fused
+    multiply-add), sharing no code with the product.  A singular system returns the zero matrix (OpenCV leaves X untouched)."""
+    s4 = np.asarray(src, np.float32).reshape(4, 2)           # Point2f: the products below are formed in FLOAT, as in OpenCV
+    d4 = np.asarray(dst, np.float32).reshape(4, 2)
+    a = [[0.0] * 8 for _ in range(8)]
+    b = [0.0] * 8
     for i in range(4):
-        x, y = s4[i]
-        u, v = d4[i]
-        a[2 * i] = [x, y, 1.0, 0.0, 0.0, 0.0, -x * u, -y * u, u]
-        a[2 * i + 1] = [0.0, 0.0, 0.0, x, y, 1.0, -x * v, -y * v, v]
-    for col in range(8):
-        piv = max(range(col, 8), key=lambda r: abs(a[r][col]))
-        a[col], a[piv] = a[piv], a[col]
-        for r in range(col + 1, 8):
-            f = a[r][col] / a[col][col]
-            for c in range(col, 9):
-                a[r][c] -= f * a[col][c]
-    h = [0.0] * 8
-    for r in range(7, -1, -1):
-        h[r] = (a[r][8] - sum(a[r][c] * h[c] for c in range(r + 1, 8))) / a[r][r]
-    return np.array(h + [1.0], np.float64).reshape(3, 3)
+        x, y, u, v = s4[i][0], s4[i][1], d4[i][0], d4[i][1]   # np.float32 scalars
+        xu, yu, xv, yv = float(-x * u), float(-y * u), float(-x * v), float(-y * v)
+        a[i] = [float(x), float(y), 1.0, 0.0, 0.0, 0.0, xu, yu]
+        a[i + 4] = [0.0, 0.0, 0.0, float(x), float(y), 1.0, xv, yv]
+        b[i], b[i + 4] = float(u), float(v)
+    eps = 2.220446049250313e-16 * 100.0
+    for i in range(8):
+        k = i
+        for j in range(i + 1, 8):
+            if abs(a[j][i]) > abs(a[k][i]):
+                k = j
+        if abs(a[k][i]) < eps:
+            return np.zeros((3, 3), np.float64)
+        if k != i:
+            for j in range(i, 8):
+                a[i][j], a[k][j] = a[k][j], a[i][j]
+            b[i], b[k] = b[k], b[i]
+        d = -1.0 / a[i][i]
+        for j in range(i + 1, 8):
+            alpha = a[j][i] * d
+            for c in range(i + 1, 8):
+                a[j][c] += alpha * a[i][c]
+            b[j] += alpha * b[i]
+    for i in range(7, -1, -1):
+        s = b[i]
+        for c in range(i + 1, 8):
+            s -= a[i][c] * b[c]
+        b[i] = s / a[i][i]
+    return np.array(b + [1.0], np.float64).reshape(3, 3)
 
 
 def _invert3(m: np.ndarray) -> np.ndarray:
-    (a, b, c), (d, e, f), (g, h, i) = m
+    """cv::invert of a 3x3 double matrix (core/src/lapack.cpp, the closed-form branch warpPerspective takes for its matrix): the
+    cofactors times the RECIPROCAL of the determinant, ``det3`` expanded along the first row.  Singular -> zeros, as OpenCV."""
+    (a, b, c), (d, e, f), (g, h, i) = [[float(v) for v in row] for row in m]
     det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g)
-    adj = np.array([[e * i - f * h, c * h - b * i, b * f - c * e],
-                    [f * g - d * i, a * i - c * g, c * d - a * f],
-                    [d * h - e * g, b * g - a * h, a * e - b * d]], np.float64)
-    return adj / det
+    if det == 0.0:
+        return np.zeros((3, 3), np.float64)
+    r = 1.0 / det
+    return np.array([[(e * i - f * h) * r, (c * h - b * i) * r, (b * f - c * e) * r],
+                     [(f * g - d * i) * r, (a * i - c * g) * r, (c * d - a * f) * r],
+                     [(d * h - e * g) * r, (b * g - a * h) * r, (a * e - b * d) * r]], np.float64)
 
 
 def warp_perspective(image: np.ndarray, m: np.ndarray, size: tuple[int, int]) -> np.ndarray:
-    """cv2.warpPerspective(image, M, (w, h)) with its defaults (INTER_LINEAR, BORDER_CONSTANT 0), in OpenCV's fixed-point form:
-    the inverse map gives source coordinates in 1/32 pixel (``INTER_BITS = 5``: X = round(32 * X0 / W0)), the four bilinear weights
-    are the integers (32-a)(32-b)*32 ... a*b*32 (``INTER_REMAP_COEF_BITS = 15``: they sum to 2^15 exactly) and the pixel is
-    ``(sum(w * p) + 2^14) >> 15`` -- round half UP, where a float blend rounds ties to even.  Taps outside the image read 0."""
+    """cv2.warpPerspective(image, M, (w, h)) with its defaults (INTER_LINEAR, BORDER_CONSTANT 0), in OpenCV's fixed-point form
+    (imgwarp.cpp: WarpPerspectiveInvoker + remapBilinear).  The destination is walked in blocks of min(128, w) x min(32, h) pixels;
+    for the block starting at column ``bx`` and the row ``y``: X0 = M0*bx + M1*y + M2 (likewise Y0, W0), and for the pixel ``x1``
+    columns into the block W = W0 + M6*x1, W = 32 / W (0 when W is 0), X = round_half_even(clamp((X0 + M0*x1) * W, INT_MIN, INT_MAX))
+    -- source coordinates in 1/32 pixel (``INTER_BITS = 5``).  The association (block start first, then the in-block column) is
+    followed literally: the last bit decides ties.  The integer pixel X >> 5 saturates to int16 (the map is CV_16SC2), the four
+    bilinear weights are the integers (32-a)(32-b)*32 ... a*b*32 (``INTER_REMAP_COEF_BITS = 15``: they sum to 2^15 exactly) and the
+    pixel is ``(sum(w * p) + 2^14) >> 15`` -- round half UP.  Taps outside the image read 0."""
     w_out, h_out = size
     inv = _invert3(np.asarray(m, np.float64))
     img = image if image.ndim == 3 else image[:, :, None]
     h, w, ch = img.shape
-    ys, xs = np.mgrid[0:h_out, 0:w_out].astype(np.float64)
-    x0 = inv[0, 0] * xs + inv[0, 1] * ys + inv[0, 2]
-    y0 = inv[1, 0] * xs + inv[1, 1] * ys + inv[1, 2]
-    w0 = inv[2, 0] * xs + inv[2, 1] * ys + inv[2, 2]
-    scale = np.where(w0 != 0, 32.0 / np.where(w0 != 0, w0, 1.0), 0.0)
-    fx = np.clip(x0 * scale, -2.0 ** 31, 2.0 ** 31 - 1)
-    fy = np.clip(y0 * scale, -2.0 ** 31, 2.0 ** 31 - 1)
+    bw = min(128, w_out)
+    cols = np.arange(w_out)
+    bx = ((cols // bw) * bw).astype(np.float64)[None, :]              # block start column of every destination column
+    x1 = (cols % bw).astype(np.float64)[None, :]
+    ys = np.arange(h_out, dtype=np.float64)[:, None]
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        x0 = (inv[0, 0] * bx + inv[0, 1] * ys) + inv[0, 2]
+        y0 = (inv[1, 0] * bx + inv[1, 1] * ys) + inv[1, 2]
+        w0 = (inv[2, 0] * bx + inv[2, 1] * ys) + inv[2, 2]
+        wq = w0 + inv[2, 0] * x1
+        scale = np.where(wq != 0, 32.0 / np.where(wq != 0, wq, 1.0), 0.0)
+        fx = np.maximum(-2147483648.0, np.minimum(2147483647.0, (x0 + inv[0, 0] * x1) * scale))
+        fy = np.maximum(-2147483648.0, np.minimum(2147483647.0, (y0 + inv[1, 0] * x1) * scale))
     xi = np.rint(fx).astype(np.int64)                        # saturate_cast<int>(double): round to nearest, ties to even
     yi = np.rint(fy).astype(np.int64)
-    sx, sy, ax, ay = xi >> 5, yi >> 5, xi & 31, yi & 31
+    sx = np.clip(xi >> 5, -32768, 32767)                     # saturate_cast<short>
+    sy = np.clip(yi >> 5, -32768, 32767)
+    ax, ay = xi & 31, yi & 31
     pad = np.zeros((h + 2, w + 2, ch), np.int64)
     pad[1:h + 1, 1:w + 1] = img
 
@@ -199,4 +234,4 @@ def extract_board(image: np.ndarray, quad: np.ndarray, size: tuple[int, int] = (
     ``_rotate_quadrangle`` leaves it) -> destination corners ((0,0), (w,0), (w,h), (0,h)) -> warp."""
     w, h = size
     dest = np.array(((0, 0), (w, 0), (w, h), (0, h)), np.float64)
-    return warp_perspective(image, perspective_matrix(np.asarray(quad, np.float64).reshape(4, 2), dest), size)
+    return warp_perspective(image, perspective_matrix(np.asarray(quad, np.float32).reshape(4, 2), dest), size)

@@ -6,8 +6,9 @@ TEST INFRASTRUCTURE (see ``oracle/__init__.py``).  The reference pipeline (``che
 and keeps the two models behind opaque callables (``core.py:53-54``).  Here it is written out stage by stage:
 
 * the two CNNs are ``oracle.unet_ref.UNet`` / ``oracle.resnet_ref.ResNet18`` on torch CPU fp32;
-* resize (integer factors), sigmoid / threshold, the perspective matrix and warp (OpenCV's fixed-point form: 1/32-pixel
-  coordinates, integer weights, round half up), gray, flip, the 64-way split, soft-max, arg-max, FEN and the pawn rule are the
+* resize (integer factors), sigmoid / threshold, the perspective matrix and warp (OpenCV's arithmetic in OpenCV's order of
+  operations: LU solve, cofactor inverse, block-wise 1/32-pixel coordinates, integer weights, round half up -- the product's
+  device warp must equal it byte for byte), gray, flip, the 64-way split, soft-max, arg-max, FEN and the pawn rule are the
   INDEPENDENT restatements of ``oracle/classical_ref.py`` -- they share no code with the product's host path
   (``chessvision/classical.py``, ``fen.py``, ``ChessVision`` statics) nor with its device / C++ path;
 * ONE stage is not independent and is taken from the product's numpy host path: the mask -> quadrangle chain
@@ -30,18 +31,31 @@ from . import classical_ref as cref
 
 
 def process_image(unet, resnet, image: np.ndarray, threshold: float = 0.5, flip: bool = False, fallback_quad: bool = False):
-    from chessvision import ChessVision, classical                             # the shared contour stage + result records only
-    from chessvision.cv_types import BoardExtractionResult, ChessVisionResult
-
     t0 = time.time()
     h, w = image.shape[:2]
     if h % 256 == 0 and w % 256 == 0:
         small = cref.resize_area_int(image, (256, 256))
     else:
+        from chessvision import classical                                      # fractional factors: the product's coverage form
+
         small = classical.resize_area(image, (256, 256))
     x = torch.from_numpy(small.astype(np.float32) / np.float32(255.0)).permute(2, 0, 1)[None]   # core.py:215-216
-    logits = unet(x)[0, 0].numpy().astype(np.float32)
+    with torch.no_grad():
+        logits = unet(x)[0, 0].numpy().astype(np.float32)
     mask = cref.binary_mask(logits, threshold)
+    return process_from_mask(resnet, image, mask, logits, flip, fallback_quad, t0)
+
+
+def process_from_mask(resnet, image: np.ndarray, mask: np.ndarray, logits: np.ndarray, flip: bool = False,
+                      fallback_quad: bool = False, t0: float | None = None):
+    """The chain downstream of the binary mask (reference core.py:277-307 + classify_position).  Also called by the end-to-end
+    tests with the PRODUCT's mask when a pixel whose logit sits within the logit tolerance of the threshold flipped, so that
+    quadrangle, warp, classifier and FEN of that board are still compared instead of skipped."""
+    from chessvision import ChessVision                                        # the shared contour stage + result records only
+    from chessvision.cv_types import BoardExtractionResult, ChessVisionResult
+
+    t0 = time.time() if t0 is None else t0
+    h = image.shape[0]
     quad = ChessVision._find_quadrangle(mask)                                  # shared (see the module docstring)
     if quad is None and fallback_quad:
         quad = np.array([[[255, 0]], [[0, 0]], [[0, 255]], [[255, 255]]], dtype=np.int32)
@@ -57,9 +71,7 @@ def process_image(unet, resnet, image: np.ndarray, threshold: float = 0.5, flip:
 
 def classify_board(resnet, board: np.ndarray, flip: bool = False):
     """The second half of the chain on a GIVEN rectified board (reference ``classify_position``, core.py:225-249, and
-    ``process_position_probabilities``, core.py:309-355): split, /255, classifier, soft-max, arg-max, FEN, pawn rule.  The
-    end-to-end tests call it on the board the device produced when that board differs from the oracle's by warp-coordinate ties,
-    so that the classifier stage is judged on identical inputs."""
+    ``process_position_probabilities``, core.py:309-355): split, /255, classifier, soft-max, arg-max, FEN, pawn rule."""
     from chessvision.cv_types import PositionResult, ValidationFix
 
     squares = cref.split_squares(board)

@@ -6,8 +6,10 @@ reference's per-image ``process_image`` order of operations with the oracle's to
 and the numpy restatements of the OpenCV stages (reference core.py:152-195, 309-355).  The UNet weights are random except
 for one rewired channel that makes the network segment bright quadrilaterals (chessvision/synthetic.py: make_segmenting), so
 masks have real contours and most boards are found the way they would be with a trained checkpoint; the rest go through
-``fallback_quad``.  Asserted per board: masks equal outside |logit| < 1e-4, quadrangles identical, probabilities within 1e-3,
-FEN / original FEN / validation fixes identical (squares whose top-2 margin is inside the probability tolerance excepted).
+``fallback_quad``.  Asserted per board: masks equal outside |logit - logit(thr)| < 1e-4 (a board with a flipped pixel inside that band is continued
+from the product's mask, not skipped), quadrangles identical, rectified boards IDENTICAL BYTE FOR BYTE (whole-image fallback
+quadrangle included), probabilities within 1e-3, FEN / original FEN / validation fixes identical (squares whose top-2 margin is
+inside the probability tolerance excepted).
 The 256-board run is checked through size-independent properties and a sampled oracle comparison."""
 from __future__ import annotations
 
@@ -46,38 +48,27 @@ def _images(n, seed0=0):
     return imgs
 
 
-def _board_close(a, b):
-    """Device warp vs the oracle's: the same fixed-point scheme (1/32-pixel coordinates, integer weights, round half up), written
-    independently.  Their matrix inverses (LAPACK vs adjugate) differ in the last bit, and a source coordinate that is an exact
-    .5 tie in 1/32 pixels -- systematic for the whole-image fallback quadrangle, whose scale 510/512 is dyadic -- then rounds to
-    the neighbouring step (at most 255 / 32 grey levels; with that quadrangle one coordinate in eight is such a tie in x and in y,
-    so up to ~23 % of the pixels are exposed).  The strict pins of the warp are elsewhere: device == host to one grey level on
-    <= 0.1 % of the pixels with a shared inverse (tests/test_gpu_pipeline.py), host == oracle on non-dyadic quadrangles to < 1e-4 of
-    the pixels (tests/test_classical_ref.py)."""
-    diff = np.abs(a.astype(int) - b.astype(int))
-    return diff.max() <= 8 and float((diff > 0).mean()) <= 0.25 and float(diff.mean()) <= 0.5, (diff.max(), float((diff > 0).mean()), float(diff.mean()))
-
-
-def _compare(got, ref, stats, resnet=None, flip=False):
+def _compare(got, ref, stats, resnet, image, flip=False, fallback_quad=True, logit_thr=0.0):
     ge, re_ = got.board_extraction, ref.board_extraction
     assert np.abs(ge.probabilities - re_.probabilities).max() <= 1e-3          # UNet logits, north_star bar
-    unsure = np.abs(re_.probabilities) < 1e-4
+    unsure = np.abs(re_.probabilities - logit_thr) < 1e-4
     assert np.array_equal(ge.binary_mask[~unsure], re_.binary_mask[~unsure])
     if unsure.any() and not np.array_equal(ge.binary_mask, re_.binary_mask):
+        # a mask pixel whose logit is within 1e-4 of the threshold flipped: the two contours may differ, so the oracle continues
+        # from the PRODUCT's mask for this board -- everything downstream of the mask is still compared
         stats["mask_flips_inside_tolerance"] += 1
-        return                                             # a flipped border pixel may move a contour: nothing further is pinned
+        ref = pipeline_ref.process_from_mask(resnet, image, ge.binary_mask, re_.probabilities, flip, fallback_quad)
+        re_ = ref.board_extraction
     assert (ge.quadrangle is None) == (re_.quadrangle is None)
     assert (got.position is None) == (ref.position is None)
     if re_.quadrangle is not None:
         assert np.array_equal(ge.quadrangle, re_.quadrangle)
     if ref.position is None:
         return
-    ok, detail = _board_close(ge.board_image, re_.board_image)
-    assert ok, detail
-    if resnet is not None and not np.array_equal(ge.board_image, re_.board_image):
-        # judge the classifier stage on identical inputs: the oracle classifies the board the device produced
-        ref.position = pipeline_ref.classify_board(resnet, ge.board_image, flip)
-        stats["boards_reclassified"] = stats.get("boards_reclassified", 0) + 1
+    # byte work is bit-exact: device warp + gray + flip == the independent oracle's, fallback quadrangle (dyadic ties) included
+    assert np.array_equal(ge.board_image, re_.board_image), (int(np.abs(ge.board_image.astype(int) - re_.board_image.astype(int)).max()),
+                                                              float((ge.board_image != re_.board_image).mean()))
+    stats["boards_identical"] = stats.get("boards_identical", 0) + 1
     gp, rp = got.position, ref.position
     perr = np.abs(gp.model_probabilities - rp.model_probabilities).max()
     assert perr <= 1e-3, perr
@@ -103,8 +94,8 @@ def test_process_images_matches_the_oracle_pipeline(cv_model):
     ref = pipeline_ref.process_images(unet, resnet, images, fallback_quad=True)
     stats = {"mask_flips_inside_tolerance": 0, "max_prob_err": 0.0, "fen_checked": 0}
     found = 0
-    for g, r in zip(got, ref):
-        _compare(g, r, stats, resnet)
+    for g, r, im in zip(got, ref, images):
+        _compare(g, r, stats, resnet, im)
         found += int(r.board_extraction.quadrangle is not None and not np.array_equal(
             r.board_extraction.quadrangle, cv_model._scale_quadrangle(np.array([[[255, 0]], [[0, 0]], [[0, 255]], [[255, 255]]], np.int32), (512, 512))))
         if g.position is not None:
@@ -122,13 +113,9 @@ def test_flip_and_threshold_variants_match_the_oracle(cv_model):
     for thr, flip in ((0.3, True), (0.7, False)):
         got = cv_model.process_images(images, threshold=thr, flip=flip, fallback_quad=True)
         ref = pipeline_ref.process_images(unet, resnet, images, threshold=thr, flip=flip, fallback_quad=True)
-        for g, r in zip(got, ref):
+        for g, r, im in zip(got, ref, images):
             # masks are thresholded on sigmoid(logit): the uncertainty band sits at logit(thr), not at 0
-            band = np.abs(1.0 / (1.0 + np.exp(-r.board_extraction.probabilities.astype(np.float64))) - thr) < 1e-5
-            if band.any():
-                continue
-            r.board_extraction.probabilities = r.board_extraction.probabilities.copy()
-            _compare(g, r, stats, resnet, flip)
+            _compare(g, r, stats, resnet, im, flip, logit_thr=float(np.log(thr / (1.0 - thr))))
             if g.position is not None:
                 assert g.position.square_names == (constants.SQUARE_NAMES_FLIPPED if flip else constants.SQUARE_NAMES_NORMAL)
     assert stats["fen_checked"] >= 4, stats
@@ -158,7 +145,7 @@ def test_full_size_job_properties_and_sampled_oracle(cv_model):
     pick = [3, 64, 65, 127, 128, 200, 255]
     ref = pipeline_ref.process_images(unet, resnet, [images[i] for i in pick], fallback_quad=True)
     for i, r in zip(pick, ref):
-        _compare(res[i], r, stats, resnet)
+        _compare(res[i], r, stats, resnet, images[i])
 
 
 def test_mixed_precision_pipeline_matches_the_oracle(tmp_path):
@@ -174,8 +161,67 @@ def test_mixed_precision_pipeline_matches_the_oracle(tmp_path):
     got = cv.process_images(images, fallback_quad=True)
     ref = pipeline_ref.process_images(unet, resnet, images, fallback_quad=True)
     stats = {"mask_flips_inside_tolerance": 0, "max_prob_err": 0.0, "fen_checked": 0}
-    for g, r in zip(got, ref):
-        _compare(g, r, stats, resnet)
+    for g, r, im in zip(got, ref, images):
+        _compare(g, r, stats, resnet, im)
     assert stats["fen_checked"] >= 8 and 0 < stats["max_prob_err"] <= 1e-3, stats
     single = cv.process_image(images[1])                    # the per-image API takes the same two engines
     assert single.position is not None and np.abs(single.position.model_probabilities - ref[1].position.model_probabilities).max() <= 1e-3
+
+
+def test_process_image_is_the_native_pipeline_and_matches_batched_api_and_oracle(cv_model):
+    """VERDICT r03 'next' 1: ``process_image`` / ``predict`` / ``extract_board`` / ``classify_position`` -- the API the reference's
+    callers use (cv_endpoint.py:159, evaluate.py:270) -- run the same device stages as ``process_images``:
+    process_image(img) == process_images([img])[0] field by field (bit for bit: same kernels, same batch size), and both match the
+    oracle pipeline (boards byte-exact, probabilities within 1e-3, FEN identical).  No numpy warp / contour code runs on this path."""
+    from unittest import mock
+
+    from chessvision import classical
+
+    unet, resnet = _oracle_models()
+    images = _images(8, seed0=700)                          # index 0 and 7: no board -> position None without the fallback
+    wide = np.zeros((384, 512, 3), np.uint8)
+    wide[:, :384] = synthetic.board_photo(5, 384)
+    images.append(wide)                                     # non-square photo: fractional resize, height-only quadrangle scale
+    stats = {"mask_flips_inside_tolerance": 0, "max_prob_err": 0.0, "fen_checked": 0}
+    with mock.patch.object(classical, "warp_perspective", side_effect=AssertionError("numpy warp on the native path")), \
+         mock.patch.object(classical, "find_contours", side_effect=AssertionError("numpy contours on the native path")), \
+         mock.patch.object(classical, "resize_area", side_effect=AssertionError("numpy resize on the native path")):
+        singles = [cv_model.process_image(im) for im in images]
+        assert cv_model.predict.__func__ is cv_model.process_image.__func__
+    for im, single in zip(images, singles):
+        batched = cv_model.process_images([im])[0]
+        a, b = single.board_extraction, batched.board_extraction
+        assert np.array_equal(a.probabilities, b.probabilities) and np.array_equal(a.binary_mask, b.binary_mask)
+        assert (a.quadrangle is None) == (b.quadrangle is None) and (single.position is None) == (batched.position is None)
+        if a.quadrangle is not None:
+            assert np.array_equal(a.quadrangle, b.quadrangle) and a.quadrangle.dtype == np.float32
+            assert np.array_equal(a.board_image, b.board_image)
+            p, q = single.position, batched.position
+            assert np.array_equal(p.model_probabilities, q.model_probabilities)
+            assert p.fen == q.fen and p.original_fen == q.original_fen and p.square_names == q.square_names
+            assert np.array_equal(p.squares, q.squares) and p.validation_fixes == q.validation_fixes
+        if im.shape[0] % 256 == 0:                          # the oracle's independent resize covers integer factors
+            ref = pipeline_ref.process_image(unet, resnet, im)
+            _compare(single, ref, stats, resnet, im, fallback_quad=False)
+    assert sum(s.position is not None for s in singles) >= 6 and stats["fen_checked"] >= 4, stats
+    # the two halves on their own: extract_board, then classify_position on a board that did NOT come from this instance's last call
+    ext = cv_model.extract_board(images[1])
+    other = cv_model.extract_board(images[2])
+    pos = cv_model.classify_position(ext.board_image.copy(), flip=True)          # a copy: takes the upload branch
+    want = pipeline_ref.classify_board(resnet, ext.board_image, flip=True)
+    assert np.abs(pos.model_probabilities - want.model_probabilities).max() <= 1e-3 and pos.square_names == want.square_names
+    assert np.array_equal(other.board_image, singles[2].board_extraction.board_image)
+
+
+def test_classifier_first_under_a_mixed_precision(tmp_path):
+    """with "f16x3+f16r" the classifier engine may be requested before the extractor's (``cv.classifier`` or
+    ``classify_position`` on an already rectified board); the engines are created independently."""
+    pe, pc = synthetic.save_checkpoints(tmp_path, segmenting=True)
+    cv = ChessVision(board_extractor_weights=str(pe), classifier_weights=str(pc), precision="f16x3+f16r")
+    assert cv.classifier.engine.precision == "f16r" and list(cv._engines) == ["f16r"]
+    board = np.random.default_rng(4).integers(0, 256, (512, 512), dtype=np.uint8)
+    res = cv.classify_position(board)
+    assert res.model_probabilities.shape == (64, 13) and cv._board_extractor is None
+    assert cv.board_extractor.engine.precision == "f16x3"
+    with pytest.raises(ValueError):
+        ChessVision(precision="f16x3+bogus")
