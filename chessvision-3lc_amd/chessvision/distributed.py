@@ -23,9 +23,19 @@ def env_world() -> tuple[int, int, int]:
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
+_PINNED = False          # this process narrowed its CPU affinity to its rank's share (module state, NOT inherited by child processes)
+
+
 def local_world_size() -> int:
-    """Ranks sharing this host (torchrun exports LOCAL_WORLD_SIZE; one node: the world size)."""
-    return max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
+    """Ranks sharing this host: LOCAL_WORLD_SIZE (torchrun exports it); without it one rank per visible GPU, at most the world
+    size -- a multi-node launcher that only exports WORLD_SIZE must not make a rank believe the whole job shares its host."""
+    if "LOCAL_WORLD_SIZE" in os.environ:
+        return max(1, int(os.environ["LOCAL_WORLD_SIZE"]))
+    world = max(1, int(os.environ.get("WORLD_SIZE", "1")))
+    if world == 1:
+        return 1
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0      # device_count does not initialise the GPU
+    return max(1, min(world, n_dev)) if n_dev else world
 
 
 def host_threads(cap: int = 32) -> int:
@@ -36,15 +46,19 @@ def host_threads(cap: int = 32) -> int:
         cpus = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         cpus = os.cpu_count() or 1
-    if os.environ.get("CV_RANK_CPUS_PINNED") == "1":            # pin_rank_cpus already narrowed the affinity mask to this rank's share
+    if _PINNED:                                                 # pin_rank_cpus already narrowed the affinity mask to this rank's share
         return max(1, min(cap, cpus))
     return max(1, min(cap, cpus // local_world_size()))
 
 
 def pin_rank_cpus() -> list[int] | None:
     """Give every local rank its own contiguous block of the CPUs the job may use (in-process ``sched_setaffinity``; no
-    ``taskset`` / ``numactl`` wrapper, which would be an exec hop in front of the GPU process).  Off with CV_PIN_RANK_CPUS=0
-    or when the host has fewer CPUs than ranks.  Returns the block, or None when nothing was pinned."""
+    ``taskset`` / ``numactl`` wrapper, which would be an exec hop in front of the GPU process).  Called FIRST THING in
+    ``init_process_group`` -- before the HIP runtime, RCCL / gloo or OpenMP create their threads, which inherit the mask of the
+    thread that starts them -- and applied to every thread the process already has (``/proc/self/task``: ``sched_setaffinity(0)``
+    alone moves only the calling thread).  Off with CV_PIN_RANK_CPUS=0 or when the host has fewer CPUs than ranks.  Returns the
+    block, or None when nothing was pinned."""
+    global _PINNED
     lw = local_world_size()
     if lw <= 1 or os.environ.get("CV_PIN_RANK_CPUS", "1") == "0" or not hasattr(os, "sched_setaffinity"):
         return None
@@ -55,7 +69,15 @@ def pin_rank_cpus() -> list[int] | None:
     lr = int(os.environ.get("LOCAL_RANK", "0")) % lw
     mine = cpus[lr * per:(lr + 1) * per]
     os.sched_setaffinity(0, mine)
-    os.environ["CV_RANK_CPUS_PINNED"] = "1"
+    try:
+        for tid in os.listdir("/proc/self/task"):                # threads that already exist (interpreter helpers, BLAS pools)
+            try:
+                os.sched_setaffinity(int(tid), mine)
+            except (OSError, ValueError):
+                pass
+    except OSError:
+        pass
+    _PINNED = True
     return mine
 
 
@@ -83,6 +105,8 @@ def init_process_group(backend: str | None = None) -> tuple[int, int, torch.devi
     host may outnumber its GPUs (rank -> device ``LOCAL_RANK % device_count``).  With several ranks per host every rank is
     pinned to its share of the CPUs and torch's intra-op pool is sized to it (``host_threads``)."""
     rank, world, local = env_world()
+    if local_world_size() > 1:
+        pin_rank_cpus()                                           # before any runtime creates its threads (they inherit the mask)
     backend = backend or os.environ.get("CV_DIST_BACKEND") or None
     use_gpu = torch.cuda.is_available()
     if use_gpu:
@@ -102,7 +126,6 @@ def init_process_group(backend: str | None = None) -> tuple[int, int, torch.devi
             kwargs["device_id"] = device
         dist.init_process_group(backend, rank=rank, world_size=world, **kwargs)
     if local_world_size() > 1:
-        pin_rank_cpus()
         torch.set_num_threads(host_threads())
     return rank, world, device
 

@@ -925,11 +925,19 @@ static hipError_t prepare_halo() {
 #ifndef CV_HALO_TH64
 #define CV_HALO_TH64 16                       // patch rows of the 64-channel tile: 16 (single halo buffer, 68 KB) | 8 (double buffered, 72 KB)
 #endif
-#define CV_FOR_EACH_HALO(X, T)                \
+#define CV_FOR_EACH_HALO_MAIN(X, T)           \
     X(T, 64, CV_HALO_TH64, 1, 4, 1, CV_HALO_NSW64, 0)    \
     X(T, 128, 16, 2, 8, 1, CV_HALO_NSW128, 0) \
     X(T, 128, 16, 2, 8, 1, 3, 8)              \
     X(T, 64, 16, 1, 4, 1, 3, 8)
+// round 4: the 64-channel tile over an 8 x 16 patch (double-buffered halo, 72 KB, two workgroups per CU -- round 1's tile) next to the
+// production 16 x 16 one, for launches whose 16 x 16 patches number fewer than the chip can hold (single boards: 128 tiles on 256
+// CUs): twice the workgroups for the same work
+#if CV_HALO_TH64 == 16
+#define CV_FOR_EACH_HALO(X, T) CV_FOR_EACH_HALO_MAIN(X, T) X(T, 64, 8, 1, 4, 1, 3, 0)
+#else
+#define CV_FOR_EACH_HALO(X, T) CV_FOR_EACH_HALO_MAIN(X, T)
+#endif
 
 hipError_t conv_halo_prepare() {
     hipError_t e;
@@ -958,10 +966,13 @@ bool conv_halo_supported(int ct, int Ho, int Wo) {
     return (ct == 128 || (ct == 64 && allow64)) && Ho % 16 == 0 && Wo % 16 == 0;
 }
 
-hipError_t conv_halo_launch(int ct, int dt, const ConvParams& p, int n_images, hipStream_t stream) {
+bool conv_halo_has_th8(int ct) { return ct == 64 && CV_HALO_TH64 == 16; }
+
+hipError_t conv_halo_launch(int ct, int dt, const ConvParams& p, int n_images, hipStream_t stream, int th) {
     const int img = (p.Ho == 8 && p.Wo == 8) ? 8 : 0;
+    if (img || !(th == 8 && conv_halo_has_th8(ct))) th = ct == 64 ? CV_HALO_TH64 : 16;
 #define X(T, CT, TH, WGC, NW, TPS, NSW, IMG) \
-    if (ct == CT && img == IMG) return launch_halo<T, CT, TH, WGC, NW, TPS, NSW, IMG>(p, n_images, stream);
+    if (ct == CT && img == IMG && (IMG != 0 || th == TH)) return launch_halo<T, CT, TH, WGC, NW, TPS, NSW, IMG>(p, n_images, stream);
     if (dt == kF16) { CV_FOR_EACH_HALO(X, half_t) } else if (dt == kSplit) { CV_FOR_EACH_HALO(X, split_t) } else { CV_FOR_EACH_HALO(X, float) }
 #undef X
     return hipErrorInvalidValue;

@@ -28,7 +28,9 @@ int conv_cfg_ct(int cfg);
 hipError_t conv_halo_prepare();
 bool conv_halo_supported(int ct, int Ho, int Wo);
 bool conv_halo_can_fuse_first_layer(int ct, int dt);     // ConvParams::f0_* (the 64-channel single-halo tile, split-f16)
-hipError_t conv_halo_launch(int ct, int dt, const ConvParams& p, int n_images, hipStream_t stream);
+bool conv_halo_has_th8(int ct);                          // the 8 x 16 patch variant of the tile exists (64-channel tile)
+// th: patch rows of the tile, 16 (default) or 8 (twice the workgroups: launches with few patches)
+hipError_t conv_halo_launch(int ct, int dt, const ConvParams& p, int n_images, hipStream_t stream, int th = 16);
 int conv_cfg_pt(int cfg);
 
 }  // namespace cv

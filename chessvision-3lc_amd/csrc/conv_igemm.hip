@@ -428,26 +428,39 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvParams p)
 // One lane = 8 consecutive channels of one output pixel (one 16 / 32-byte store unit).  Deterministic: the summation order is the
 // split index, whatever order the first pass's workgroups finished in.
 template <typename T>
-__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParams p) {
+__global__ __launch_bounds__(64) void conv_splitk_reduce_kernel(const ConvParams p) {
     constexpr int UN = 8;
     const int upp = p.rows / UN;                          // units per pixel (rows is a multiple of 16)
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long idx = (long long)blockIdx.x * 64 + threadIdx.x;
     if (idx >= (long long)p.M * upp) return;
     const int pix = (int)(idx / upp), cu = (int)(idx - (long long)pix * upp);
     const int row = cu * UN;
     float w[UN];
     {
+        // four running sums over the splits ks = 0, 1, 2, 3 (mod 4), combined as (s0 + s1) + (s2 + s3): a FIXED order, and four
+        // independent load streams in flight per lane (one dependent chain of ksplit loads is latency-bound: 35 us at 36 splits)
         const float* src = p.partial + (size_t)pix * p.prow + row;
         const size_t sstride = (size_t)p.M * p.prow;
-        f4 a = *reinterpret_cast<const f4*>(src), b = *reinterpret_cast<const f4*>(src + 4);
-        for (int ks = 1; ks < p.ksplit; ++ks) {
-            a += *reinterpret_cast<const f4*>(src + ks * sstride);
-            b += *reinterpret_cast<const f4*>(src + ks * sstride + 4);
+        f4 a[4], b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a[j] = f4{0.f, 0.f, 0.f, 0.f}; b[j] = f4{0.f, 0.f, 0.f, 0.f}; }
+        int ks = 0;
+        for (; ks + 4 <= p.ksplit; ks += 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[j] += *reinterpret_cast<const f4*>(src + (ks + j) * sstride);
+                b[j] += *reinterpret_cast<const f4*>(src + (ks + j) * sstride + 4);
+            }
         }
+        for (int j = 0; ks < p.ksplit; ++ks, ++j) {
+            a[j] += *reinterpret_cast<const f4*>(src + ks * sstride);
+            b[j] += *reinterpret_cast<const f4*>(src + ks * sstride + 4);
+        }
+        const f4 sa_ = (a[0] + a[1]) + (a[2] + a[3]), sb_ = (b[0] + b[1]) + (b[2] + b[3]);
         const f4 sa = *reinterpret_cast<const f4*>(p.scale + row), sb = *reinterpret_cast<const f4*>(p.scale + row + 4);
         const f4 ha = *reinterpret_cast<const f4*>(p.shift + row), hb = *reinterpret_cast<const f4*>(p.shift + row + 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { w[j] = a[j] * sa[j] + ha[j]; w[4 + j] = b[j] * sb[j] + hb[j]; }
+        for (int j = 0; j < 4; ++j) { w[j] = sa_[j] * sa[j] + ha[j]; w[4 + j] = sb_[j] * sb[j] + hb[j]; }
     }
     const int HoWo = p.Ho * p.Wo;
     const int n = pix / HoWo;
@@ -500,7 +513,7 @@ static hipError_t launch_one(const ConvParams& p, hipStream_t stream) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || splits == 1) return e;
     const long long units = (long long)p.M * (p.rows / 8);
-    hipLaunchKernelGGL(conv_splitk_reduce_kernel<T>, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(conv_splitk_reduce_kernel<T>, dim3((unsigned)((units + 63) / 64)), dim3(64), 0, stream, p);
     return hipGetLastError();
 }
 

@@ -313,11 +313,11 @@ struct Knobs {
     // split-K for launches that cannot fill the chip (single boards, the 64-square classifier batch; r04_tuning.md):
     //   splitk            0 = off
     //   splitk_max_tiles  launches with at least this many output tiles run unsplit
-    //   splitk_target     workgroups aimed for (2 per CU)
-    //   splitk_min_stages K stages (128 bytes of K per row) every split keeps at least
+    //   splitk_target     workgroups the chip runs at once (2 per CU): more than that and the K loops queue behind each other
     int splitk = env_int("CV_SPLITK", 1), splitk_max_tiles = env_int("CV_SPLITK_MAX_TILES", 192);
-    int splitk_target = env_int("CV_SPLITK_TARGET", 512), splitk_min_stages = env_int("CV_SPLITK_MIN_STAGES", 4);
+    int splitk_target = env_int("CV_SPLITK_TARGET", 512);
     int splitk_force = env_int("CV_SPLITK_FORCE", 0);   // tests: this many splits on every launch that can take them
+    int halo_th8 = env_int("CV_HALO_TH8", 1), halo_th8_max_tiles = env_int("CV_HALO_TH8_MAX_TILES", 384);
 };
 static const Knobs& knobs() {
     static const Knobs k;
@@ -445,6 +445,10 @@ size_t Engine::workspace_bytes() const {
     return total;
 }
 
+static bool halo_th8_for(const ConvLayer& L, const ConvParams& p, int ct, int Ho, bool fused) {
+    return !fused && Ho != 8 && conv_halo_has_th8(ct) && knobs().halo_th8 && blocks_for(L.rows, p.M, ct, 256) < knobs().halo_th8_max_tiles;
+}
+
 Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, const TensorRef* res, bool relu,
                         hipStream_t s, const Head* head, const TensorRef* pool_out, const Fuse0* fuse0) {
     if (x.C != L.cinPad) return fail(1, L.name + ": input slice has " + std::to_string(x.C) + " channels, layer packs " + std::to_string(L.cinPad));
@@ -520,11 +524,25 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
     if (knobs().splitk && !head && !fuse0 && !calibrating) {
         const int64_t tiles_igemm = blocks_for(L.rows, p.M, conv_cfg_ct(cfg), conv_cfg_pt(cfg));
         const int64_t tiles_now = halo ? blocks_for(L.rows, p.M, ct, 256) : tiles_igemm;
+        const double split_bytes = 2.0 * (double)p.M * (double)p.nCt * conv_cfg_ct(cfg) * sizeof(float);   // one split's partials, written + read
         int want = 1;
-        if (knobs().splitk_force > 1) want = knobs().splitk_force;
-        else if (tiles_now < knobs().splitk_max_tiles) want = (int)((knobs().splitk_target + tiles_igemm / 2) / tiles_igemm);
-        want = std::min(want, L.nStages / std::max(1, knobs().splitk_min_stages));
-        while (want > 1 && (size_t)want * (size_t)p.M * (size_t)p.nCt * conv_cfg_ct(cfg) * sizeof(float) > ((size_t)256 << 20)) --want;
+        if (knobs().splitk_force > 1) want = std::min(knobs().splitk_force, L.nStages);
+        else if (tiles_now < knobs().splitk_max_tiles) {
+            // Cost model in microseconds, fitted to single-board launches on MI355X (profiles/r04_tuning.md step 2): a launch costs
+            // ~7 us before its first stage and after its last; a workgroup alone on its CU walks a 128-byte K stage in ~0.45 us
+            // (0.5 for the halo tile); a second pass costs another launch plus the partials through L2 / Infinity Cache at ~3 TB/s.
+            const double t_launch = 7.0, t_stage = 0.45, bw = 3.0e6;
+            const double t_unsplit = t_launch + (halo ? 0.5 : t_stage) * L.nStages;
+            double best = t_unsplit * 0.8;                            // a split must win clearly: it also costs the fused pool / two-per-CU overlap
+            for (int k = 2; k <= std::min(L.nStages, 64); ++k) {
+                const int kper = (L.nStages + k - 1) / k, ks = (L.nStages + kper - 1) / kper;
+                if (ks != k) continue;
+                const double waves = std::max(1.0, (double)(tiles_igemm * ks) / (double)knobs().splitk_target);
+                const double t = 2.0 * t_launch + t_stage * kper * waves + ks * split_bytes / bw;
+                if (t < best) { best = t; want = ks; }
+            }
+        }
+        while (want > 1 && (double)want * split_bytes / 2.0 > (double)((size_t)256 << 20)) --want;
         if (want > 1) {
             const int kper = (L.nStages + want - 1) / want;
             p.ksplit = (L.nStages + kper - 1) / kper;                 // every split non-empty
@@ -575,7 +593,7 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
                    ((double)L.macs_per_out_pixel() + (fuse0 ? fuse0->macs_per_pixel : 0.0)) * (double)p.M, s, b);
         const char* tn = dt == kF32 ? "float" : dt == kF16 ? "half_t" : "split_t";
         if (halo)
-            prof.back().kernel = std::string("conv3x3_halo_kernel<") + tn + "," + std::to_string(ct) + ",16x16" +
+            prof.back().kernel = std::string("conv3x3_halo_kernel<") + tn + "," + std::to_string(ct) + (halo_th8_for(L, p, ct, Ho, fuse0 != nullptr) ? ",8x16" : ",16x16") +
                                  (Ho == 8 ? ",IMG8" : "") + (fuse0 ? ",FUSE0" : "") + ">";   // template parameters only: a fused pool / 1x1 head is
                                                                                               // a run-time option of the same instantiation
         else
@@ -583,7 +601,9 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
                                  std::to_string(conv_cfg_pt(cfg)) + ",ring" + std::to_string(ns) + (L.shuffle ? ",shuffle" : "") +
                                  (p.ksplit > 1 ? ",splitK" + std::to_string(p.ksplit) : std::string()) + ">";
     }
-    hipError_t e = halo ? conv_halo_launch(ct, dt, p, x.N, s) : conv_igemm_launch(cfg, ns, dt, p, s);
+    // launches with fewer 16 x 16 patches than the chip holds workgroups (2 per CU) take the 8 x 16 patch: twice the workgroups
+    const int th = (halo && halo_th8_for(L, p, ct, Ho, fuse0 != nullptr)) ? 8 : 16;
+    hipError_t e = halo ? conv_halo_launch(ct, dt, p, x.N, s, th) : conv_igemm_launch(cfg, ns, dt, p, s);
     if (profiling) prof_end(s);
     if (stamp_dev) {
         std::vector<unsigned long long> h(stamp_n);

@@ -43,7 +43,10 @@ def _native_library():
     if not lib.exists():
         import __graft_entry__ as ge
 
-        ge.build()
+        try:
+            ge.build()
+        except Exception as exc:                             # no hipcc on this box: the pure-Python tests still run; the tests that
+            print(f"conftest: native build failed ({exc!r}); tests that load the library will fail on their own", file=sys.stderr)
     yield
 
 

@@ -156,8 +156,17 @@ def test_world2_process_images_sharded_returns_the_global_batch_in_order():
 
 def test_host_threads_divide_the_cpus_among_local_ranks(monkeypatch):
     cpus = len(os.sched_getaffinity(0))
-    monkeypatch.delenv("CV_RANK_CPUS_PINNED", raising=False)
+    monkeypatch.setattr(cvd, "_PINNED", False)
     monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
     assert cvd.host_threads() == max(1, min(32, cpus // 8))
     monkeypatch.setenv("LOCAL_WORLD_SIZE", "1")
     assert cvd.host_threads(cap=4) == min(4, cpus)
+    # a launcher that exports WORLD_SIZE only (multi-node): the share is sized by the GPUs of THIS host, never by the whole job;
+    # without GPUs (this test box) the world size is the only bound left
+    monkeypatch.delenv("LOCAL_WORLD_SIZE")
+    monkeypatch.setenv("WORLD_SIZE", "64")
+    import torch
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    assert cvd.local_world_size() == (min(64, n_dev) if n_dev else 64)
+    # the "pinned" flag is module state: a child process (which inherits the environment, not the module) divides again
+    assert "CV_RANK_CPUS_PINNED" not in os.environ

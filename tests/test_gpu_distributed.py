@@ -4,6 +4,7 @@ quadrangles, masks) must be staged through the rank's GPU and come back as host 
 from __future__ import annotations
 
 import os
+import socket
 import subprocess
 import sys
 from pathlib import Path
@@ -38,6 +39,9 @@ print("RCCL_HOST_STAGING_OK")
 
 def test_host_arrays_travel_through_rccl():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "CV_DIST_BACKEND")}
-    env.update(CV_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29531")
+    with socket.socket() as sock:                            # a free port of this box, not a fixed one that another job may hold
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env.update(CV_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     out = subprocess.run([sys.executable, "-c", SCRIPT.replace("ROOT", str(ROOT))], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "RCCL_HOST_STAGING_OK" in out.stdout, out.stderr[-3000:]

