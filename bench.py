@@ -162,6 +162,10 @@ def pipeline_e2e(dtype: str, n_boards: int = 256, n_checked: int = 8):
         cv = ChessVision(board_extractor_weights=str(pe), classifier_weights=str(pc), precision=dtype)
         images = [synthetic.board_photo(s) for s in range(n_boards)]
         cv.process_images(images[:96], fallback_quad=True, return_crops=False)   # warm-up (lazy model init, pinned buffers, workspace)
+        try:
+            latency = process_image_latency(cv)
+        except Exception as exc:                                                   # extra figure only
+            latency = {"error": repr(exc)}
         best, tm_best, res = None, None, None
         for _ in range(3):
             tm = {}
@@ -198,6 +202,7 @@ def pipeline_e2e(dtype: str, n_boards: int = 256, n_checked: int = 8):
                      "copies on side streams; stages: host seconds (*_s) and event-timed GPU milliseconds (*_ms) summed over the jobs"}
     if mixed is not None:
         block["classifier_fp16"] = mixed
+    block["latency"] = latency
     return block, images[:n_checked], res[:n_checked]
 
 
@@ -302,6 +307,70 @@ def classifier_fp16(eng_main, x, sq, B, rsd, args, device, cvd, oracle_out):
     return block
 
 
+def byte_kernel_rooflines(eng, device, n_boards=256):
+    """HBM roofline of the SURVEY section 8f byte kernels on the pipeline's job shape (n_boards 512x512 BGR photos resident in HBM):
+    algorithmic bytes (input once + outputs once) / event-timed launch / 8 TB/s.  Events are recorded on torch's current stream,
+    which is the stream the C ABI launches these kernels on."""
+    import numpy as np
+
+    from chessvision import synthetic
+    from chessvision.hip_backend import board_homographies
+
+    rng = np.random.default_rng(0)
+    base = np.stack([synthetic.board_photo(s) for s in range(8)])
+    imgs = torch.from_numpy(np.concatenate([base] * (n_boards // 8))).to(device)
+    quads = np.stack([np.array([[430, 40], [60, 55], [45, 440], [470, 450]], np.float32) + rng.uniform(-25, 25, (4, 2)).astype(np.float32)
+                      for _ in range(n_boards)])
+    inv = torch.from_numpy(board_homographies(quads).reshape(n_boards, 9)).pin_memory()
+
+    def timed(fn, iters=10):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize(device)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            fn()
+        b.record()
+        torch.cuda.synchronize(device)
+        return a.elapsed_time(b) / iters
+
+    out = {}
+    for name, fn, nbytes in (
+            ("resize_area_u8", lambda: eng.resize_area_u8(imgs, (256, 256)), n_boards * (512 * 512 * 3 + 256 * 256 * 3)),
+            ("extract_squares_u8", lambda: eng.extract_squares_u8(imgs, inv, want_boards=True), n_boards * (512 * 512 * 3 + 2 * 512 * 512))):
+        ms = timed(fn)
+        out[name] = {"bound": "hbm", "achieved": round(nbytes / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4), "launches": 1, "ms_per_step": round(ms, 4),
+                     "algorithmic_mb_per_launch": round(nbytes / 1e6, 2), "boards_per_launch": n_boards}
+    out["extract_squares_u8"]["note"] = ("warp + gray + flip + split incl. the rectified boards; ~75 integer + fp64 vector instructions per pixel "
+                                         "(OpenCV-exact double-precision coordinates): VALU-bound, not HBM-bound (DESIGN.md section 4)")
+    return out
+
+
+def process_image_latency(cv, iters=100):
+    """Median wall milliseconds of `ChessVision.process_image` -- the entry point the reference's Flask endpoint and eval script
+    call (cv_endpoint.py:159, evaluate.py:270) -- on 512x512 photos, warm, one call at a time (host image in, FEN out)."""
+    import numpy as np
+
+    from chessvision import synthetic
+
+    images = [synthetic.board_photo(1000 + s) for s in range(8)]
+    for im in images:
+        cv.process_image(im)
+    times, found = [], 0
+    for k in range(iters):
+        t0 = time.perf_counter()
+        r = cv.process_image(images[k % 8])
+        times.append((time.perf_counter() - t0) * 1e3)
+        found += int(r.position is not None)
+    a = np.array(times)
+    return {"process_image_ms_median": round(float(np.median(a)), 3), "process_image_ms_p10": round(float(np.percentile(a, 10)), 3),
+            "process_image_ms_p90": round(float(np.percentile(a, 90)), 3), "iters": iters, "boards_found": found,
+            "image": "512x512x3 uint8 on the host", "note": "UNet B=1 + ResNet-18 B=64 (split-K launches, hipGraph replay), C++ contours, "
+                                                              "device resize / warp; every call synchronises twice (mask, probabilities)"}
+
+
 def measure(eng, x, sq, steps, warmup, device, cvd, streams=None):
     """W warm-up steps, then exactly K timed steps bracketed by barrier + synchronize; returns (seconds, outputs of the last step)."""
     def step():
@@ -401,6 +470,67 @@ def rooflines(eng, x, sq, dtype, B, quiet=False):
     return roof, roof_hbm, launches, conv_ms, conv_n, all_ms
 
 
+def flatten_evidence(result):
+    """The driver's record of this line keeps `config`, `roofline` and `cpu_baseline` (scalar entries) and only the NAMES of the
+    other top-level blocks: the figures a reader needs to judge the run are therefore mirrored into those three as flat scalars."""
+    cfg, roof = result["config"], result["roofline"]
+
+    def pick(d, *path):
+        for k in path:
+            if not isinstance(d, dict) or k not in d:
+                return None
+            d = d[k]
+        return d
+
+    def put(dst, key, val):
+        if val is not None and not isinstance(val, (dict, list)):
+            dst[key] = val
+
+    put(cfg, "rccl_ranks_seen", result.get("rccl_ranks_seen"))
+    put(cfg, "dist_backend", result.get("dist_backend"))
+    put(cfg, "init_s_max_over_ranks", pick(result, "init_s", "max"))
+    put(cfg, "calibration_identical_across_ranks", pick(result, "calibration_sync", "identical_across_ranks"))
+    put(cfg, "sharding_gathered_in_order", pick(result, "sharding", "gathered_in_order"))
+    put(cfg, "parity_unet_logit_max_abs_err", pick(result, "parity_vs_oracle", "unet_logit_max_abs_err"))
+    put(cfg, "parity_resnet_logit_max_abs_err", pick(result, "parity_vs_oracle", "resnet_logit_max_abs_err"))
+    put(cfg, "parity_boards_checked", pick(result, "parity_vs_oracle", "boards_checked"))
+    put(cfg, "pipeline_e2e_boards_per_sec", pick(result, "pipeline_e2e", "boards_per_sec"))
+    if pick(result, "pipeline_e2e", "boards_per_sec") and result.get("value"):
+        cfg["pipeline_e2e_frac_of_resident_rate"] = round(result["pipeline_e2e"]["boards_per_sec"] / result["value"], 4)
+    put(cfg, "pipeline_e2e_fen_checked", pick(result, "pipeline_e2e", "fen_checked"))
+    put(cfg, "pipeline_e2e_fen_mismatches", pick(result, "pipeline_e2e", "fen_mismatches"))
+    put(cfg, "pipeline_e2e_board_byte_mismatches_vs_oracle", pick(result, "pipeline_e2e", "board_byte_mismatches_vs_oracle"))
+    put(cfg, "pipeline_e2e_prob_max_abs_err_vs_oracle", pick(result, "pipeline_e2e", "prob_max_abs_err_vs_oracle"))
+    put(cfg, "pipeline_e2e_fp16_classifier_boards_per_sec", pick(result, "pipeline_e2e", "classifier_fp16", "boards_per_sec"))
+    lat = pick(result, "pipeline_e2e", "latency")
+    if isinstance(lat, dict):
+        cfg["latency"] = lat                                     # the block itself ...
+        for k in ("process_image_ms_median", "process_image_ms_p10", "process_image_ms_p90"):
+            put(cfg, "latency_" + k, lat.get(k))                 # ... and its scalars, flat
+    for dt in ("f32", "f16"):
+        put(cfg, f"{dt}_boards_per_sec", pick(result, "by_dtype", dt, "value"))
+        put(cfg, f"{dt}_roofline_frac", pick(result, "by_dtype", dt, "roofline", "frac"))
+        put(cfg, f"{dt}_parity_unet_logit_max_abs_err", pick(result, "by_dtype", dt, "parity_vs_oracle", "unet_logit_max_abs_err"))
+    put(cfg, "classifier_fp16_step_boards_per_sec", pick(result, "classifier_fp16", "step_with_headline_unet", "boards_per_sec"))
+    put(cfg, "classifier_fp16_prob_max_abs_err", pick(result, "classifier_fp16", "parity_vs_oracle", "prob_max_abs_err"))
+    put(cfg, "bilinear_variant_boards_per_sec", pick(result, "by_variant", "bilinear", "value"))
+    put(cfg, "pipeline_e2e_ranks_whole_job_boards_per_sec", pick(result, "pipeline_e2e_ranks", "boards_per_sec_whole_job"))
+    for k in ("min", "mean", "max"):
+        put(cfg, f"pipeline_e2e_ranks_boards_per_sec_{k}", pick(result, "pipeline_e2e_ranks", "boards_per_sec_per_rank", k))
+    put(roof, "dominant_kernel", pick(roof, "dominant", "kernel"))
+    put(roof, "dominant_frac", pick(roof, "dominant", "frac"))
+    put(roof, "dominant_avg_launch_ms", pick(roof, "dominant", "avg_launch_ms"))
+    put(roof, "dominant_launches_per_step", pick(roof, "dominant", "launches_per_step"))
+    put(roof, "dominant_share_of_conv_time", pick(roof, "dominant", "share_of_conv_time"))
+    put(roof, "unet_conv_frac", pick(roof, "by_model", "unet", "frac"))
+    put(roof, "resnet18_conv_frac", pick(roof, "by_model", "resnet18", "frac"))
+    for name, blk in (result.get("roofline_hbm") or {}).items():
+        if isinstance(blk, dict) and "frac" in blk:
+            key = "hbm_" + "".join(c if c.isalnum() else "_" for c in name).strip("_")
+            roof[key + "_frac"] = blk["frac"]
+            roof[key + "_gbs"] = blk["achieved"]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -442,6 +572,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
 
     # ---- weights: rank 0 generates, one RCCL broadcast replicates ----
+    t_init = time.perf_counter()
     bilinear = args.unet_variant == "bilinear"
     uspec, rspec = synthetic.unet_spec(bilinear), synthetic.resnet18_spec()
     usd = cvd.broadcast_state_dict(synthetic.unet_state_dict(1, bilinear) if rank == 0 else None, uspec, device)
@@ -455,6 +586,9 @@ def main():
         return e
 
     eng = make_engine(args.dtype)
+    calibration = cvd.sync_calibration(eng, device)              # every rank computes with rank 0's tensor exponents
+    torch.cuda.synchronize(device)
+    init_s = cvd.stats_over_ranks(time.perf_counter() - t_init, device)   # weights: generate (rank 0) + broadcast + pack + calibrate
 
     # ---- synthetic inputs, resident in HBM before the timed region ----
     # ONE global batch of world * B boards, board i drawn from its own seed; rank r holds boards r::world of it (SURVEY.md
@@ -494,6 +628,11 @@ def main():
         return
 
     roof, roof_hbm, launches, conv_ms, conv_n, all_ms = rooflines(eng, x, sq, args.dtype, B)
+    if not args.no_extras:
+        try:
+            roof_hbm.update(byte_kernel_rooflines(eng, device))
+        except Exception as exc:
+            roof_hbm["byte_kernels_error"] = repr(exc)
     macs_board = eng.model_macs("unet") + 64 * eng.model_macs("resnet18")
     log(f"  step: {ms_per_step:.2f} ms; event-timed kernels {all_ms:.2f} ms; conv family {conv_ms:.2f} ms over {conv_n} launches")
 
@@ -519,6 +658,7 @@ def main():
                    "resnet_chunk": eff_resnet, "parallelism": f"replicas x{world}, boards sharded, weights RCCL-broadcast once",
                    "gflop_per_board": round(2 * macs_board / 1e9, 3)},
         "rccl_ranks_seen": rccl_ranks, "dist_backend": cvd.backend_name(),
+        "init_s": {k: round(v, 3) for k, v in init_s.items()}, "calibration_sync": calibration,
         "sharding": {"global_boards": world * B, "rule": "rank r owns boards r::world", "gathered_in_order": shard_ok},
         "host_threads_per_rank": cvd.host_threads(),
         "e2e_tflops": round(2 * macs_board * value / 1e12, 2),
@@ -589,6 +729,7 @@ def main():
                 e3.close()
             except Exception as exc:
                 result["by_variant"] = {"bilinear": {"error": repr(exc)}}
+    flatten_evidence(result)
     print(json.dumps(result), file=json_out, flush=True)
     cvd.barrier(device)
     cvd.shutdown()

@@ -362,13 +362,18 @@ class ChessVision:
         if pool is None:
             pool = self._copy_pool = ThreadPoolExecutor(max_workers=min(16, n_host), thread_name_prefix="cv-stage")
 
-        def segment(ids, slice_upload=False):               # host -> device (own stream), resize, UNet; masks start back
+        def upload(ids, slice_upload=False, gate=None):      # host -> pinned staging -> device, on the upload stream
+            """``gate``: an event of the compute stream the copy must not start before.  Jobs are uploaded TWO ahead, gated on the
+            end of the previous job's UNet, so that the 50 MB copy runs beside the (short, HBM-light) warp + classifier phase instead
+            of beside a UNet, whose launches it slows by 4-7 % (r03_tuning.md step 17, r04_tuning.md)."""
             t0 = time.perf_counter()
             shape = images[ids[0]].shape
             staged = pinned((len(ids),) + shape, torch.uint8)
             view = staged.numpy()
             with torch.cuda.stream(up):
                 batch = torch.empty((len(ids),) + shape, dtype=torch.uint8, device=dev)
+                if gate is not None:
+                    up.wait_event(gate)
             # the first job of a call is staged and uploaded in slices of 16 images (the upload of a slice overlaps the host copies
             # of the next one: nothing else hides that job's staging); later jobs are staged in one go behind the GPU's work
             step_ = 16 if slice_upload else len(ids)
@@ -387,15 +392,19 @@ class ChessVision:
             with torch.cuda.stream(up):
                 arrived = torch.cuda.Event()
                 arrived.record()
-            main.wait_event(arrived)
+            return {"ids": ids, "batch": batch, "staged": staged, "arrived": arrived}
+
+        def compute(u):                                      # resize, UNet on the compute stream; masks start back
+            ids, batch = u["ids"], u["batch"]
+            main.wait_event(u["arrived"])
             batch.record_stream(main)
             tm.setdefault("first_enqueue_s", time.time() - started)      # host time until the first kernel of the call is queued
             small = gpu_timed("resize_ms", lambda: eng.resize_area_u8(batch, (constants.INPUT_SIZE[1], constants.INPUT_SIZE[0])))
             lg, mk = gpu_timed("unet_ms", lambda: eng.unet_forward_u8(small, threshold=threshold, want_mask=True))
             done = torch.cuda.Event()
             done.record()
-            st = {"ids": ids, "batch": batch, "logits": pinned((len(ids), 256, 256), torch.float32),
-                  "masks": pinned((len(ids), 256, 256), torch.uint8), "ev": torch.cuda.Event(), "keep": (lg, mk, staged)}
+            st = {"ids": ids, "batch": batch, "logits": pinned((len(ids), 256, 256), torch.float32), "unet_done": done,
+                  "masks": pinned((len(ids), 256, 256), torch.uint8), "ev": torch.cuda.Event(), "keep": (lg, mk, u["staged"])}
             with torch.cuda.stream(down):
                 down.wait_event(done)
                 st["masks"].copy_(mk, non_blocking=True)     # masks first: the contour stage waits for them only
@@ -484,11 +493,22 @@ class ChessVision:
                 clock("wait_probs_s", t0)
             st["keep"] = st["keep2"] = None
 
-        # software pipeline over the jobs: segment(k+1) is enqueued before the host works on job k
-        seg = segment(jobs[0], slice_upload=True)
+        # software pipeline over the jobs: the UNet of job k+1 is enqueued before the host works on job k, and the upload of job k+2
+        # is issued behind the end of that UNet (CHESSVISION_PIPE_PREFETCH=1 restores round 3's schedule: upload k+1 beside UNet k)
+        prefetch = int(os.environ.get("CHESSVISION_PIPE_PREFETCH", "2"))
+        ups = {0: upload(jobs[0], slice_upload=True)}
+        seg = compute(ups.pop(0))                            # the first kernels are queued before anything else is staged
+        if prefetch >= 2 and len(jobs) > 1:
+            ups[1] = upload(jobs[1])                         # nothing to hide behind yet: beside the (short) first job's UNet
         cls = None
         for k in range(len(jobs)):
-            nxt = segment(jobs[k + 1]) if k + 1 < len(jobs) else None
+            nxt = None
+            if k + 1 < len(jobs):
+                if k + 1 not in ups:
+                    ups[k + 1] = upload(jobs[k + 1])
+                nxt = compute(ups.pop(k + 1))
+                if prefetch >= 2 and k + 2 < len(jobs):
+                    ups[k + 2] = upload(jobs[k + 2], gate=nxt["unet_done"])
             cur = classify(seg)
             if cls is not None:
                 finish(cls)

@@ -178,6 +178,29 @@ def broadcast_state_dict(state: Mapping[str, np.ndarray] | None, spec: Sequence[
     return unflatten_state(flat, spec)
 
 
+def sync_calibration(engine, device: torch.device, models: Sequence[str] = ("unet", "resnet18"), src: int = 0) -> dict:
+    """Make every rank compute with rank ``src``'s range calibration (the per-tensor power-of-two exponents the f16-based engines
+    choose at load time, ``HipEngine.export_calibration``): one small broadcast per model, imported on every rank.  The calibration
+    pass is deterministic, so the vectors normally agree already; the broadcast makes divergence IMPOSSIBLE instead of unlikely
+    (a rank with other exponents would still be correct to 1e-3 but no longer bit-identical to its peers).  Returns
+    {"models": ..., "changed_here": bool, "identical_across_ranks": bool}; a world of one is a no-op."""
+    report = {"models": list(models), "changed_here": False, "identical_across_ranks": True}
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not _forced()):
+        return report
+    cdev = _coll_device(device)
+    for model in models:
+        mine = torch.from_numpy(np.ascontiguousarray(engine.export_calibration(model), dtype=np.int32))
+        ref = mine.clone().to(cdev)
+        dist.broadcast(ref, src=src)
+        ref = ref.cpu()
+        same = torch.tensor([int(torch.equal(ref, mine))], dtype=torch.int32, device=cdev)
+        dist.all_reduce(same, op=dist.ReduceOp.MIN)
+        report["identical_across_ranks"] = report["identical_across_ranks"] and bool(same.item())
+        if engine.import_calibration(model, ref.numpy()):
+            report["changed_here"] = True
+    return report
+
+
 def all_gather_rows(local: torch.Tensor) -> torch.Tensor:
     """Concatenate equally-shaped per-rank result tensors along dim 0, rank-major."""
     if not dist.is_initialized() or (dist.get_world_size() == 1 and not _forced()):

@@ -22,7 +22,7 @@ import torch
 
 _LIB_NAME = "libchessvision_hip.so"
 PREC_F32, PREC_F16, PREC_F16X3, PREC_F16R = 0, 1, 2, 3
-ABI_VERSION = 2
+ABI_VERSION = 3
 _PRECISIONS = {"f32": PREC_F32, "fp32": PREC_F32, "float32": PREC_F32, "f16": PREC_F16, "fp16": PREC_F16,
                "float16": PREC_F16, "f16x3": PREC_F16X3, "split": PREC_F16X3, "f16r": PREC_F16R}
 _PREC_NAMES = {PREC_F32: "f32", PREC_F16: "f16", PREC_F16X3: "f16x3", PREC_F16R: "f16r"}
@@ -88,6 +88,8 @@ SYMBOLS = [
     ("cv_get_activation_exponent", _i, [_vp, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(_i)]),
     ("cv_profile_entry_bytes", _i, [_vp, _i, ctypes.POINTER(ctypes.c_double)]),
     ("cv_profile_entry_kernel", _i, [_vp, _i, ctypes.c_char_p, _i]),
+    ("cv_engine_export_calibration", _i, [_vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int32), _i, ctypes.POINTER(_i)]),
+    ("cv_engine_import_calibration", _i, [_vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int32), _i, ctypes.POINTER(_i)]),
     ("cv_board_homographies", _i, [_fp, _i, _i, _i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     ("cv_decode_positions", _i, [_fp, _i, _i, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int8),
                                  ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
@@ -294,6 +296,24 @@ class HipEngine:
         """Synchronise the current stream and raise ``HipBackendError`` naming the first layer that produced a non-finite
         value since the last check (f16 range exceeded, NaN in the input); re-arms the guard."""
         _check(self._lib.cv_engine_numeric_status(self._h, _stream_ptr(self.device)))
+
+    def export_calibration(self, model: str) -> np.ndarray:
+        """The load-time range calibration of ``model`` ("unet" | "resnet18") as an int32 vector (two exponents per tensor)."""
+        n = _i()
+        _check(self._lib.cv_engine_export_calibration(self._h, model.encode(), None, 0, ctypes.byref(n)))
+        out = np.zeros(n.value, dtype=np.int32)
+        _check(self._lib.cv_engine_export_calibration(self._h, model.encode(), out.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                                                      n.value, ctypes.byref(n)))
+        return out
+
+    def import_calibration(self, model: str, exponents: np.ndarray) -> bool:
+        """Set the tensor exponents of ``model`` (a vector from ``export_calibration`` of an engine with the same precision and
+        checkpoint layout); True when anything changed."""
+        e = np.ascontiguousarray(exponents, dtype=np.int32)
+        changed = _i()
+        _check(self._lib.cv_engine_import_calibration(self._h, model.encode(), e.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                                                      int(e.size), ctypes.byref(changed)))
+        return bool(changed.value)
 
     def workspace_bytes(self) -> int:
         v = ctypes.c_size_t()

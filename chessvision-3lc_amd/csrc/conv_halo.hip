@@ -87,7 +87,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(halo_wa
     const unsigned lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
     const int tilesX = IMG ? 1 : p.Wo / 16, tilesY = IMG ? 1 : p.Ho / TH;
     const int nImg = p.M / (p.Ho * p.Wo);
-    const int nCb = p.nStages / 9, nS = nCb * SPC;       // p.nStages counts (channel block, tap) pairs
+    // Split-K (single boards: a 16 x 16 feature map is ONE patch, so a deep layer has Cout/64 tiles and a K loop of hundreds of stages):
+    // the channel blocks of a tile's K loop are dealt to p.ksplit workgroups, p.kper blocks each; every workgroup leaves its raw f32
+    // accumulators in p.partial[split][pixel][channel] and conv_splitk_reduce_kernel (conv_igemm.hip) sums them in split order and runs
+    // the epilogue.  Plain launches only (not persistent, no fused producer, no packed images).
+    const int kSplits = (!PERSIST && !FUSE0 && IMG == 0 && p.ksplit > 1) ? p.ksplit : 1;
+    const int nCbAll = p.nStages / 9;                   // p.nStages counts (channel block, tap) pairs
+    int nCb = nCbAll, nS = nCb * SPC, cbBase = 0, ksCur = 0;
     const unsigned nTiles = (unsigned)((IMG ? (nImg + 3) / 4 : nImg * tilesX * tilesY) * p.nCt);
     // the tile the DMA side works on (in a persistent workgroup that is already the NEXT tile during an epilogue)
     int ctTile, tx, ty, n;
@@ -122,13 +128,26 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(halo_wa
         }
     };
     auto decode = [&](unsigned tile) __attribute__((always_inline)) {
-        ctTile = tile % p.nCt;
-        int pt = tile / p.nCt;
+        int pt;
+        if (kSplits > 1) {
+            // the patches of one (channel tile, K split) are neighbours: they stream the same weight slab through one L2
+            const int nPatch = nImg * tilesX * tilesY;
+            pt = tile % nPatch;
+            const int rest = tile / nPatch;
+            ctTile = rest % p.nCt;
+            ksCur = rest / p.nCt;
+            cbBase = ksCur * p.kper;
+            nCb = nCbAll - cbBase < p.kper ? nCbAll - cbBase : p.kper;
+            nS = nCb * SPC;
+        } else {
+            ctTile = tile % p.nCt;
+            pt = tile / p.nCt;
+        }
         tx = pt % tilesX; pt /= tilesX;
         ty = pt % tilesY;
         n = IMG ? 4 * (pt / tilesY) : pt / tilesY;      // (first) image of the tile
         hbase = (unsigned)((n * p.xHp + ty * TH) * p.xWp + tx * 16);
-        wsrc = p.w + (size_t)ctTile * p.nStages * WTAP + wi * 1024;
+        wsrc = p.w + ((size_t)ctTile * p.nStages + (size_t)cbBase * 9) * WTAP + wi * 1024;
         if constexpr (kHoistHalo) {
 #pragma unroll
             for (int i = 0; i < H; ++i) hoff[i] = halo_row_offset(i);
@@ -144,7 +163,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(halo_wa
     auto issue_halo = [&](int cb, int hb, auto i0_tag, auto n_tag) __attribute__((always_inline)) {          // pieces [I0, I0 + N) of this wave's H
         constexpr int I0 = decltype(i0_tag)::value, N = decltype(n_tag)::value;
         char* sH = halo + hb * HBYTES;
-        const char* const src = xsrc + cb * 128;        // wave-uniform base of this channel block
+        const char* const src = xsrc + (cbBase + cb) * 128;   // wave-uniform base of this channel block
         if constexpr (kHoistHalo) {
 #pragma unroll
             for (int i = I0; i < I0 + N && i < H; ++i) glds16s(src, hoff[i], sH + (i * NWI + wi) * 1024);
@@ -590,6 +609,17 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(halo_wa
         sc[i] = a[0]; sc[i + 1] = a[1]; sc[i + 2] = a[2]; sc[i + 3] = a[3];
         sh[i] = b[0]; sh[i + 1] = b[1]; sh[i + 2] = b[2]; sh[i + 3] = b[3];
     }
+    if (kSplits > 1) {
+        // raw accumulators -> partial[split][pixel][channel]; a lane's 16 channels are 64 contiguous bytes
+        float* const part = p.partial + (size_t)ksCur * p.M * p.prow + row0;
+#pragma unroll
+        for (int g = 0; g < FP; ++g) {
+            const size_t pix = ((size_t)eN * p.Ho + eTy * TH + wrow0 + g) * p.Wo + eTx * 16 + l15;
+#pragma unroll
+            for (int f = 0; f < FC; ++f) *reinterpret_cast<f4*>(part + pix * p.prow + f * 4) = acc[f][g];
+        }
+        return;
+    }
     T* const ybase = reinterpret_cast<T*>(p.y);
     const T* const rbase = reinterpret_cast<const T*>(p.res);
     // output pixel of (patch row wrow0 + g, lane l15): image, row origin, column
@@ -841,7 +871,9 @@ template <typename T, int CT, int TH> static constexpr bool halo_can_fuse0() { r
 
 template <typename T, int CT, int TH, int WGC, int NW, int TPS, int NSW, int IMG>
 static hipError_t launch_halo(const ConvParams& p, int n_images, hipStream_t stream) {
-    const int tiles = (IMG ? (n_images + 3) / 4 : n_images * (p.Ho / TH) * (p.Wo / 16)) * p.nCt;
+    const bool split = p.ksplit > 1;
+    if (split && (IMG != 0 || p.f0_x || !p.partial || p.kper < 1)) return hipErrorInvalidValue;
+    const int tiles = (IMG ? (n_images + 3) / 4 : n_images * (p.Ho / TH) * (p.Wo / 16)) * p.nCt * (split ? p.ksplit : 1);
     const size_t lds = halo_lds<CT, TH, NW, TPS, NSW, IMG>();
     if (p.f0_x) {
         if constexpr (halo_can_fuse0<T, CT, TH>() && IMG == 0) {
@@ -862,14 +894,14 @@ static hipError_t launch_halo(const ConvParams& p, int n_images, hipStream_t str
         // epilogue): CV_HALO_PERSIST64=1, launches of short K with many tiles only
         static const int on64 = [] { const char* v = std::getenv("CV_HALO_PERSIST64"); return v && *v ? std::atoi(v) : 0; }();
         static const int max_k64 = [] { const char* v = std::getenv("CV_HALO_PERSIST64_MAXK"); return v && *v ? std::atoi(v) : 36; }();
-        if (on64 && !p.head_w && !p.res && tiles >= 8 * g_halo_cus && p.nStages <= max_k64) {
+        if (on64 && !split && !p.head_w && !p.res && tiles >= 8 * g_halo_cus && p.nStages <= max_k64) {
             auto kern = conv3x3_halo_kernel<T, CT, TH, WGC, NW, TPS, NSW, IMG, true, false>;
             hipLaunchKernelGGL(kern, dim3((unsigned)(2 * g_halo_cus)), dim3(64 * NW), lds, stream, p);
             launched = true;
         }
     }
     if constexpr (NW == 8) {
-        if (halo_persistent<NW>() && tiles >= 4 * g_halo_cus && p.nStages <= max_k) {
+        if (halo_persistent<NW>() && !split && tiles >= 4 * g_halo_cus && p.nStages <= max_k) {
             auto kern = conv3x3_halo_kernel<T, CT, TH, WGC, NW, TPS, NSW, IMG, true, true>;
             const int grid = tiles < g_halo_cus ? tiles : g_halo_cus;
             hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * NW), lds, stream, p);

@@ -21,6 +21,7 @@ enum ConvCfg {            // <channel tile> x <pixel tile> of one 256-thread wor
 
 hipError_t conv_igemm_prepare();                                   // raise dynamic-LDS limits (once per device)
 hipError_t conv_igemm_launch(int cfg, int ns, int dt, const ConvParams& p, hipStream_t stream);   // ns = LDS ring depth 2|3
+hipError_t conv_splitk_reduce_launch(int dt, const ConvParams& p, hipStream_t stream);   // second pass of a split-K launch (ConvParams::ksplit > 1)
 bool conv_cfg_has_ns(int cfg, int ns);
 int conv_cfg_ct(int cfg);
 

@@ -426,76 +426,105 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvParams p)
 
 // ---- split-K second pass: sum the splits in order, then the same epilogue as above -----------------------------------
 // One lane = 8 consecutive channels of one output pixel (one 16 / 32-byte store unit).  Deterministic: the summation order is the
-// split index, whatever order the first pass's workgroups finished in.
-template <typename T>
+// split index, whatever order the first pass's workgroups finished in.  POOL: one lane = the same 8 channels of a 2 x 2 pixel
+// block, which also yields the block's max_pool2d(2) value (UNet encoder: the pooled copy next to the skip tensor, as the halo
+// kernel's fused epilogue writes it) -- a split launch then needs no stand-alone pooling kernel behind it.
+template <typename T, bool POOL>
 __global__ __launch_bounds__(64) void conv_splitk_reduce_kernel(const ConvParams p) {
     constexpr int UN = 8;
+    constexpr int NPX = POOL ? 4 : 1;
     const int upp = p.rows / UN;                          // units per pixel (rows is a multiple of 16)
     const long long idx = (long long)blockIdx.x * 64 + threadIdx.x;
-    if (idx >= (long long)p.M * upp) return;
-    const int pix = (int)(idx / upp), cu = (int)(idx - (long long)pix * upp);
+    const long long nblk = POOL ? (long long)p.M / 4 : (long long)p.M;
+    if (idx >= nblk * upp) return;
+    const int blk = (int)(idx / upp), cu = (int)(idx - (long long)blk * upp);
     const int row = cu * UN;
-    float w[UN];
-    {
-        // four running sums over the splits ks = 0, 1, 2, 3 (mod 4), combined as (s0 + s1) + (s2 + s3): a FIXED order, and four
-        // independent load streams in flight per lane (one dependent chain of ksplit loads is latency-bound: 35 us at 36 splits)
-        const float* src = p.partial + (size_t)pix * p.prow + row;
-        const size_t sstride = (size_t)p.M * p.prow;
-        f4 a[4], b[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { a[j] = f4{0.f, 0.f, 0.f, 0.f}; b[j] = f4{0.f, 0.f, 0.f, 0.f}; }
-        int ks = 0;
-        for (; ks + 4 <= p.ksplit; ks += 4) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                a[j] += *reinterpret_cast<const f4*>(src + (ks + j) * sstride);
-                b[j] += *reinterpret_cast<const f4*>(src + (ks + j) * sstride + 4);
-            }
-        }
-        for (int j = 0; ks < p.ksplit; ++ks, ++j) {
-            a[j] += *reinterpret_cast<const f4*>(src + ks * sstride);
-            b[j] += *reinterpret_cast<const f4*>(src + ks * sstride + 4);
-        }
-        const f4 sa_ = (a[0] + a[1]) + (a[2] + a[3]), sb_ = (b[0] + b[1]) + (b[2] + b[3]);
-        const f4 sa = *reinterpret_cast<const f4*>(p.scale + row), sb = *reinterpret_cast<const f4*>(p.scale + row + 4);
-        const f4 ha = *reinterpret_cast<const f4*>(p.shift + row), hb = *reinterpret_cast<const f4*>(p.shift + row + 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { w[j] = sa_[j] * sa[j] + ha[j]; w[4 + j] = sb_[j] * sb[j] + hb[j]; }
-    }
     const int HoWo = p.Ho * p.Wo;
-    const int n = pix / HoWo;
-    const int rem = pix - n * HoWo;
-    const int oy = rem / p.Wo;
-    const int ox = rem - oy * p.Wo;
-    unsigned ob = p.shuffle ? (unsigned)((n * p.yHp + 2 * oy + 1) * p.yWp + 2 * ox + 1) : (unsigned)((n * p.yHp + oy + 1) * p.yWp + ox + 1);
-    int co = row;
-    if (p.shuffle) {                                     // rows are (dy, dx, co): k2 s2 transposed conv
-        const int grp = row / p.Cout;
-        co = row - grp * p.Cout;
-        ob += (unsigned)((grp >> 1) * p.yWp + (grp & 1));
+    int n, oy, ox;
+    if constexpr (POOL) {
+        const int qw = p.Wo >> 1, qhw = (p.Ho >> 1) * qw;
+        n = blk / qhw;
+        const int rem = blk - n * qhw;
+        oy = 2 * (rem / qw);
+        ox = 2 * (rem - (rem / qw) * qw);
+    } else {
+        n = blk / HoWo;
+        const int rem = blk - n * HoWo;
+        oy = rem / p.Wo;
+        ox = rem - oy * p.Wo;
     }
+    const f4 sa = *reinterpret_cast<const f4*>(p.scale + row), sb = *reinterpret_cast<const f4*>(p.scale + row + 4);
+    const f4 ha = *reinterpret_cast<const f4*>(p.shift + row), hb = *reinterpret_cast<const f4*>(p.shift + row + 4);
     T* const ybase = reinterpret_cast<T*>(p.y);
     const T* const rbase = reinterpret_cast<const T*>(p.res);
-    if (rbase) {
-        bool done = false;
-        if constexpr (__is_same(T, half_t)) {
-            if (p.res_f32) {
-                f4 raw[2];
-                trunk32_fetch(reinterpret_cast<const float*>(p.res) + (size_t)ob * p.rCs + p.rCoff + co, raw);
-                trunk32_add_raw(raw, w, p.res_mul);
-                done = true;
-            }
-        }
-        if (!done) OutVec<T, UN>::add(rbase + (size_t)ob * p.rCs + p.rCoff + co, p.rCoff + co, w, p.res_mul);
-    }
-    if (p.relu) {
-#pragma unroll
-        for (int j = 0; j < UN; ++j) w[j] = w[j] > 0.f ? w[j] : 0.f;
-    }
     float bad = 0.f;
-    OutVec<T, UN>::store(ybase + (size_t)ob * p.yCs + p.yCoff + co, p.yCoff + co, w, bad);
-    if constexpr (__is_same(T, half_t)) {
-        if (p.y32) trunk32_store(reinterpret_cast<float*>(p.y32) + (size_t)ob * p.yCs + p.yCoff + co, w);
+    float best[UN];
+#pragma unroll
+    for (int j = 0; j < UN; ++j) best[j] = -3.0e38f;
+#pragma unroll
+    for (int px = 0; px < NPX; ++px) {
+        const int yy = oy + (px >> 1), xx = ox + (px & 1);
+        const int pix = (n * p.Ho + yy) * p.Wo + xx;
+        float w[UN];
+        {
+            // four running sums over the splits ks = 0, 1, 2, 3 (mod 4), combined as (s0 + s1) + (s2 + s3): a FIXED order, and four
+            // independent load streams in flight per lane (one dependent chain of ksplit loads is latency-bound: 35 us at 36 splits)
+            const float* src = p.partial + (size_t)pix * p.prow + row;
+            const size_t sstride = (size_t)p.M * p.prow;
+            f4 a[4], b[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a[j] = f4{0.f, 0.f, 0.f, 0.f}; b[j] = f4{0.f, 0.f, 0.f, 0.f}; }
+            int ks = 0;
+            for (; ks + 4 <= p.ksplit; ks += 4) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a[j] += *reinterpret_cast<const f4*>(src + (ks + j) * sstride);
+                    b[j] += *reinterpret_cast<const f4*>(src + (ks + j) * sstride + 4);
+                }
+            }
+            for (int j = 0; ks < p.ksplit; ++ks, ++j) {
+                a[j] += *reinterpret_cast<const f4*>(src + ks * sstride);
+                b[j] += *reinterpret_cast<const f4*>(src + ks * sstride + 4);
+            }
+            const f4 sa_ = (a[0] + a[1]) + (a[2] + a[3]), sb_ = (b[0] + b[1]) + (b[2] + b[3]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { w[j] = sa_[j] * sa[j] + ha[j]; w[4 + j] = sb_[j] * sb[j] + hb[j]; }
+        }
+        unsigned ob = p.shuffle ? (unsigned)((n * p.yHp + 2 * yy + 1) * p.yWp + 2 * xx + 1) : (unsigned)((n * p.yHp + yy + 1) * p.yWp + xx + 1);
+        int co = row;
+        if (p.shuffle) {                                     // rows are (dy, dx, co): k2 s2 transposed conv
+            const int grp = row / p.Cout;
+            co = row - grp * p.Cout;
+            ob += (unsigned)((grp >> 1) * p.yWp + (grp & 1));
+        }
+        if (rbase) {
+            bool done = false;
+            if constexpr (__is_same(T, half_t)) {
+                if (p.res_f32) {
+                    f4 raw[2];
+                    trunk32_fetch(reinterpret_cast<const float*>(p.res) + (size_t)ob * p.rCs + p.rCoff + co, raw);
+                    trunk32_add_raw(raw, w, p.res_mul);
+                    done = true;
+                }
+            }
+            if (!done) OutVec<T, UN>::add(rbase + (size_t)ob * p.rCs + p.rCoff + co, p.rCoff + co, w, p.res_mul);
+        }
+        if (p.relu) {
+#pragma unroll
+            for (int j = 0; j < UN; ++j) w[j] = w[j] > 0.f ? w[j] : 0.f;
+        }
+        OutVec<T, UN>::store(ybase + (size_t)ob * p.yCs + p.yCoff + co, p.yCoff + co, w, bad);
+        if constexpr (__is_same(T, half_t)) {
+            if (p.y32) trunk32_store(reinterpret_cast<float*>(p.y32) + (size_t)ob * p.yCs + p.yCoff + co, w);
+        }
+        if constexpr (POOL) {
+#pragma unroll
+            for (int j = 0; j < UN; ++j) best[j] = best[j] > w[j] ? best[j] : w[j];
+        }
+    }
+    if constexpr (POOL) {
+        const unsigned qb = (unsigned)((n * p.pHp + (oy >> 1) + 1) * p.pWp + (ox >> 1) + 1);
+        OutVec<T, UN>::store(reinterpret_cast<T*>(p.pool_y) + (size_t)qb * p.pCs + p.pCoff + row, p.pCoff + row, best, bad);
     }
     report_bad(p, bad);
 }
@@ -510,10 +539,21 @@ static hipError_t launch_one(const ConvParams& p, hipStream_t stream) {
     const int splits = p.ksplit > 1 ? p.ksplit : 1;
     auto kern = conv_igemm_kernel<T, CT, PT, WGC, NS, NW, SEP>;
     hipLaunchKernelGGL(kern, dim3((unsigned)(nPt * p.nCt * splits)), dim3(64 * NW), lds, stream, p);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess || splits == 1) return e;
-    const long long units = (long long)p.M * (p.rows / 8);
-    hipLaunchKernelGGL(conv_splitk_reduce_kernel<T>, dim3((unsigned)((units + 63) / 64)), dim3(64), 0, stream, p);
+    return hipGetLastError();
+}
+
+// second pass of a split-K launch (either conv kernel): sums p.partial over the splits and runs the layer's epilogue
+hipError_t conv_splitk_reduce_launch(int dt, const ConvParams& p, hipStream_t stream) {
+    if (p.ksplit <= 1 || !p.partial) return hipErrorInvalidValue;
+    const bool pool = p.pool_y != nullptr;                 // fused 2x2 max-pool: even output extent, no pixel shuffle (checked by the engine)
+    if (pool && (p.shuffle || (p.Ho & 1) || (p.Wo & 1))) return hipErrorInvalidValue;
+    const long long units = (long long)(pool ? p.M / 4 : p.M) * (p.rows / 8);
+    const dim3 grid((unsigned)((units + 63) / 64)), block(64);
+#define CV_REDUCE(T) \
+    do { if (pool) hipLaunchKernelGGL((conv_splitk_reduce_kernel<T, true>), grid, block, 0, stream, p); \
+         else hipLaunchKernelGGL((conv_splitk_reduce_kernel<T, false>), grid, block, 0, stream, p); } while (0)
+    if (dt == kF16) CV_REDUCE(half_t); else if (dt == kSplit) CV_REDUCE(split_t); else CV_REDUCE(float);
+#undef CV_REDUCE
     return hipGetLastError();
 }
 

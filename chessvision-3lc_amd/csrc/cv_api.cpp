@@ -467,6 +467,48 @@ static int impl_cv_extract_squares_u8(cv_engine_t* eng, const uint8_t* images, i
     return CV_OK;
 }
 
+// range calibration as data: the per-tensor exponents of a model, in the fixed order of its activation list (two per tensor: the
+// tensor's exponent and the second half's exponent of a concatenated buffer)
+static int impl_cv_engine_calibration(cv_engine_t* eng, const char* model, int32_t* exps, int capacity, int* count, int import) {
+    Status s = check_engine(eng);
+    if (!s.ok()) return finish(s);
+    if (!model || !count) return finish(fail(CV_ERR_INVALID, "null argument"));
+    std::lock_guard<std::mutex> lk(eng->impl.mu);
+    DeviceGuard g(eng->impl.device);
+    Engine& e = eng->impl;
+    std::vector<Activation*>* acts = nullptr;
+    if (std::strcmp(model, "unet") == 0 && e.unet) acts = &e.unet->acts;
+    else if (std::strcmp(model, "resnet18") == 0 && e.resnet) acts = &e.resnet->acts;
+    else return finish(fail(CV_ERR_STATE, "model must be a loaded 'unet' or 'resnet18'"));
+    const int n = 2 * (int)acts->size();
+    if (!import) {
+        *count = n;
+        if (!exps) return CV_OK;                                  // size query
+        if (capacity < n) return finish(fail(CV_ERR_INVALID, "calibration buffer too small"));
+        for (size_t i = 0; i < acts->size(); ++i) { exps[2 * i] = (*acts)[i]->exp; exps[2 * i + 1] = (*acts)[i]->exp2; }
+        return CV_OK;
+    }
+    if (!exps || capacity != n) return finish(fail(CV_ERR_INVALID, "calibration vector does not match this model (" + std::to_string(n) + " entries expected)"));
+    if (e.dt == kF32) return CV_OK;                               // the f32 engine stores real values: nothing to set
+    bool changed = false;
+    for (size_t i = 0; i < acts->size(); ++i) {
+        Activation* a = (*acts)[i];
+        if (exps[2 * i] < -60 || exps[2 * i] > 60 || exps[2 * i + 1] < -60 || exps[2 * i + 1] > 60) return finish(fail(CV_ERR_INVALID, "exponent out of range"));
+        if (a->fixed_exp) continue;
+        if (a->exp != exps[2 * i] || (a->split_c && a->exp2 != exps[2 * i + 1])) changed = true;
+        a->exp = exps[2 * i];
+        if (a->split_c) a->exp2 = exps[2 * i + 1];
+    }
+    if (changed) {                                                // the layers re-fold their epilogue constants at their next launch
+        hipError_t he = hipDeviceSynchronize();
+        if (he != hipSuccess) return finish(hip_fail(he, "cv_engine_import_calibration"));
+        e.graph_invalidate();
+        e.graph_clear();
+    }
+    *count = changed ? 1 : 0;
+    return CV_OK;
+}
+
 static int impl_cv_board_homographies(const float* quads, int n, int out_w, int out_h, double* forward, double* inverse) {
     if (n < 0 || out_w <= 0 || out_h <= 0 || (n > 0 && (!quads || (!forward && !inverse))))
         return finish(fail(CV_ERR_INVALID, "cv_board_homographies: bad argument"));
@@ -693,6 +735,19 @@ int cv_resize_area_u8(cv_engine_t* eng, const uint8_t* src, int n, int h, int w_
 int cv_extract_squares_u8(cv_engine_t* eng, const uint8_t* images, int n, int h, int w_, const double* inv_host,
                           uint8_t* squares, uint8_t* boards, void* stream) {
     return guarded("cv_extract_squares_u8", [&]() -> int { return impl_cv_extract_squares_u8(eng, images, n, h, w_, inv_host, squares, boards, stream); });
+}
+
+int cv_engine_export_calibration(cv_engine_t* eng, const char* model, int32_t* exps, int capacity, int* count) {
+    return guarded("cv_engine_export_calibration", [&]() -> int { return impl_cv_engine_calibration(eng, model, exps, capacity, count, 0); });
+}
+
+int cv_engine_import_calibration(cv_engine_t* eng, const char* model, const int32_t* exps, int count, int* changed) {
+    return guarded("cv_engine_import_calibration", [&]() -> int {
+        int ch = 0;
+        const int rc = impl_cv_engine_calibration(eng, model, const_cast<int32_t*>(exps), count, &ch, 1);
+        if (changed) *changed = ch;
+        return rc;
+    });
 }
 
 int cv_board_homographies(const float* quads, int n, int out_w, int out_h, double* forward, double* inverse) {

@@ -14,6 +14,8 @@ static int env_int(const char* name, int dflt);       // experiment switches, de
 
 // ---- error plumbing: thread-local message, never abort (SURVEY.md section 8b "Errors") -------------
 static thread_local std::string g_err;
+static thread_local bool g_capturing = false;
+bool& capture_flag() { return g_capturing; }
 void set_error(const std::string& msg) { g_err = msg; }
 const char* get_error() { return g_err.c_str(); }
 Status fail(int code, const std::string& msg) {
@@ -175,6 +177,7 @@ static inline void k_decode(int kgroup, int ntaps, int kk, int* tap, int* ci);
 // re-packed.  Happens during load-time calibration only.
 Status ConvLayer::set_input_split(int split, int delta, hipStream_t s) {
     if (split == in_split && delta == in_delta) return Status();
+    if (capture_flag()) return fail(1, name + ": weights re-packed during graph capture");
     if (Wk0.empty()) return fail(1, name + ": the halves of its concatenated input need different exponents but the layer kept no host weights");
     CV_HIP(hipStreamSynchronize(s));
     std::vector<float> Wk = Wk0;
@@ -193,6 +196,7 @@ Status ConvLayer::set_input_split(int split, int delta, hipStream_t s) {
 // Re-fold the tensor exponents into the device copies of the epilogue constants (only when they change: calibration).
 Status ConvLayer::set_exps(int in_exp_, int out_exp_, hipStream_t s) {
     if (in_exp_ == in_exp && out_exp_ == out_exp) return Status();
+    if (capture_flag()) return fail(1, name + ": epilogue constants re-folded during graph capture");
     CV_HIP(hipStreamSynchronize(s));                     // launches that still read the old constants
     std::vector<float> sc(h_scale.size()), sh(h_shift.size());
     for (size_t i = 0; i < sc.size(); ++i) {
@@ -268,6 +272,7 @@ Status ConvLayer::get_koff(const TensorRef& x, const int** chunks, const int** b
     const KoffKey key{x.W + 2, x.Cs, x.Coff};
     auto it = koff.find(key);
     if (it == koff.end()) {
+        if (capture_flag()) return fail(1, name + ": offset table created during graph capture");
         const int esz = dtype_size(dt);
         const int K = k * k * cinPad;
         const int pad = (k - 1) / 2;
@@ -318,6 +323,8 @@ struct Knobs {
     int splitk_target = env_int("CV_SPLITK_TARGET", 512);
     int splitk_force = env_int("CV_SPLITK_FORCE", 0);   // tests: this many splits on every launch that can take them
     int halo_th8 = env_int("CV_HALO_TH8", 1), halo_th8_max_tiles = env_int("CV_HALO_TH8_MAX_TILES", 384);
+    int splitk_halo = env_int("CV_SPLITK_HALO", 1);     // 3x3 layers on maps >= 16 x 16 split inside the halo kernel (by channel blocks)
+    int splitk_halo_stage_ns = env_int("CV_SPLITK_HALO_STAGE_NS", 500);
 };
 static const Knobs& knobs() {
     static const Knobs k;
@@ -387,8 +394,23 @@ bool calibration_enabled() {
 }
 
 // ---- engine --------------------------------------------------------------------------------------
-Engine::Engine() { layer_names.push_back("input tensor"); }
-Engine::~Engine() { prof_clear(); }
+Engine::Engine() {
+    layer_names.push_back("input tensor");
+    graphs_on = env_int("CV_GRAPH", 1) != 0;
+}
+Engine::~Engine() {
+    prof_clear();
+    graph_clear();
+    if (capture_stream) (void)hipStreamDestroy(capture_stream);
+}
+
+void Engine::graph_clear() {
+    for (auto& g : graphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    graphs.clear();
+}
 
 unsigned Engine::register_layer(const std::string& name) {
     for (size_t i = 0; i < layer_names.size(); ++i)
@@ -446,7 +468,8 @@ size_t Engine::workspace_bytes() const {
 }
 
 static bool halo_th8_for(const ConvLayer& L, const ConvParams& p, int ct, int Ho, bool fused) {
-    return !fused && Ho != 8 && conv_halo_has_th8(ct) && knobs().halo_th8 && blocks_for(L.rows, p.M, ct, 256) < knobs().halo_th8_max_tiles;
+    const int64_t wgs = blocks_for(L.rows, p.M, ct, 256) * (p.ksplit > 1 ? p.ksplit : 1);
+    return !fused && Ho != 8 && conv_halo_has_th8(ct) && knobs().halo_th8 && wgs < knobs().halo_th8_max_tiles;
 }
 
 Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, const TensorRef* res, bool relu,
@@ -515,54 +538,83 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
     const int ns = choose_ns(cfg, dt, L.rows, p.M, L.nStages);
     p.nCt = (L.rows + conv_cfg_ct(cfg) - 1) / conv_cfg_ct(cfg);
     // 3x3 / stride-1 layers whose patch grid divides the image keep the input patch in LDS across the nine taps
-    bool halo = L.k == 3 && L.stride == 1 && !L.shuffle && kbase != nullptr && L.nStages % 9 == 0 &&
-                knobs().halo && conv_halo_supported(ct, Ho, Wo) &&
-                blocks_for(L.rows, p.M, ct, 256) >= 128;              // single boards: 128x128 tiles give more workgroups
+    const bool halo_capable = L.k == 3 && L.stride == 1 && !L.shuffle && kbase != nullptr && L.nStages % 9 == 0 &&
+                              knobs().halo && conv_halo_supported(ct, Ho, Wo);
+    // few patches: the generic kernel's smaller tiles give more workgroups (with the 8 x 16 patch variant the halo kernel doubles its own)
+    bool halo = halo_capable && blocks_for(L.rows, p.M, ct, 256) >= ((conv_halo_has_th8(ct) && knobs().halo_th8 && Ho != 8) ? 64 : 128);
     // Split-K: a launch with fewer output tiles than CUs leaves most of the chip idle while every workgroup walks a long K loop
     // alone (UNet B=1 down4: 16 tiles x 288 stages; ResNet-18 layer4 at 64 squares: 8 tiles x 144 stages).  Such launches deal their
-    // K stages to several workgroups per tile (generic kernel) and a second pass sums the f32 partials in split order.
+    // K loop to several workgroups per tile -- the halo kernel by input-channel blocks (3x3 layers on maps of 16 x 16 and up: the
+    // patch stays resident, only weights stream), the generic kernel by 128-byte K stages (everything else) -- and a second pass sums
+    // the f32 partials in split order and runs the epilogue.
+    int split_kind = 0;                                               // 0 none | 1 generic kernel | 2 halo kernel
     if (knobs().splitk && !head && !fuse0 && !calibrating) {
         const int64_t tiles_igemm = blocks_for(L.rows, p.M, conv_cfg_ct(cfg), conv_cfg_pt(cfg));
-        const int64_t tiles_now = halo ? blocks_for(L.rows, p.M, ct, 256) : tiles_igemm;
-        const double split_bytes = 2.0 * (double)p.M * (double)p.nCt * conv_cfg_ct(cfg) * sizeof(float);   // one split's partials, written + read
+        const int64_t tiles_halo = blocks_for(L.rows, p.M, ct, 256);
+        const int64_t tiles_now = halo ? tiles_halo : tiles_igemm;
+        const bool halo_split_ok = halo_capable && Ho != 8 && knobs().splitk_halo;
+        const int nCb = L.nStages / 9;
+        const double bytes_igemm = 2.0 * (double)p.M * (double)p.nCt * conv_cfg_ct(cfg) * sizeof(float);   // one split's partials, written + read
+        const double bytes_halo = 2.0 * (double)p.M * (double)((L.rows + ct - 1) / ct * ct) * sizeof(float);
         int want = 1;
-        if (knobs().splitk_force > 1) want = std::min(knobs().splitk_force, L.nStages);
-        else if (tiles_now < knobs().splitk_max_tiles) {
-            // Cost model in microseconds, fitted to single-board launches on MI355X (profiles/r04_tuning.md step 2): a launch costs
-            // ~7 us before its first stage and after its last; a workgroup alone on its CU walks a 128-byte K stage in ~0.45 us
-            // (0.5 for the halo tile); a second pass costs another launch plus the partials through L2 / Infinity Cache at ~3 TB/s.
-            const double t_launch = 7.0, t_stage = 0.45, bw = 3.0e6;
+        if (knobs().splitk_force > 1) {
+            split_kind = halo_split_ok ? 2 : 1;
+            want = std::min(knobs().splitk_force, split_kind == 2 ? nCb : L.nStages);
+        } else if (tiles_now < knobs().splitk_max_tiles) {
+            // Cost model in microseconds, fitted to single-board launches on MI355X (profiles/r04_tuning.md): a launch costs ~7 us
+            // before its first stage and after its last; a workgroup alone on its CU walks a 128-byte K stage in ~0.45 us (generic
+            // 64x128 / 128x128 tiles; the halo tile does twice the MFMAs per stage in ~0.5 us); a second pass costs another launch plus
+            // the partials through L2 / Infinity Cache at ~3 TB/s.
+            const double t_launch = 7.0, t_stage = conv_cfg_ct(cfg) >= 128 ? 0.6 : 0.45, t_stage_halo = knobs().splitk_halo_stage_ns * 1e-3, bw = 3.0e6;
             const double t_unsplit = t_launch + (halo ? 0.5 : t_stage) * L.nStages;
-            double best = t_unsplit * 0.8;                            // a split must win clearly: it also costs the fused pool / two-per-CU overlap
+            double best = t_unsplit * 0.8;                            // a split must win clearly: it also costs the fused pool
             for (int k = 2; k <= std::min(L.nStages, 64); ++k) {
                 const int kper = (L.nStages + k - 1) / k, ks = (L.nStages + kper - 1) / kper;
                 if (ks != k) continue;
                 const double waves = std::max(1.0, (double)(tiles_igemm * ks) / (double)knobs().splitk_target);
-                const double t = 2.0 * t_launch + t_stage * kper * waves + ks * split_bytes / bw;
-                if (t < best) { best = t; want = ks; }
+                const double t = 2.0 * t_launch + t_stage * kper * waves + ks * bytes_igemm / bw;
+                if (t < best) { best = t; want = ks; split_kind = 1; }
             }
+            if (halo_split_ok)
+                for (int k = 2; k <= std::min(nCb, 64); ++k) {
+                    const int kper = (nCb + k - 1) / k, ks = (nCb + kper - 1) / kper;
+                    if (ks != k) continue;
+                    // the 8 x 16 patch doubles the workgroups (and halves a stage) while the chip is not full
+                    const bool th8 = conv_halo_has_th8(ct) && knobs().halo_th8 && tiles_halo * ks < knobs().halo_th8_max_tiles;
+                    const double wgs = (double)tiles_halo * ks * (th8 ? 2 : 1);
+                    const double waves = std::max(1.0, wgs / (double)knobs().splitk_target);
+                    const double t = 2.0 * t_launch + t_stage_halo * (th8 ? 0.6 : 1.0) * 9.0 * kper * waves + ks * bytes_halo / bw;
+                    if (t < best) { best = t; want = ks; split_kind = 2; }
+                }
         }
-        while (want > 1 && (double)want * split_bytes / 2.0 > (double)((size_t)256 << 20)) --want;
+        const double sb = split_kind == 2 ? bytes_halo : bytes_igemm;
+        while (want > 1 && (double)want * sb / 2.0 > (double)((size_t)256 << 20)) --want;
         if (want > 1) {
-            const int kper = (L.nStages + want - 1) / want;
-            p.ksplit = (L.nStages + kper - 1) / kper;                 // every split non-empty
+            const int units = split_kind == 2 ? nCb : L.nStages;      // what is dealt out: channel blocks (halo) / K stages (generic)
+            const int kper = (units + want - 1) / want;
+            p.ksplit = (units + kper - 1) / kper;                     // every split non-empty
             p.kper = kper;
-            p.prow = p.nCt * conv_cfg_ct(cfg);
+            p.prow = split_kind == 2 ? (L.rows + ct - 1) / ct * ct : p.nCt * conv_cfg_ct(cfg);
             const size_t need = (size_t)p.ksplit * (size_t)p.M * (size_t)p.prow * sizeof(float);
             if (splitk_ws.bytes < need) {
+                if (capture_flag()) return fail(1, "split-K buffer growth during graph capture");   // run_graphed falls back to an eager run
+                graph_invalidate();
                 CV_HIP(hipStreamSynchronize(s));                      // earlier launches may still read the old buffer
                 CV_TRY(splitk_ws.alloc(std::max(need, (size_t)32 << 20), false));
             }
             p.partial = reinterpret_cast<float*>(splitk_ws.ptr);
-            if (p.ksplit > 1) halo = false; else { p.ksplit = 0; p.partial = nullptr; }
-        }
+            if (p.ksplit > 1) halo = split_kind == 2;
+            else { p.ksplit = 0; p.partial = nullptr; split_kind = 0; }
+        } else split_kind = 0;
     }
+    if (halo && split_kind == 2) p.nCt = (L.rows + ct - 1) / ct;      // the halo kernel's channel tiles
     if (fuse0) {
         if (!halo || !conv_halo_can_fuse_first_layer(ct, dt)) { Status ns; ns.code = kNotFused; return ns; }   // caller runs the layers apart
         p.f0_x = fuse0->x; p.f0_u8 = fuse0->u8 ? 1 : 0; p.f0_w = fuse0->w; p.f0_scale = fuse0->scale; p.f0_shift = fuse0->shift;
         p.f0_in_mul = fuse0->in_mul;
     }
-    const bool fuse_pool = pool_out && halo && !head && knobs().fuse_pool;
+    // the pooled copy comes from the halo kernel's epilogue, or from the second pass of a split launch (either kernel)
+    const bool fuse_pool = pool_out && !head && knobs().fuse_pool && (p.ksplit > 1 ? (Ho % 2 == 0 && Wo % 2 == 0 && !L.shuffle) : halo);
     if (pool_out) {
         if (pool_out->H * 2 != y.H || pool_out->W * 2 != y.W || pool_out->C != y.C || pool_out->N != y.N)
             return fail(1, L.name + ": pooled output shape mismatch");
@@ -594,7 +646,7 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
         const char* tn = dt == kF32 ? "float" : dt == kF16 ? "half_t" : "split_t";
         if (halo)
             prof.back().kernel = std::string("conv3x3_halo_kernel<") + tn + "," + std::to_string(ct) + (halo_th8_for(L, p, ct, Ho, fuse0 != nullptr) ? ",8x16" : ",16x16") +
-                                 (Ho == 8 ? ",IMG8" : "") + (fuse0 ? ",FUSE0" : "") + ">";   // template parameters only: a fused pool / 1x1 head is
+                                 (Ho == 8 ? ",IMG8" : "") + (fuse0 ? ",FUSE0" : "") + (p.ksplit > 1 ? ",splitK" + std::to_string(p.ksplit) : std::string()) + ">";   // template parameters only: a fused pool / 1x1 head is
                                                                                               // a run-time option of the same instantiation
         else
             prof.back().kernel = std::string("conv_igemm_kernel<") + tn + "," + std::to_string(conv_cfg_ct(cfg)) + "x" +
@@ -604,6 +656,7 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
     // launches with fewer 16 x 16 patches than the chip holds workgroups (2 per CU) take the 8 x 16 patch: twice the workgroups
     const int th = (halo && halo_th8_for(L, p, ct, Ho, fuse0 != nullptr)) ? 8 : 16;
     hipError_t e = halo ? conv_halo_launch(ct, dt, p, x.N, s, th) : conv_igemm_launch(cfg, ns, dt, p, s);
+    if (e == hipSuccess && p.ksplit > 1) e = conv_splitk_reduce_launch(dt, p, s);
     if (profiling) prof_end(s);
     if (stamp_dev) {
         std::vector<unsigned long long> h(stamp_n);

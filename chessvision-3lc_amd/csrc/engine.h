@@ -16,6 +16,8 @@
 
 namespace cv {
 
+bool& capture_flag();                               // this thread is recording a forward pass into a hipGraph: nothing may allocate,
+                                                    // copy synchronously or synchronise (such paths fail, the caller re-runs eagerly)
 void set_error(const std::string& msg);
 const char* get_error();
 
@@ -199,6 +201,34 @@ class Engine {
     template <class Fwd> Status calibrate(const std::vector<Activation*>& acts, Fwd&& forward, hipStream_t s, const char* what);
     size_t workspace_bytes() const;
 
+    // hipGraph replay of small forward passes (the single-board shape: UNet B=1 = 21-33 launches, ResNet-18 B=64 = 19-27): the launch
+    // sequence of a forward that fits one chunk is captured once per (model, entry, batch, caller pointers) and replayed with one
+    // hipGraphLaunch.  A captured launch holds workspace / split-K / weight pointers by value, so every cached graph carries the
+    // `graph_epoch` it was captured in and anything that re-allocates or re-folds such memory bumps the epoch (workspace growth,
+    // split-K buffer growth, exponent changes, offset tables created on first use).  CV_GRAPH=0 switches the replay off.
+    struct GraphKey {
+        int model = 0, n = 0, flags = 0;                  // model 0 = UNet, 1 = ResNet-18; flags: u8 entry / softmax
+        const void* x = nullptr; void* out = nullptr; void* mask = nullptr;
+        unsigned thr_bits = 0;
+        bool operator==(const GraphKey& o) const {
+            return model == o.model && n == o.n && flags == o.flags && x == o.x && out == o.out && mask == o.mask && thr_bits == o.thr_bits;
+        }
+    };
+    struct GraphEntry {
+        GraphKey key;
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;                  // null: the key was seen once (its first call ran eagerly and warmed lazy state)
+        uint64_t epoch = 0, last_use = 0, hits = 0;
+    };
+    std::vector<GraphEntry> graphs;
+    uint64_t graph_epoch = 0, graph_clock = 0;
+    int graph_wasted = 0;                               // captures evicted without a single replay: callers whose pointers never repeat
+    bool graphs_on = true;
+    hipStream_t capture_stream = nullptr;
+    void graph_invalidate() { ++graph_epoch; }
+    void graph_clear();
+    template <class Run> Status run_graphed(const GraphKey& key, hipStream_t s, Run&& run);
+
     // profiling (cv_profile_convs)
     bool profiling = false;
     std::vector<ProfileEntry> prof;
@@ -272,6 +302,64 @@ Status Engine::calibrate(const std::vector<Activation*>& acts, Fwd&& forward, hi
         if (!changed) return Status();
     }
     return fail(1, std::string(what) + ": activation range calibration did not converge (non-finite weights or activations beyond f32?)");
+}
+
+// Replay `run` (a launch sequence on the stream it is handed; no allocation, no synchronisation once warmed) through a cached graph.
+template <class Run>
+Status Engine::run_graphed(const GraphKey& key, hipStream_t s, Run&& run) {
+    if (!graphs_on || profiling || calibrating) return run(s);
+    ++graph_clock;
+    GraphEntry* hit = nullptr;
+    for (auto& g : graphs)
+        if (g.key == key) { hit = &g; break; }
+    if (hit && hit->exec && hit->epoch == graph_epoch) {
+        hit->last_use = graph_clock; ++hit->hits;
+        CV_HIP(hipGraphLaunch(hit->exec, s));
+        return Status();
+    }
+    if (!hit) {                                         // first sight of this call shape: run eagerly (creates offset tables, grows buffers)
+        if (graphs.size() >= 8) {
+            size_t victim = 0;
+            for (size_t i = 1; i < graphs.size(); ++i)
+                if (graphs[i].last_use < graphs[victim].last_use) victim = i;
+            if (graphs[victim].exec && graphs[victim].hits == 0 && ++graph_wasted >= 4) graphs_on = false;   // pointers never repeat: stop capturing
+            if (graphs[victim].exec) (void)hipGraphExecDestroy(graphs[victim].exec);
+            if (graphs[victim].graph) (void)hipGraphDestroy(graphs[victim].graph);
+            graphs.erase(graphs.begin() + (long)victim);
+        }
+        GraphEntry ge;
+        ge.key = key; ge.last_use = graph_clock;
+        graphs.push_back(ge);
+        return run(s);
+    }
+    // second sight (or a stale capture): record the sequence on the engine's own stream, instantiate, replay on the caller's
+    if (hit->exec) { (void)hipGraphExecDestroy(hit->exec); hit->exec = nullptr; }
+    if (hit->graph) { (void)hipGraphDestroy(hit->graph); hit->graph = nullptr; }
+    if (!capture_stream && hipStreamCreateWithFlags(&capture_stream, hipStreamNonBlocking) != hipSuccess) { graphs_on = false; return run(s); }
+    const uint64_t epoch0 = graph_epoch;
+    if (hipStreamBeginCapture(capture_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); graphs_on = false; return run(s); }
+    capture_flag() = true;
+    Status st = run(capture_stream);
+    capture_flag() = false;
+    hipGraph_t graph = nullptr;
+    const hipError_t ce = hipStreamEndCapture(capture_stream, &graph);
+    if (!st.ok() || ce != hipSuccess || !graph || graph_epoch != epoch0) {
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        hit->last_use = graph_clock;
+        if (st.ok() && graph_epoch == epoch0 && ce != hipSuccess) graphs_on = false;          // the runtime cannot capture this sequence at all
+        return run(s);                                  // nothing was executed by the failed capture: run it for real
+    }
+    hipGraphExec_t exec = nullptr;
+    if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess || !exec) {
+        (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        graphs_on = false;
+        return run(s);
+    }
+    hit->graph = graph; hit->exec = exec; hit->epoch = graph_epoch; hit->last_use = graph_clock; hit->hits = 0;
+    CV_HIP(hipGraphLaunch(exec, s));
+    return Status();
 }
 
 }  // namespace cv

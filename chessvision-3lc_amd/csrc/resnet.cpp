@@ -30,6 +30,7 @@ static void bn_keys(std::vector<std::string>& out, const std::string& p) {
 // fold the stem's output exponent into the device copies of its epilogue constants (ConvLayer::set_exps for the stem)
 static Status stem_set_exp(Engine::ResNet& R, int dt, int out_exp, hipStream_t s) {
     if (R.stem_scale.ptr && out_exp == R.stem_out_exp) return Status();
+    if (capture_flag()) return fail(1, "stem constants re-folded during graph capture");
     if (R.stem_scale.ptr) CV_HIP(hipStreamSynchronize(s));
     std::vector<float> sc(64), sh(64);
     const int in_exp = dt == kF32 ? 0 : kInputExp;
@@ -199,6 +200,7 @@ static Status resnet_reserve(Engine& e, int n) {
     const int want = std::min(R.max_cap, std::max(n, 1));
     if (want <= R.cap) return Status();
     CV_HIP(hipDeviceSynchronize());
+    e.graph_invalidate();                            // captured launches hold the old buffers
     CV_TRY(Activation::reserve_all(R.acts, want));
     R.cap = want;
     const int S = want;
@@ -286,6 +288,11 @@ Status resnet_forward(Engine& e, const void* x, bool x_u8, int n, float* out, bo
     if (n < 0 || (n > 0 && (!x || !out))) return fail(1, "cv_resnet18_forward: null tensor or negative batch");
     if (n == 0) return Status();
     CV_TRY(resnet_reserve(e, n));
+    if (n <= e.resnet->cap && n <= 512) {                // one small chunk (a board's 64 squares): the launch sequence replays as a hipGraph
+        Engine::GraphKey key;
+        key.model = 1; key.n = n; key.flags = (x_u8 ? 1 : 0) | (softmax ? 2 : 0); key.x = x; key.out = out;
+        return e.run_graphed(key, s, [&](hipStream_t st) { return resnet_chunk(e, x, x_u8, n, out, softmax, st); });
+    }
     const size_t in_stride = (size_t)64 * 64 * (x_u8 ? 1 : 4);
     for (int off = 0; off < n; off += e.resnet->cap) {
         const int c = std::min(e.resnet->cap, n - off);

@@ -9,6 +9,7 @@
 // at >= one full wave of workgroups while bounding the live working set.
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 
 #include "engine.h"
 #include "models.h"
@@ -316,6 +317,7 @@ static Status unet_reserve(Engine& e, int n) {
     const int want = std::min(U.max_cap, std::max(n, 1));
     if (want <= U.cap) return Status();
     CV_HIP(hipDeviceSynchronize());                  // nothing may still read the buffers about to be replaced
+    e.graph_invalidate();                            // captured launches hold the old buffers
     CV_TRY(Activation::reserve_all(U.acts, want));
     U.cap = want;
     const int S = want;
@@ -441,6 +443,12 @@ Status unet_forward(Engine& e, const void* x, bool x_u8, int batch, float* logit
     if (batch < 0 || (batch > 0 && (!x || !logits))) return fail(1, "cv_unet_forward: null tensor or negative batch");
     if (batch == 0) return Status();
     CV_TRY(unet_reserve(e, batch));
+    if (batch <= e.unet->cap && batch <= 8) {            // one small chunk: the launch sequence replays as a hipGraph
+        Engine::GraphKey key;
+        key.model = 0; key.n = batch; key.flags = x_u8 ? 1 : 0; key.x = x; key.out = logits; key.mask = mask;
+        std::memcpy(&key.thr_bits, &thr, sizeof(float));
+        return e.run_graphed(key, s, [&](hipStream_t st) { return unet_chunk(e, x, x_u8, batch, logits, mask, thr, st); });
+    }
     const size_t in_stride = (size_t)3 * 256 * 256 * (x_u8 ? 1 : 4);
     for (int off = 0; off < batch; off += e.unet->cap) {
         const int n = std::min(e.unet->cap, batch - off);

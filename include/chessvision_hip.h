@@ -39,7 +39,8 @@
 extern "C" {
 #endif
 
-#define CV_ABI_VERSION 2      /* 2: CV_PREC_F16R, CV_ERR_NUMERIC + cv_engine_numeric_status, cv_engine_set_chunk before cv_load_* only */
+#define CV_ABI_VERSION 3      /* 2: CV_PREC_F16R, CV_ERR_NUMERIC + cv_engine_numeric_status, cv_engine_set_chunk before cv_load_* only
+                                 3: cv_board_homographies, cv_engine_export/import_calibration (additions only) */
 
 enum cv_status {
     CV_OK = 0,
@@ -113,6 +114,14 @@ int cv_engine_workspace_bytes(cv_engine_t* eng, size_t* bytes);
  * CV_ERR_NUMERIC with the name of the first such layer in cv_last_error() and re-arms the guard; CV_OK when every
  * forward since the previous check was clean.  The forward calls themselves stay asynchronous. */
 int cv_engine_numeric_status(cv_engine_t* eng, void* stream);
+
+/* The load-time range calibration as data (f16-based precisions): the per-tensor exponents of a loaded model, two int32 per tensor
+ * in the engine's fixed tensor order.  export: exps == NULL returns the count only.  import: sets them (count must match; the
+ * layers re-fold their epilogue constants at their next launch; *changed = 1 when any exponent differed).  Multi-GPU jobs
+ * broadcast rank 0's vector so that every rank computes with IDENTICAL scalings even if a calibration pass were ever to differ
+ * between ranks (chessvision/distributed.py: sync_calibration). */
+int cv_engine_export_calibration(cv_engine_t* eng, const char* model, int32_t* exps, int capacity, int* count);
+int cv_engine_import_calibration(cv_engine_t* eng, const char* model, const int32_t* exps, int count, int* changed);
 
 /* ---- forward (the hot path) ---------------------------------------------------------------------- */
 /* x: (batch,3,256,256) float32 NCHW in [0,1]  ->  logits: (batch,1,256,256) float32.

@@ -40,8 +40,25 @@ def _worker(rank: int, world: int, port: int, q):
         ok_order = ordered[:, 0].tolist() == list(range(n_boards))
         t = cvd.max_over_ranks(float(rank + 1), device)
         seen = cvd.count_ranks(device)                 # bench.py's `rccl_ranks_seen`: an all-reduce of ones
+
+        class _Eng:                                    # the two calibration calls of HipEngine; rank 1 starts with other exponents
+            def __init__(self):
+                self.cal = {"unet": np.arange(6, dtype=np.int32) + rank, "resnet18": np.full(4, 3, np.int32)}
+
+            def export_calibration(self, model):
+                return self.cal[model]
+
+            def import_calibration(self, model, e):
+                changed = not np.array_equal(self.cal[model], e)
+                self.cal[model] = np.array(e, np.int32)
+                return changed
+
+        eng = _Eng()
+        rep = cvd.sync_calibration(eng, device)
+        cal_ok = (np.array_equal(eng.cal["unet"], np.arange(6)) and rep["changed_here"] == (rank == 1)
+                  and rep["identical_across_ranks"] is False and cvd.sync_calibration(eng, device)["identical_across_ranks"] is True)
         cvd.barrier(device)
-        q.put((rank, same, mine, ok_order, t, seen))
+        q.put((rank, same and cal_ok, mine, ok_order, t, seen))
     finally:
         if dist.is_initialized():
             dist.destroy_process_group()

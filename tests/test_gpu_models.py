@@ -313,3 +313,50 @@ def test_workspace_growth_is_transactional():
     after = eng.unet_forward(x1).cpu()
     assert torch.equal(before, after)
     eng.close()
+
+
+def test_graph_replay_of_small_forwards_is_transparent():
+    """Round 4: a forward that fits one small chunk (UNet <= 8 images, ResNet-18 <= 512 squares) is captured into a hipGraph on its
+    second call with the same pointers and replayed afterwards.  Eager call, capture call and replays give identical bits; a
+    different output tensor, a workspace growth (which moves every activation buffer) and new input VALUES in the same tensor are
+    all honoured (the captured launches read the caller's memory at replay time; stale captures are dropped by epoch)."""
+    from chessvision.hip_backend import HipEngine
+
+    unet, resnet = synth.make_unet(seed=1), synth.make_resnet(seed=2)
+    eng = HipEngine(precision="f16x3")
+    eng.load_unet(unet.state_dict())
+    eng.load_resnet18(resnet.state_dict())
+    x = synth.unet_input(seed=41, batch=1).cuda()
+    sq = synth.squares_input(seed=42, n=64).cuda()
+    with torch.no_grad():
+        ref_u, ref_r = unet(x.cpu()), resnet(sq.cpu())
+    lib, h = eng._lib, eng._h
+    out_u = torch.empty((1, 1, 256, 256), device="cuda")
+    out_r = torch.empty((64, 13), device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    runs_u, runs_r = [], []
+    for _ in range(4):                                       # eager, capture, replay, replay -- same pointers every time
+        assert lib.cv_unet_forward(h, x.data_ptr(), 1, out_u.data_ptr(), stream) == 0
+        assert lib.cv_resnet18_forward(h, sq.data_ptr(), 64, out_r.data_ptr(), stream) == 0
+        torch.cuda.synchronize()
+        runs_u.append(out_u.cpu().clone()); runs_r.append(out_r.cpu().clone())
+    assert all(torch.equal(runs_u[0], r) for r in runs_u[1:]) and all(torch.equal(runs_r[0], r) for r in runs_r[1:])
+    assert (runs_u[0] - ref_u).abs().max() <= 1e-3 and (runs_r[0] - ref_r).abs().max() <= 1e-3
+    # new values in the same input tensor: the replay must read them
+    x2, sq2 = synth.unet_input(seed=43, batch=1), synth.squares_input(seed=44, n=64)
+    x.copy_(x2); sq.copy_(sq2)
+    assert lib.cv_unet_forward(h, x.data_ptr(), 1, out_u.data_ptr(), stream) == 0
+    assert lib.cv_resnet18_forward(h, sq.data_ptr(), 64, out_r.data_ptr(), stream) == 0
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        assert (out_u.cpu() - unet(x2)).abs().max() <= 1e-3 and (out_r.cpu() - resnet(sq2)).abs().max() <= 1e-3
+    after_new_values = out_u.cpu().clone()
+    # grow the workspace (batch 3 re-allocates every UNet tensor), then the captured shape again: stale graph dropped, same bits
+    eng.unet_forward(synth.unet_input(seed=45, batch=3).cuda())
+    eng.resnet18_forward(synth.squares_input(seed=46, n=700).cuda())
+    for _ in range(3):
+        assert lib.cv_unet_forward(h, x.data_ptr(), 1, out_u.data_ptr(), stream) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(out_u.cpu(), after_new_values)
+    eng.check_numerics()
+    eng.close()

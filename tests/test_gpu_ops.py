@@ -71,6 +71,14 @@ CONV_CASES = [
     # >= 4 tiles per CU and K <= 72 stages: the persistent variants of the 8-wave halo tiles (with a ragged last image group)
     ("persistent_halo128_residual", 64, 64, 64, 64, 128, 3, 1, True, True),
     ("persistent_packed_8x8_tail", 4098, 128, 8, 8, 128, 3, 1, True, True),
+    # round 4, split-K launches (few output tiles, long K): the halo kernel dealt by channel blocks (maps of 16 x 16 and up) ...
+    ("splitk_halo_unet_down4_like", 1, 512, 16, 16, 256, 3, 1, True, False),
+    ("splitk_halo_32x32_residual", 1, 256, 32, 32, 128, 3, 1, True, True),
+    ("splitk_halo_uneven_blocks_cin160", 1, 160, 16, 16, 64, 3, 1, False, False),
+    # ... and the generic kernel dealt by K stages (small maps, strided, 1x1)
+    ("splitk_generic_resnet_layer4_like", 64, 512, 2, 2, 512, 3, 1, True, True),
+    ("splitk_generic_stride2", 16, 256, 8, 8, 512, 3, 2, True, False),
+    ("splitk_generic_4x4", 64, 256, 4, 4, 256, 3, 1, True, True),
 ]
 
 
@@ -95,7 +103,8 @@ def test_conv_bn_relu(engines, prec, case):
 
 
 @pytest.mark.parametrize("prec", PRECS)
-@pytest.mark.parametrize("shape", [(2, 64, 8, 8, 32), (1, 128, 16, 16, 64), (2, 1024, 4, 4, 512), (16, 128, 64, 64, 64)])
+@pytest.mark.parametrize("shape", [(2, 64, 8, 8, 32), (1, 128, 16, 16, 64), (2, 1024, 4, 4, 512), (16, 128, 64, 64, 64),
+                                   (1, 1024, 16, 16, 512)])       # the last one: UNet up1.up at one board (a split-K launch)
 def test_conv_transpose_k2s2(engines, prec, shape):
     n, cin, h, w, cout = shape
     x = _t(21, "ctx", (n, cin, h, w))
