@@ -423,7 +423,9 @@ static int impl_cv_find_quadrangle(const uint8_t* mask, int h, int w, int32_t qu
 static int impl_cv_find_quadrangles(const uint8_t* masks, int n, int h, int w, int32_t* quads, int32_t* found, int n_threads) {
     if (!masks || !quads || !found || n < 0 || h <= 0 || w <= 0) return finish(fail(CV_ERR_INVALID, "cv_find_quadrangles: bad argument"));
     int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
-    nt = std::max(1, std::min(nt, std::min(n, 32)));
+    // a mask takes ~50 us since round 4 (run-based labelling): starting a thread costs about as much, so every thread gets at least
+    // eight masks (64 masks: 8 threads; a single board: none)
+    nt = std::max(1, std::min(nt, std::min((n + 7) / 8, 32)));
     auto work = [&](int t) {
         for (int i = t; i < n; i += nt)
             found[i] = find_quadrangle(masks + (size_t)i * h * w, h, w, quads + (size_t)i * 8) ? 1 : 0;

@@ -54,6 +54,30 @@ static int host_mode(void) {
     printf("fen0 %s\nfen1 %s\norig1 %s\nfixes %d", fen, fen + 72, orig + 72, (int)n_fixes);
     for (int i = 0; i < n_fixes * 4; ++i) printf(" %d", (int)fixes[i]);
     printf("\n");
+    /* quadrangle (scaled to a 512-row photo) -> the warp's matrices, OpenCV's order of operations: forward maps the corners onto
+       (0,0), (512,0), (512,512), (0,512); inverse * forward = identity */
+    float corners[8];
+    for (int i = 0; i < 8; ++i) corners[i] = (float)quad[i] * 2.0f;
+    double fwd[9], inv[9];
+    CHECK(cv_board_homographies(corners, 1, 512, 512, fwd, inv));
+    double worst = 0.0;
+    const double want[8] = {0, 0, 512, 0, 512, 512, 0, 512};
+    for (int i = 0; i < 4; ++i) {
+        const double x = corners[2 * i], y = corners[2 * i + 1];
+        const double w = fwd[6] * x + fwd[7] * y + fwd[8];
+        const double u = (fwd[0] * x + fwd[1] * y + fwd[2]) / w, v = (fwd[3] * x + fwd[4] * y + fwd[5]) / w;
+        const double du = u - want[2 * i], dv = v - want[2 * i + 1];
+        if (du * du > worst) worst = du * du;
+        if (dv * dv > worst) worst = dv * dv;
+    }
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            double acc = 0.0;
+            for (int k = 0; k < 3; ++k) acc += inv[r * 3 + k] * fwd[k * 3 + c];
+            const double d = acc - (r == c ? 1.0 : 0.0);
+            if (d * d > worst) worst = d * d;
+        }
+    printf("homography_err2 %.3g\n", worst);
     /* error path: status + message, never an abort */
     int rc = cv_find_quadrangle(NULL, 256, 256, quad, &found);
     printf("null_mask rc=%d msg=%s\n", rc, cv_last_error());
