@@ -237,6 +237,11 @@ def pipeline_e2e_sharded(dtype, boards_per_rank, rank, world, device, cvd):
     with tempfile.TemporaryDirectory() as d:
         pe, pc = synthetic.save_checkpoints(d, segmenting=True)      # same seeds on every rank: identical weights
         cv = ChessVision(board_extractor_weights=str(pe), classifier_weights=str(pc), precision=dtype)
+        _ = cv.board_extractor, cv.classifier                         # load + calibrate, then take rank 0's tensor exponents
+        cal = {"identical_across_ranks": True}
+        for model, engine in (("unet", cv._get_engine("unet")), ("resnet18", cv._get_engine("resnet18"))):
+            rep = cvd.sync_calibration(engine, device, models=(model,))      # the two engines of a mixed precision, one model each
+            cal["identical_across_ranks"] = cal["identical_across_ranks"] and rep["identical_across_ranks"]
         for i in cvd.shard_indices(n_global, rank, world):
             photos[i]                                                 # render this rank's shard before any clock starts
         warm = _LazyPhotos(min(96, boards_per_rank) * world)
@@ -258,6 +263,7 @@ def pipeline_e2e_sharded(dtype, boards_per_rank, rank, world, device, cvd):
     fens = sum(r is not None and r.position is not None for r in res)
     return {"boards_per_sec_per_rank": {k: round(v, 1) for k, v in rate.items()}, "boards_per_sec_whole_job": round(whole, 1),
             "gather_s": {k: round(v, 4) for k, v in gather.items()}, "global_boards": n_global, "fens_on_rank0": fens,
+            "calibration_identical_across_ranks": cal["identical_across_ranks"],
             "note": "host photos in, FEN out on every rank (best of 3 calls); per-rank rate = shard boards / that rank's process_images time; "
                     "whole job = all boards / slowest rank's call including the all_gather of probabilities, quadrangles and masks"}
 
@@ -515,6 +521,7 @@ def flatten_evidence(result):
     put(cfg, "classifier_fp16_prob_max_abs_err", pick(result, "classifier_fp16", "parity_vs_oracle", "prob_max_abs_err"))
     put(cfg, "bilinear_variant_boards_per_sec", pick(result, "by_variant", "bilinear", "value"))
     put(cfg, "pipeline_e2e_ranks_whole_job_boards_per_sec", pick(result, "pipeline_e2e_ranks", "boards_per_sec_whole_job"))
+    put(cfg, "pipeline_e2e_ranks_precision", pick(result, "pipeline_e2e_ranks", "precision"))
     for k in ("min", "mean", "max"):
         put(cfg, f"pipeline_e2e_ranks_boards_per_sec_{k}", pick(result, "pipeline_e2e_ranks", "boards_per_sec_per_rank", k))
     put(roof, "dominant_kernel", pick(roof, "dominant", "kernel"))
@@ -549,6 +556,9 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--extra-steps", type=int, default=10, help="timed steps of each by_dtype / by_variant / classifier_fp16 leg")
     ap.add_argument("--extra-warmup", type=int, default=3)
+    ap.add_argument("--e2e-precision", default=None,
+                    help="precision of the sharded host-images-to-FEN leg at N > 1 (BASELINE configs[4] says fp16: default "
+                         "'<dtype>+f16r' = the headline UNet with the classifier in its fp16 mode)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -620,7 +630,9 @@ def main():
     # N > 1: every rank also runs the full host-images-to-FEN pipeline on its shard of one global list of photos
     e2e_ranks = None
     if world > 1 and not args.no_extras:
-        e2e_ranks = pipeline_e2e_sharded(args.dtype, B, rank, world, device, cvd)
+        e2e_prec = args.e2e_precision or (args.dtype if "+" in args.dtype or args.dtype == "f16r" else f"{args.dtype}+f16r")
+        e2e_ranks = pipeline_e2e_sharded(e2e_prec, B, rank, world, device, cvd)
+        e2e_ranks["precision"] = e2e_prec
 
     if rank != 0:
         cvd.barrier(device)                              # leave together with rank 0 (it still profiles and reports)

@@ -17,6 +17,9 @@ void decode_positions(const float* probs, int n_boards, int flip, char* fen, cha
                       int32_t* fixes, int32_t* n_fixes);
 bool find_quadrangle(const uint8_t* mask, int h, int w, int32_t quad[8]);
 hipError_t resize_area_u8(const uint8_t* src, int n, int h, int w, int c, uint8_t* dst, int oh, int ow, hipStream_t s);
+void resize_area_table(int ssize, int dsize, std::vector<int>& ofs, std::vector<int>& si, std::vector<float>& alpha);
+hipError_t resize_area_u8_tab(const uint8_t* src, int n, int h, int w, int c, uint8_t* dst, int oh, int ow, const int* xofs,
+                              const int* xsi, const float* xa, const int* yofs, const int* ysi, const float* ya, hipStream_t s);
 hipError_t extract_squares_u8(const uint8_t* images, int n, int h, int w, const double* inv, uint8_t* squares,
                               uint8_t* boards, hipStream_t s);
 void board_homographies(const float* quads, int n, int out_w, int out_h, double* forward, double* inverse);
@@ -444,7 +447,38 @@ static int impl_cv_resize_area_u8(cv_engine_t* eng, const uint8_t* src, int n, i
     if (!src || !dst || n <= 0 || h <= 0 || w_ <= 0 || channels <= 0 || out_h <= 0 || out_w <= 0)
         return finish(fail(CV_ERR_INVALID, "cv_resize_area_u8: bad argument"));
     DeviceGuard g(eng->impl.device);
-    hipError_t e = resize_area_u8(src, n, h, w_, channels, dst, out_h, out_w, (hipStream_t)stream);
+    hipError_t e;
+    const bool integer = h % out_h == 0 && w_ % out_w == 0;
+    if (!integer && out_h <= h && out_w <= w_ && channels <= 4) {
+        // fractional shrink: OpenCV's float32 table form; the two tables are built once per geometry and stay on the device
+        std::lock_guard<std::mutex> lk(eng->impl.mu);
+        Engine& en = eng->impl;
+        const long long key = (((long long)h * 65536 + w_) * 65536 + out_h) * 65536 + out_w;
+        if (en.area_key != key) {
+            std::vector<int> xo, xs, yo, ys;
+            std::vector<float> xa, ya;
+            resize_area_table(w_, out_w, xo, xs, xa);
+            resize_area_table(h, out_h, yo, ys, ya);
+            e = hipStreamSynchronize((hipStream_t)stream);             // a launch in flight may still read the previous tables
+            if (e != hipSuccess) return finish(hip_fail(e, "cv_resize_area_u8"));
+            std::vector<char> blob;
+            auto put = [&](const void* p, size_t nbytes) { const size_t at = blob.size(); blob.resize(at + ((nbytes + 15) & ~(size_t)15)); std::memcpy(blob.data() + at, p, nbytes); return at; };
+            const size_t o0 = put(xo.data(), xo.size() * 4), o1 = put(xs.data(), xs.size() * 4), o2 = put(xa.data(), xa.size() * 4);
+            const size_t o3 = put(yo.data(), yo.size() * 4), o4 = put(ys.data(), ys.size() * 4), o5 = put(ya.data(), ya.size() * 4);
+            s = en.area_tabs.upload(blob.data(), blob.size());
+            if (!s.ok()) return finish(s);
+            const size_t off[6] = {o0, o1, o2, o3, o4, o5};
+            for (int i = 0; i < 6; ++i) en.area_off[i] = off[i];
+            en.area_key = key;
+            en.graph_invalidate();
+        }
+        const char* base = (const char*)en.area_tabs.ptr;
+        e = resize_area_u8_tab(src, n, h, w_, channels, dst, out_h, out_w, (const int*)(base + en.area_off[0]), (const int*)(base + en.area_off[1]),
+                               (const float*)(base + en.area_off[2]), (const int*)(base + en.area_off[3]), (const int*)(base + en.area_off[4]),
+                               (const float*)(base + en.area_off[5]), (hipStream_t)stream);
+    } else {
+        e = resize_area_u8(src, n, h, w_, channels, dst, out_h, out_w, (hipStream_t)stream);
+    }
     if (e != hipSuccess) return finish(hip_fail(e, "resize_area_u8"));
     return CV_OK;
 }

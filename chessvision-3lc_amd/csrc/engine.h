@@ -185,6 +185,9 @@ class Engine {
 
     DeviceBuffer scratch;                               // small per-call parameter blocks (homographies)
     DeviceBuffer splitk_ws;                             // f32 partial sums of split-K conv launches (grown on demand)
+    DeviceBuffer area_tabs;                             // INTER_AREA tables of the last fractional resize geometry (cv_resize_area_u8)
+    long long area_key = -1;
+    size_t area_off[6] = {0, 0, 0, 0, 0, 0};
 
     // numeric guard: one device word, 0xffffffff = clean, else the lowest id of a layer that stored a non-finite value
     DeviceBuffer guard;

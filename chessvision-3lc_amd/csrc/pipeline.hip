@@ -19,6 +19,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cmath>
+#include <vector>
+
 namespace cv {
 
 typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
@@ -60,6 +63,43 @@ __global__ __launch_bounds__(256) void resize_area_2x2c3_kernel(const uint8_t* _
     *reinterpret_cast<u32x3*>(d) = u32x3{out[0], out[1], out[2]};        // 12 bytes, 4-byte aligned
 }
 
+// Fractional shrink = OpenCV's ResizeArea_Invoker with float32 work type, operation by operation: per contributing source row a
+// horizontal pass buf = buf + S * alpha over the column table's entries in order, then sum = beta * buf for the first source row of
+// a destination row and sum = sum + beta * buf for the others; saturate_cast<uchar>(sum) rounds half to even.  The tables
+// (computeResizeAreaTab: weights computed in double, stored as float) come from the host (resize_area_tables below).
+// One lane = one destination pixel, all channels (<= 4).
+struct AreaTabs { const int* xofs; const int* xsi; const float* xa; const int* yofs; const int* ysi; const float* ya; };
+
+__global__ __launch_bounds__(256) void resize_area_tab_kernel(const uint8_t* __restrict__ src, int n, int h, int w, int c,
+                                                              uint8_t* __restrict__ dst, int oh, int ow, AreaTabs t) {
+#pragma clang fp contract(off)
+    const size_t total = (size_t)n * oh * ow;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int dx = (int)(idx % ow);
+    const int dy = (int)((idx / ow) % oh);
+    const size_t img = idx / ((size_t)ow * oh);
+    const uint8_t* s = src + img * (size_t)h * w * c;
+    const int k0 = t.xofs[dx], k1 = t.xofs[dx + 1], j0 = t.yofs[dy], j1 = t.yofs[dy + 1];
+    float sum[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int j = j0; j < j1; ++j) {
+        const uint8_t* row = s + (size_t)t.ysi[j] * w * c;
+        const float beta = t.ya[j];
+        float buf[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = k0; k < k1; ++k) {
+            const float alpha = t.xa[k];
+            const uint8_t* px = row + (size_t)t.xsi[k] * c;
+            for (int ch = 0; ch < c; ++ch) buf[ch] = buf[ch] + (float)px[ch] * alpha;
+        }
+        for (int ch = 0; ch < c; ++ch) sum[ch] = j == j0 ? beta * buf[ch] : sum[ch] + beta * buf[ch];
+    }
+    uint8_t* d = dst + idx * c;
+    for (int ch = 0; ch < c; ++ch) {
+        const float v = rintf(sum[ch]);
+        d[ch] = (uint8_t)(v < 0.f ? 0.f : v > 255.f ? 255.f : v);
+    }
+}
+
 __global__ void resize_area_u8_kernel(const uint8_t* __restrict__ src, int n, int h, int w, int c,
                                       uint8_t* __restrict__ dst, int oh, int ow) {
 #pragma clang fp contract(off)                          // keep mul/add unfused: matches the numpy checker bit for bit
@@ -80,7 +120,8 @@ __global__ void resize_area_u8_kernel(const uint8_t* __restrict__ src, int n, in
         dst[idx] = (uint8_t)((acc + (fy * fx) / 2) / (fy * fx));
         return;
     }
-    // fractional shrink: coverage-weighted mean (rows then columns accumulate in double); enlarging: bilinear
+    // (a fractional SHRINK never reaches this kernel: resize_area_tab_kernel reproduces OpenCV's float32 table form; the branch below
+    // stays for callers without tables)  enlarging: bilinear
     const double sy = (double)h / oh, sx = (double)w / ow;
     double acc = 0.0;
     if (oh <= h && ow <= w) {
@@ -191,6 +232,37 @@ __global__ __launch_bounds__(256) void extract_squares_u8_kernel(const uint8_t* 
     if (boards) *reinterpret_cast<uint32_t*>(boards + ((size_t)img * B + by) * B + bx0) = packed;
     const int sq = (by >> 6) * 8 + (bx0 >> 6);            // a8..h8, a7.. order (reference core.py:436-439)
     *reinterpret_cast<uint32_t*>(squares + ((size_t)img * 64 + sq) * 4096 + (size_t)(by & 63) * 64 + (bx0 & 63)) = packed;
+}
+
+// host side of the fractional shrink: OpenCV's computeResizeAreaTab for one axis (source indices in PIXELS, float weights, CSR offsets)
+void resize_area_table(int ssize, int dsize, std::vector<int>& ofs, std::vector<int>& si, std::vector<float>& alpha) {
+    const double scale = (double)ssize / dsize;
+    ofs.assign(1, 0); si.clear(); alpha.clear();
+    for (int d = 0; d < dsize; ++d) {
+        const double fs1 = d * scale, fs2 = fs1 + scale;
+        const double cell = scale < ssize - fs1 ? scale : ssize - fs1;
+        int s1 = (int)std::ceil(fs1), s2 = (int)std::floor(fs2);
+        s2 = s2 < ssize - 1 ? s2 : ssize - 1;
+        s1 = s1 < s2 ? s1 : s2;
+        if (s1 - fs1 > 1e-3) { si.push_back(s1 - 1); alpha.push_back((float)((s1 - fs1) / cell)); }
+        for (int sx = s1; sx < s2; ++sx) { si.push_back(sx); alpha.push_back((float)(1.0 / cell)); }
+        if (fs2 - s2 > 1e-3) {
+            double a = fs2 - s2 < 1.0 ? fs2 - s2 : 1.0;
+            a = a < cell ? a : cell;
+            si.push_back(s2); alpha.push_back((float)(a / cell));
+        }
+        ofs.push_back((int)si.size());
+    }
+}
+
+// tabs: device pointers of the two tables (built by the caller with resize_area_table and uploaded once per geometry)
+hipError_t resize_area_u8_tab(const uint8_t* src, int n, int h, int w, int c, uint8_t* dst, int oh, int ow, const int* xofs,
+                              const int* xsi, const float* xa, const int* yofs, const int* ysi, const float* ya, hipStream_t s) {
+    if (c < 1 || c > 4) return hipErrorInvalidValue;
+    const size_t total = (size_t)n * oh * ow;
+    const AreaTabs t{xofs, xsi, xa, yofs, ysi, ya};
+    hipLaunchKernelGGL(resize_area_tab_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, n, h, w, c, dst, oh, ow, t);
+    return hipGetLastError();
 }
 
 hipError_t resize_area_u8(const uint8_t* src, int n, int h, int w, int c, uint8_t* dst, int oh, int ow, hipStream_t s) {

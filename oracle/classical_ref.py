@@ -6,7 +6,8 @@ a misreading of OpenCV or of the reference that both of those share would otherw
 Deliberately the slow, literal form (loops and float64) -- small inputs only.
 
     stage                               reference call site                         here
-    cv2.resize(INTER_AREA), 512 -> 256  chessvision/core.py:212                     resize_area_int
+    cv2.resize(INTER_AREA), 512 -> 256  chessvision/core.py:212                     resize_area_int (integer factors),
+                                                                                    resize_area (any shrink: OpenCV's float32 table form)
     sigmoid > threshold -> 0 / 255      core.py:273, utils.py:101-112               binary_mask
     cv2.cvtColor(BGR2GRAY)              core.py:299                                 bgr_to_gray
     cv2.flip(board, 1)                  core.py:300                                 flip_lr
@@ -47,6 +48,57 @@ def resize_area_int(image: np.ndarray, out_hw: tuple[int, int]) -> np.ndarray:
         for dx in range(fx):
             total += image[dy::fy, dx::fx]
     return ((2 * total + fy * fx) // (2 * fy * fx)).astype(np.uint8)
+
+
+def _area_table(ssize: int, dsize: int, scale: float):
+    """OpenCV's ``computeResizeAreaTab`` (imgproc/src/resize.cpp): for every destination index the source indices it covers and
+    their weights -- a leading partial cell (if it covers more than 1e-3 of a pixel), the whole cells at 1 / cellWidth, a trailing
+    partial cell; weights computed in double and stored as FLOAT.  Returns a list (per destination index) of (source index, weight)."""
+    tab = []
+    for d in range(dsize):
+        fs1 = d * scale
+        fs2 = fs1 + scale
+        cell = min(scale, ssize - fs1)
+        s1, s2 = int(np.ceil(fs1)), int(np.floor(fs2))
+        s2 = min(s2, ssize - 1)
+        s1 = min(s1, s2)
+        row = []
+        if s1 - fs1 > 1e-3:
+            row.append((s1 - 1, np.float32((s1 - fs1) / cell)))
+        for sx in range(s1, s2):
+            row.append((sx, np.float32(1.0 / cell)))
+        if fs2 - s2 > 1e-3:
+            row.append((s2, np.float32(min(min(fs2 - s2, 1.0), cell) / cell)))
+        tab.append(row)
+    return tab
+
+
+def resize_area(image: np.ndarray, out_hw: tuple[int, int]) -> np.ndarray:
+    """cv2.resize(image, (w, h), interpolation=INTER_AREA) for a SHRINK in both directions (core.py:212).  Integer factors in both
+    directions are OpenCV's integer fast path (``resize_area_int``); anything else is ``ResizeArea_Invoker`` with float32 work type,
+    restated with its order of operations: per source row a horizontal pass ``buf[dx] = buf[dx] + S[sx] * alpha`` over the table
+    entries in order, then ``sum[dx] = beta * buf[dx]`` for the first source row of a destination row and ``sum[dx] += beta *
+    buf[dx]`` for the others, and ``saturate_cast<uchar>(sum)`` = round half to even.  Every operation rounds to float32."""
+    h, w, c = image.shape
+    oh, ow = out_hw
+    assert oh <= h and ow <= w, "INTER_AREA as a shrink only (enlarging goes through OpenCV's bilinear path)"
+    if h % oh == 0 and w % ow == 0:
+        return resize_area_int(image, out_hw)
+    xtab, ytab = _area_table(w, ow, w / ow), _area_table(h, oh, h / oh)
+    src = image.astype(np.float32)
+    out = np.zeros((oh, ow, c), np.uint8)
+    for dy in range(oh):
+        total = None
+        for sy, beta in ytab[dy]:
+            buf = np.zeros((ow, c), np.float32)
+            for dx in range(ow):
+                acc = np.zeros(c, np.float32)
+                for sx, alpha in xtab[dx]:
+                    acc = (acc + src[sy, sx] * alpha).astype(np.float32)
+                buf[dx] = acc
+            total = (beta * buf).astype(np.float32) if total is None else (total + (beta * buf).astype(np.float32)).astype(np.float32)
+        out[dy] = np.clip(np.rint(total), 0, 255).astype(np.uint8)
+    return out
 
 
 def binary_mask(logits: np.ndarray, threshold: float) -> np.ndarray:

@@ -15,7 +15,8 @@ and keeps the two models behind opaque callables (``core.py:53-54``).  Here it i
   (``ChessVision._find_quadrangle`` = Suzuki border following, area / box filter, Douglas-Peucker; pinned on the reference's
   own 631 label masks against ``coordinates.json``, tests/test_contour_cpp.py).  For it the end-to-end test compares two
   implementations (C++ versus numpy) of ONE reading of OpenCV; a shared misreading there is caught only by the 631-mask
-  fixture, not here.  Non-integer resize factors also fall back to the product's coverage-weighted form.
+  fixture, not here.  (Photos smaller than 256 pixels, which INTER_AREA enlarges through OpenCV's bilinear path, also use the
+  product's approximation of it.)
 
 ``fallback_quad`` mirrors the option of ``process_images``: boards whose mask yields no quadrangle are classified through
 the whole-image quadrangle (TR, TL, BL, BR of the 256x256 mask) so that random-init weights still exercise the classifier.
@@ -33,10 +34,10 @@ from . import classical_ref as cref
 def process_image(unet, resnet, image: np.ndarray, threshold: float = 0.5, flip: bool = False, fallback_quad: bool = False):
     t0 = time.time()
     h, w = image.shape[:2]
-    if h % 256 == 0 and w % 256 == 0:
-        small = cref.resize_area_int(image, (256, 256))
+    if h >= 256 and w >= 256:
+        small = cref.resize_area(image, (256, 256))                            # integer and fractional shrinks, independent of the product
     else:
-        from chessvision import classical                                      # fractional factors: the product's coverage form
+        from chessvision import classical                                      # enlarging: the product's bilinear approximation
 
         small = classical.resize_area(image, (256, 256))
     x = torch.from_numpy(small.astype(np.float32) / np.float32(255.0)).permute(2, 0, 1)[None]   # core.py:215-216

@@ -57,7 +57,12 @@ def test_relaunch_command_is_torchrun_on_localhost(monkeypatch):
 
 @pytest.mark.gpu
 def test_bench_line_contract_with_rccl_world_of_one():
-    env = dict(os.environ, CV_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29517")
+    import socket
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, CV_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--boards", "64", "--steps", "1", "--warmup", "1",
@@ -85,22 +90,28 @@ def test_two_ranks_on_one_gpu_over_gloo_run_the_sharded_bench():
     """The N > 1 code path of bench.py on a one-GPU box: RCCL refuses two ranks per device, so CV_DIST_BACKEND=gloo carries the
     collectives (host buffers) while both ranks compute on the same MI355X.  `python bench.py --gpus 2` from a bare shell starts
     its own torchrun child (never an exec), rank 0 generates the weights and both ranks receive them by broadcast, the global
-    batch of 2 x 32 boards is sharded r::2, rank 1 leaves through the barrier / shutdown branch, the sharded host pipeline runs
-    on both ranks, and exactly one JSON line reaches stdout."""
+    batch of 2 x 256 boards (BASELINE configs[4]'s per-rank shape) is sharded r::2, rank 1 leaves through the barrier / shutdown
+    branch, the sharded host pipeline runs on both ranks at configs[4]'s precision (f16x3 UNet + the classifier's fp16 mode), the
+    range calibration is synchronised from rank 0, and exactly one JSON line reaches stdout."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "CV_FORCE_DIST")}
     env["CV_DIST_BACKEND"] = "gloo"
-    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--boards", "32", "--steps", "1", "--warmup", "1",
-                          "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=1500)
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--boards", "256", "--steps", "1", "--warmup", "1",
+                          "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=2400)
     assert out.returncode == 0, out.stderr[-4000:]
     lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["rccl_ranks_seen"] == 2 and line["dist_backend"] == "gloo"
-    assert line["config"]["global_boards_per_step"] == 64 and line["scaling"] == "weak" and line["value"] > 0
-    assert line["sharding"] == {"global_boards": 64, "rule": "rank r owns boards r::world", "gathered_in_order": True}
+    assert line["config"]["global_boards_per_step"] == 512 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["sharding"] == {"global_boards": 512, "rule": "rank r owns boards r::world", "gathered_in_order": True}
+    assert line["calibration_sync"]["identical_across_ranks"] is True and line["init_s"]["max"] > 0
+    assert line["config"]["init_s_max_over_ranks"] == line["init_s"]["max"] and line["config"]["rccl_ranks_seen"] == 2
     ncpu = os.cpu_count() or 1
     assert 1 <= line["host_threads_per_rank"] <= max(1, min(32, ncpu // 2))
     e2e = line["pipeline_e2e_ranks"]
-    assert e2e["global_boards"] == 64 and e2e["fens_on_rank0"] == 64
+    assert e2e["global_boards"] == 512 and e2e["fens_on_rank0"] == 512
+    assert e2e["precision"] == "f16x3+f16r" and e2e["calibration_identical_across_ranks"] is True
+    assert line["config"]["pipeline_e2e_ranks_precision"] == "f16x3+f16r"
+    assert line["config"]["pipeline_e2e_ranks_boards_per_sec_min"] == round(e2e["boards_per_sec_per_rank"]["min"], 1)
     r = e2e["boards_per_sec_per_rank"]
     assert 0 < r["min"] <= r["mean"] <= r["max"] and e2e["boards_per_sec_whole_job"] > 0

@@ -28,6 +28,13 @@ def test_gray_flip_split_resize_agree():
     assert np.array_equal(classical.bgr_to_gray(every), cref.bgr_to_gray(every))  # a lattice over the colour cube
     assert np.array_equal(classical.resize_area(img, (256, 256)), cref.resize_area_int(img, (256, 256)))
     assert np.array_equal(classical.resize_area(img[:, :256], (64, 128)), cref.resize_area_int(img[:, :256], (128, 64)))
+    # fractional shrink factors (a 4:3 photo, odd sizes, one integer and one fractional axis): OpenCV's float32 table form, restated
+    # twice (vectorised numpy in the product, scalar loops in the oracle) -- identical bytes
+    for shape in ((384, 512, 3), (300, 400, 3), (257, 300, 3), (480, 641, 3), (512, 384, 3)):
+        photo = rng.integers(0, 256, shape, dtype=np.uint8)
+        assert np.array_equal(classical.resize_area(photo, (256, 256)), cref.resize_area(photo, (256, 256))), shape
+    flat = np.full((300, 400, 3), 77, np.uint8)
+    assert (cref.resize_area(flat, (256, 256)) == 77).all()                        # the weights of a cell sum to 1 (to float32 rounding)
     gray = cref.bgr_to_gray(img)
     assert np.array_equal(classical.flip_horizontal(gray), cref.flip_lr(gray))
     assert np.array_equal(ChessVision.extract_squares(gray), cref.split_squares(gray))

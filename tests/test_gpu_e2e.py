@@ -200,7 +200,7 @@ def test_process_image_is_the_native_pipeline_and_matches_batched_api_and_oracle
             assert np.array_equal(p.model_probabilities, q.model_probabilities)
             assert p.fen == q.fen and p.original_fen == q.original_fen and p.square_names == q.square_names
             assert np.array_equal(p.squares, q.squares) and p.validation_fixes == q.validation_fixes
-        if im.shape[0] % 256 == 0:                          # the oracle's independent resize covers integer factors
+        if True:                                            # the oracle's independent resize covers every shrink factor
             ref = pipeline_ref.process_image(unet, resnet, im)
             _compare(single, ref, stats, resnet, im, fallback_quad=False)
     assert sum(s.position is not None for s in singles) >= 6 and stats["fen_checked"] >= 4, stats

@@ -94,10 +94,14 @@ def test_device_resize_matches_host_restatement(engines):
     got = engines["f32"].resize_area_u8(torch.from_numpy(img), (256, 256)).cpu().numpy()
     want = np.stack([classical.resize_area(im, (256, 256)) for im in img])
     assert np.array_equal(got, want)                                       # integer factor: exact box mean
-    odd = rng.integers(0, 256, (2, 300, 400, 3), dtype=np.uint8)
-    got = engines["f32"].resize_area_u8(torch.from_numpy(odd), (256, 256)).cpu().numpy()
-    want = np.stack([classical.resize_area(im, (256, 256)) for im in odd])
-    assert np.abs(got.astype(int) - want.astype(int)).max() <= 1            # fractional: same weights, fp order differs
+    from oracle import classical_ref as cref
+
+    for shape in ((2, 300, 400, 3), (1, 384, 512, 3), (1, 257, 641, 3)):    # fractional shrink: OpenCV's float32 table form, bit-exact
+        odd = rng.integers(0, 256, shape, dtype=np.uint8)
+        got = engines["f32"].resize_area_u8(torch.from_numpy(odd), (256, 256)).cpu().numpy()
+        want = np.stack([classical.resize_area(im, (256, 256)) for im in odd])
+        assert np.array_equal(got, want), shape                              # device == host
+        assert np.array_equal(got[0], cref.resize_area(odd[0], (256, 256)))  # ... == the independent oracle
 
 
 def test_device_warp_gray_flip_split_matches_host_chain(engines):

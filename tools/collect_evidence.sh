@@ -17,4 +17,15 @@ done
 python3 bench.py --unet-variant bilinear --no-cpu-baseline --no-extras > "$OUT/bench_bilinear.json" 2> "$OUT/bench_bilinear.err"
 python3 tools/latency.py > "$OUT/latency.txt" 2>&1
 python3 tools/e2e_profile.py > "$OUT/e2e_profile.txt" 2>&1
+# round 4: the single-board shape (what process_image runs) and the byte kernels
+for d in f16x3 f32 f16; do
+  python3 tools/layer_profile.py --prec $d --unet-batch 1 --squares 64 --iters 20 > "$OUT/layer_profile_b1_$d.txt" 2>&1
+done
+python3 tools/process_image_latency.py --prec f16x3,f16x3+f16r,f32 > "$OUT/process_image_latency.txt" 2>&1
+python3 tools/process_image_breakdown.py > "$OUT/process_image_breakdown.txt" 2>&1
+python3 tools/byte_kernels.py > "$OUT/byte_kernels.txt" 2>&1
+rm -rf /tmp/rp_b1
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_b1 -o b1 -- python3 "$(cd "$OLDPWD" && pwd)/tools/b1_trace.py" f16x3 50 > /tmp/rp_b1.log 2>&1)
+find /tmp/rp_b1 -name '*kernel_stats.csv' -exec cp {} "$OUT/b1_kernel_stats.csv" \;
+python3 tools/b1_trace_summary.py "$(find /tmp/rp_b1 -name '*kernel_trace.csv' | head -1)" > "$OUT/b1_kernel_trace_summary.txt" 2>&1
 cat "$OUT/rocprof_reduce.log" | tail -3; cat "$OUT/latency.txt" | tail -5
