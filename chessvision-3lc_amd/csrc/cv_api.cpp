@@ -309,6 +309,7 @@ static int impl_cv_op_conv2d(cv_engine_t* eng, const float* x, int n, int cin, i
     const int cinPad = round_up(cin, 8);
     std::vector<float> ones(cout, 1.f), zeros(cout, 0.f);
     ConvLayer L;
+    e.ws_slot = 0;
     s = L.build_conv("op_conv2d", e.dt, w_host, cout, cin, k, stride, scale_host ? scale_host : ones.data(),
                      shift_host ? shift_host : zeros.data(), cinPad, (int64_t)n * ho * wo, (ho == wo) ? ho : 0);
     if (!s.ok()) return finish(s);
@@ -338,6 +339,7 @@ static int impl_cv_op_conv_transpose2x2(cv_engine_t* eng, const float* x, int n,
     Engine& e = eng->impl;
     hipStream_t st = (hipStream_t)stream;
     ConvLayer L;
+    e.ws_slot = 0;
     s = L.build_convT("op_convT", e.dt, w_host, cin, cout, bias_host, (int64_t)n * h * w_);
     if (!s.ok()) return finish(s);
     Activation ax, ay;

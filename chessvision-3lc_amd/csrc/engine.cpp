@@ -596,13 +596,14 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
             p.kper = kper;
             p.prow = split_kind == 2 ? (L.rows + ct - 1) / ct * ct : p.nCt * conv_cfg_ct(cfg);
             const size_t need = (size_t)p.ksplit * (size_t)p.M * (size_t)p.prow * sizeof(float);
-            if (splitk_ws.bytes < need) {
+            DeviceBuffer& ws = splitk_ws[ws_slot & 1];
+            if (ws.bytes < need) {
                 if (capture_flag()) return fail(1, "split-K buffer growth during graph capture");   // run_graphed falls back to an eager run
                 graph_invalidate();
                 CV_HIP(hipStreamSynchronize(s));                      // earlier launches may still read the old buffer
-                CV_TRY(splitk_ws.alloc(std::max(need, (size_t)32 << 20), false));
+                CV_TRY(ws.alloc(std::max(need, (size_t)32 << 20), false));
             }
-            p.partial = reinterpret_cast<float*>(splitk_ws.ptr);
+            p.partial = reinterpret_cast<float*>(ws.ptr);
             if (p.ksplit > 1) halo = split_kind == 2;
             else { p.ksplit = 0; p.partial = nullptr; split_kind = 0; }
         } else split_kind = 0;

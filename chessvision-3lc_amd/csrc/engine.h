@@ -184,7 +184,11 @@ class Engine {
     std::unique_ptr<ResNet> resnet;
 
     DeviceBuffer scratch;                               // small per-call parameter blocks (homographies)
-    DeviceBuffer splitk_ws;                             // f32 partial sums of split-K conv launches (grown on demand)
+    // f32 partial sums of split-K conv launches (grown on demand).  One buffer per model: the UNet pass and the ResNet-18 pass of one
+    // engine may be enqueued on two streams (bench.py --overlap 1) and must not share scratch memory; ws_slot is set by the model's
+    // forward (0 = UNet and the single-layer entry points, 1 = ResNet-18) under the engine mutex.
+    DeviceBuffer splitk_ws[2];
+    int ws_slot = 0;
     DeviceBuffer area_tabs;                             // INTER_AREA tables of the last fractional resize geometry (cv_resize_area_u8)
     long long area_key = -1;
     size_t area_off[6] = {0, 0, 0, 0, 0, 0};

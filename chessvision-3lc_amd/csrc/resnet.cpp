@@ -235,6 +235,7 @@ Status resnet_activation(Engine& e, const std::string& name, TensorRef* out) {
 static Status resnet_chunk(Engine& e, const void* x, bool x_u8, int n, float* out, bool softmax, hipStream_t s) {
     Engine::ResNet& R = *e.resnet;
     R.last_n = n;
+    e.ws_slot = 1;
     const int dt = e.dt;
     const double esz = dtype_size(dt), in_b = x_u8 ? 1.0 : 4.0;
     auto begin = [&](const char* name, double macs, double bytes) { if (e.profiling) e.prof_begin(name, false, macs, s, bytes); };

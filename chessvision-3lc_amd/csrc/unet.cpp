@@ -365,6 +365,7 @@ static Status unet_chunk(Engine& e, const void* x, bool x_u8, int n, float* logi
                          hipStream_t s) {
     Engine::UNet& U = *e.unet;
     U.last_n = n;
+    e.ws_slot = 0;
     const int dt = e.dt;
     const int enc_c[5] = {64, 128, 256, 512, U.c5};
     auto timed = [&](const char* name, hipError_t err) -> Status {

@@ -26,7 +26,9 @@
  *     with respect to the host and ordered on `stream`.
  *   - the caller owns inputs and outputs; the engine owns its packed weights and its workspace and
  *     frees them in cv_engine_destroy.  The library never frees caller memory.
- *   - an engine serialises concurrent forward calls with an internal mutex (one workspace per engine).
+ *   - an engine serialises concurrent forward calls with an internal mutex (one workspace per engine and model).  The mutex orders
+ *     the HOST side only: forwards of the SAME model must be enqueued on one stream (or on streams ordered by events); a UNet
+ *     forward and a ResNet-18 forward of one engine may run on two streams at once (separate workspaces and scratch).
  *   - plain C types only: no torch / C++ types cross this boundary.
  */
 #ifndef CHESSVISION_HIP_H

@@ -184,3 +184,41 @@ def test_rotated_board_vertex_order(find_quadrangle):
                         for sx, sy in ((1, -1), (-1, -1), (-1, 1), (1, 1))])
     for c in corners:
         assert np.min(np.hypot(*(q - c).T)) <= 3.0
+
+
+def test_run_based_labelling_agrees_with_the_numpy_restatement_on_adversarial_masks(find_quadrangle):
+    """Round 4 replaced the two flood fills by a run-based union-find (csrc/contour.cpp).  Component order, hole detection
+    (4-connected background that does not touch the frame), bounding-box pruning and the traced borders must be unchanged: the C++
+    result equals the numpy restatement (scipy labelling) on noise of several densities, checkerboards (thousands of one-pixel
+    components), nested frames (holes inside components inside holes), widths that are not multiples of 8 / 64 (the bit packing's
+    tail) and degenerate rows."""
+    rng = np.random.default_rng(0)
+    checked = 0
+    for t in range(72):
+        h, w = [(256, 256), (64, 64), (37, 91), (128, 70), (9, 200), (65, 129)][t % 6]
+        kind = t % 8
+        if kind == 0:
+            m = rng.random((h, w)) < 0.5
+        elif kind == 1:
+            m = rng.random((h, w)) < 0.92
+        elif kind == 2:
+            m = np.zeros((h, w), bool); m[2:h - 2, 2:w - 2] = True
+            m[h // 3:h // 3 + 4, w // 3:w // 3 + 5] = False; m[h // 2, w // 2] = False
+        elif kind == 3:
+            m = np.ones((h, w), bool); m[rng.integers(0, h, 20), rng.integers(0, w, 20)] = False
+        elif kind == 4:
+            yy, xx = np.mgrid[0:h, 0:w]; m = ((yy // 3 + xx // 3) % 2 == 0)
+        elif kind == 5:
+            m = np.zeros((h, w), bool); m[1:h - 1, 1:w - 1] = True; m[3:h - 3, 3:w - 3] = False; m[5:h - 5, 5:w - 5] = True
+        elif kind == 6:
+            m = rng.random((h, w)) < 0.08
+        else:
+            m = np.zeros((h, w), bool); m[h // 4:3 * h // 4, w // 5:4 * w // 5] = True          # one clean quadrilateral
+            m ^= rng.random((h, w)) < 0.002                                                       # ... with salt-and-pepper noise
+        mask = (m * 255).astype(np.uint8)
+        got, want = find_quadrangle(mask), ChessVision._find_quadrangle(mask)
+        assert (got is None) == (want is None), (t, got, want)
+        if got is not None:
+            assert np.array_equal(got, want), (t, got, want)
+            checked += 1
+    assert checked >= 6
