@@ -156,6 +156,8 @@ class ChessVision:
         assert len(image.shape) == 3, "Image must be 3-dimensional (H,W,C)"
         logger.info("Starting image processing pipeline...")
         started = time.time()
+        if image.shape[2] == 3 and self._native(self.board_extractor) and self._native(self.classifier):
+            return self._process_image_native(image, threshold, flip, started)
         board_result = self.extract_board(image, threshold)
         position_result = None
         if board_result.board_image is None:
@@ -204,6 +206,26 @@ class ChessVision:
                                                    square_crops=squares)
 
     # ---- the native single-image path -----------------------------------------------------------------
+    def _process_image_native(self, image, threshold, flip, started, fallback_quad: bool = False) -> ChessVisionResult:
+        """``process_image`` as ONE native call (``cv_process_image``): upload, resize, UNet, mask, contours, homography, warp, split,
+        classifier, soft-max, FEN and the pawn rule all happen behind the C ABI; Python only wraps the arrays into the result records."""
+        from .hip_backend import process_image_native
+
+        r = process_image_native(self.board_extractor.engine, self.classifier.engine, image, threshold, flip, fallback_quad)
+        if not r["found"]:
+            logger.info("No valid board found in image")
+            extraction = BoardExtractionResult(board_image=None, binary_mask=r["mask"], quadrangle=None, probabilities=r["logits"])
+            return ChessVisionResult(board_extraction=extraction, position=None, processing_time=time.time() - started)
+        names = constants.SQUARE_NAMES_FLIPPED if flip else constants.SQUARE_NAMES_NORMAL
+        fixes = [ValidationFix(square_name=names[sq], original_piece=constants.LABEL_NAMES[old], corrected_piece=constants.LABEL_NAMES[new],
+                               rule_name="no_pawns_on_ends") for sq, old, new in r["fixes"]]
+        extraction = BoardExtractionResult(board_image=r["board"], binary_mask=r["mask"], quadrangle=r["quadrangle"], probabilities=r["logits"])
+        position = PositionResult(fen=r["fen"], original_fen=r["original_fen"], model_probabilities=r["probabilities"],
+                                  squares=self.extract_squares(r["board"]), square_names=names, validation_fixes=fixes)
+        elapsed = time.time() - started
+        logger.info(f"Processing completed in {elapsed:.2f} seconds")
+        return ChessVisionResult(board_extraction=extraction, position=position, processing_time=elapsed)
+
     def _staging(self, shape=None):
         """Page-locked staging buffers of the single-image path: mask, logits, board, squares, probabilities, homography (shared),
         and one image buffer per image shape seen (a server sees few distinct camera formats)."""

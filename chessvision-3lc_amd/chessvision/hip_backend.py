@@ -32,6 +32,13 @@ class HipBackendError(RuntimeError):
     """Raised for every non-zero status of the C ABI (message = ``cv_last_error()``)."""
 
 
+class _ImageResult(ctypes.Structure):             # mirrors cv_image_result_t (include/chessvision_hip.h)
+    _fields_ = [("logits", ctypes.POINTER(ctypes.c_float)), ("mask", ctypes.POINTER(ctypes.c_uint8)), ("quadrangle", ctypes.c_float * 8),
+                ("found", ctypes.c_int32), ("board", ctypes.POINTER(ctypes.c_uint8)), ("probabilities", ctypes.POINTER(ctypes.c_float)),
+                ("labels", ctypes.POINTER(ctypes.c_int8)), ("fen", ctypes.c_char * 72), ("original_fen", ctypes.c_char * 72),
+                ("fixes", ctypes.c_int32 * 64), ("n_fixes", ctypes.c_int32)]
+
+
 class _Param(ctypes.Structure):
     _fields_ = [("name", ctypes.c_char_p), ("data", ctypes.POINTER(ctypes.c_float)), ("ndim", ctypes.c_int32),
                 ("shape", ctypes.c_int64 * 4)]
@@ -90,6 +97,7 @@ SYMBOLS = [
     ("cv_profile_entry_kernel", _i, [_vp, _i, ctypes.c_char_p, _i]),
     ("cv_engine_export_calibration", _i, [_vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int32), _i, ctypes.POINTER(_i)]),
     ("cv_engine_import_calibration", _i, [_vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int32), _i, ctypes.POINTER(_i)]),
+    ("cv_process_image", _i, [_vp, _vp, _vp, _i, _i, _f, _i, _i, ctypes.c_void_p, _vp]),
     ("cv_board_homographies", _i, [_fp, _i, _i, _i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     ("cv_decode_positions", _i, [_fp, _i, _i, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int8),
                                  ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
@@ -204,6 +212,36 @@ def board_homographies(quads: np.ndarray, out_size=(512, 512), want_forward: boo
         _check(lib.cv_board_homographies(q.ctypes.data_as(_fp), n, int(out_size[0]), int(out_size[1]),
                                          fwd.ctypes.data_as(dp) if want_forward else None, inv.ctypes.data_as(dp)))
     return (inv, fwd) if want_forward else inv
+
+
+def process_image_native(unet_engine: "HipEngine", classifier_engine: "HipEngine", image: np.ndarray, threshold: float = 0.5,
+                         flip: bool = False, fallback_quad: bool = False) -> dict:
+    """One host image through ``cv_process_image`` (the native form of ``ChessVision.process_image``, reference core.py:152-195):
+    returns {"logits" (256,256) f32, "mask" (256,256) u8, "found", and when found "quadrangle" (4,1,2) f32, "board" (512,512) u8,
+    "probabilities" (64,13) f32, "fen", "original_fen", "fixes" [(square index, original class, corrected class)]}."""
+    lib = load_library()
+    img = np.ascontiguousarray(image, dtype=np.uint8)
+    if img.ndim != 3 or img.shape[2] != 3:
+        raise HipBackendError("process_image_native expects an (H,W,3) uint8 image")
+    logits = np.empty((256, 256), np.float32)
+    mask = np.empty((256, 256), np.uint8)
+    board = np.empty((512, 512), np.uint8)
+    probs = np.empty((64, 13), np.float32)
+    res = _ImageResult()
+    res.logits = logits.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+    res.mask = mask.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
+    res.board = board.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
+    res.probabilities = probs.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+    res.labels = None
+    _check(lib.cv_process_image(unet_engine._h, classifier_engine._h, img.ctypes.data_as(_vp), img.shape[0], img.shape[1],
+                                float(threshold), int(bool(flip)), int(bool(fallback_quad)), ctypes.byref(res),
+                                _stream_ptr(unet_engine.device)))
+    out = {"logits": logits, "mask": mask, "found": bool(res.found)}
+    if res.found:
+        out.update(quadrangle=np.array(list(res.quadrangle), dtype=np.float32).reshape(4, 1, 2), board=board, probabilities=probs,
+                   fen=res.fen.decode(), original_fen=res.original_fen.decode(),
+                   fixes=[(int(res.fixes[4 * i + 1]), int(res.fixes[4 * i + 2]), int(res.fixes[4 * i + 3])) for i in range(res.n_fixes)])
+    return out
 
 
 def decode_positions(probabilities: np.ndarray, flip: bool = False):

@@ -442,6 +442,40 @@ static int impl_cv_find_quadrangles(const uint8_t* masks, int n, int h, int w, i
     return CV_OK;
 }
 
+// INTER_AREA on `st` with the engine's cached tables for fractional shrinks (caller holds the engine mutex)
+static Status resize_on_stream(Engine& en, const uint8_t* src, int n, int h, int w_, int channels, uint8_t* dst, int out_h, int out_w, hipStream_t st) {
+    hipError_t e;
+    const bool integer = h % out_h == 0 && w_ % out_w == 0;
+    if (!integer && out_h <= h && out_w <= w_ && channels <= 4) {
+        // fractional shrink: OpenCV's float32 table form; the two tables are built once per geometry and stay on the device
+        const long long key = (((long long)h * 65536 + w_) * 65536 + out_h) * 65536 + out_w;
+        if (en.area_key != key) {
+            if (capture_flag()) return fail(CV_ERR_STATE, "resize tables rebuilt during graph capture");
+            std::vector<int> xo, xs, yo, ys;
+            std::vector<float> xa, ya;
+            resize_area_table(w_, out_w, xo, xs, xa);
+            resize_area_table(h, out_h, yo, ys, ya);
+            CV_HIP(hipStreamSynchronize(st));                          // a launch in flight may still read the previous tables
+            std::vector<char> blob;
+            auto put = [&](const void* p, size_t nbytes) { const size_t at = blob.size(); blob.resize(at + ((nbytes + 15) & ~(size_t)15)); std::memcpy(blob.data() + at, p, nbytes); return at; };
+            const size_t o0 = put(xo.data(), xo.size() * 4), o1 = put(xs.data(), xs.size() * 4), o2 = put(xa.data(), xa.size() * 4);
+            const size_t o3 = put(yo.data(), yo.size() * 4), o4 = put(ys.data(), ys.size() * 4), o5 = put(ya.data(), ya.size() * 4);
+            CV_TRY(en.area_tabs.upload(blob.data(), blob.size()));
+            const size_t off[6] = {o0, o1, o2, o3, o4, o5};
+            for (int i = 0; i < 6; ++i) en.area_off[i] = off[i];
+            en.area_key = key;
+        }
+        const char* base = (const char*)en.area_tabs.ptr;
+        e = resize_area_u8_tab(src, n, h, w_, channels, dst, out_h, out_w, (const int*)(base + en.area_off[0]), (const int*)(base + en.area_off[1]),
+                               (const float*)(base + en.area_off[2]), (const int*)(base + en.area_off[3]), (const int*)(base + en.area_off[4]),
+                               (const float*)(base + en.area_off[5]), st);
+    } else {
+        e = resize_area_u8(src, n, h, w_, channels, dst, out_h, out_w, st);
+    }
+    if (e != hipSuccess) return hip_fail(e, "resize_area_u8");
+    return Status();
+}
+
 static int impl_cv_resize_area_u8(cv_engine_t* eng, const uint8_t* src, int n, int h, int w_, int channels, uint8_t* dst, int out_h,
                       int out_w, void* stream) {
     Status s = check_engine(eng);
@@ -449,40 +483,8 @@ static int impl_cv_resize_area_u8(cv_engine_t* eng, const uint8_t* src, int n, i
     if (!src || !dst || n <= 0 || h <= 0 || w_ <= 0 || channels <= 0 || out_h <= 0 || out_w <= 0)
         return finish(fail(CV_ERR_INVALID, "cv_resize_area_u8: bad argument"));
     DeviceGuard g(eng->impl.device);
-    hipError_t e;
-    const bool integer = h % out_h == 0 && w_ % out_w == 0;
-    if (!integer && out_h <= h && out_w <= w_ && channels <= 4) {
-        // fractional shrink: OpenCV's float32 table form; the two tables are built once per geometry and stay on the device
-        std::lock_guard<std::mutex> lk(eng->impl.mu);
-        Engine& en = eng->impl;
-        const long long key = (((long long)h * 65536 + w_) * 65536 + out_h) * 65536 + out_w;
-        if (en.area_key != key) {
-            std::vector<int> xo, xs, yo, ys;
-            std::vector<float> xa, ya;
-            resize_area_table(w_, out_w, xo, xs, xa);
-            resize_area_table(h, out_h, yo, ys, ya);
-            e = hipStreamSynchronize((hipStream_t)stream);             // a launch in flight may still read the previous tables
-            if (e != hipSuccess) return finish(hip_fail(e, "cv_resize_area_u8"));
-            std::vector<char> blob;
-            auto put = [&](const void* p, size_t nbytes) { const size_t at = blob.size(); blob.resize(at + ((nbytes + 15) & ~(size_t)15)); std::memcpy(blob.data() + at, p, nbytes); return at; };
-            const size_t o0 = put(xo.data(), xo.size() * 4), o1 = put(xs.data(), xs.size() * 4), o2 = put(xa.data(), xa.size() * 4);
-            const size_t o3 = put(yo.data(), yo.size() * 4), o4 = put(ys.data(), ys.size() * 4), o5 = put(ya.data(), ya.size() * 4);
-            s = en.area_tabs.upload(blob.data(), blob.size());
-            if (!s.ok()) return finish(s);
-            const size_t off[6] = {o0, o1, o2, o3, o4, o5};
-            for (int i = 0; i < 6; ++i) en.area_off[i] = off[i];
-            en.area_key = key;
-            en.graph_invalidate();
-        }
-        const char* base = (const char*)en.area_tabs.ptr;
-        e = resize_area_u8_tab(src, n, h, w_, channels, dst, out_h, out_w, (const int*)(base + en.area_off[0]), (const int*)(base + en.area_off[1]),
-                               (const float*)(base + en.area_off[2]), (const int*)(base + en.area_off[3]), (const int*)(base + en.area_off[4]),
-                               (const float*)(base + en.area_off[5]), (hipStream_t)stream);
-    } else {
-        e = resize_area_u8(src, n, h, w_, channels, dst, out_h, out_w, (hipStream_t)stream);
-    }
-    if (e != hipSuccess) return finish(hip_fail(e, "resize_area_u8"));
-    return CV_OK;
+    std::lock_guard<std::mutex> lk(eng->impl.mu);
+    return finish(resize_on_stream(eng->impl, src, n, h, w_, channels, dst, out_h, out_w, (hipStream_t)stream));
 }
 
 static int impl_cv_extract_squares_u8(cv_engine_t* eng, const uint8_t* images, int n, int h, int w_, const double* inv_host,
@@ -551,6 +553,123 @@ static int impl_cv_board_homographies(const float* quads, int n, int out_w, int 
     if (n < 0 || out_w <= 0 || out_h <= 0 || (n > 0 && (!quads || (!forward && !inverse))))
         return finish(fail(CV_ERR_INVALID, "cv_board_homographies: bad argument"));
     board_homographies(quads, n, out_w, out_h, forward, inverse);
+    return CV_OK;
+}
+
+// ---- one image, host to host ---------------------------------------------------------------------------------------------
+static Status resize_on_stream(Engine& en, const uint8_t* src, int n, int h, int w_, int channels, uint8_t* dst, int out_h, int out_w, hipStream_t st);
+
+static int impl_cv_process_image(cv_engine_t* ue, cv_engine_t* ce, const uint8_t* image, int h, int w_, float threshold, int flip,
+                                 int fallback_quad, cv_image_result_t* out, void* stream) {
+    Status s = check_engine(ue);
+    if (s.ok()) s = check_engine(ce);
+    if (!s.ok()) return finish(s);
+    if (!image || !out || h <= 0 || w_ <= 0 || (size_t)h * w_ > ((size_t)1 << 28)) return finish(fail(CV_ERR_INVALID, "cv_process_image: bad argument"));
+    if (!(threshold >= 0.f && threshold <= 1.f)) return finish(fail(CV_ERR_INVALID, "threshold must be between 0 and 1"));
+    if (ue->impl.device != ce->impl.device) return finish(fail(CV_ERR_STATE, "cv_process_image: both engines must live on one device"));
+    Engine& U = ue->impl;
+    Engine& C = ce->impl;
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard g(U.device);
+    out->found = 0;
+    out->n_fixes = 0;
+    const size_t img_b = (size_t)h * w_ * 3, small_b = 256 * 256 * 3, lg_b = 65536 * sizeof(float), mk_b = 65536, sq_b = 64 * 4096,
+                 bd_b = 512 * 512, pr_b = 64 * 13 * sizeof(float), inv_b = 9 * sizeof(double);
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    // host block: image | mask | logits | board | probs | inv          device block: image | small | logits | mask | squares | board | probs | inv
+    const size_t h_off[6] = {0, up(img_b), up(img_b) + up(mk_b), up(img_b) + up(mk_b) + up(lg_b), up(img_b) + up(mk_b) + up(lg_b) + up(bd_b),
+                             up(img_b) + up(mk_b) + up(lg_b) + up(bd_b) + up(pr_b)};
+    const size_t h_need = h_off[5] + up(inv_b);
+    size_t d_off[8];
+    std::lock_guard<std::mutex> pipe_lock(U.pipe_mu);   // one request at a time per extractor engine: the staging blocks are shared
+    {
+        const size_t sizes[8] = {img_b, small_b, lg_b, mk_b, sq_b, bd_b, pr_b, inv_b};
+        size_t at = 0;
+        for (int i = 0; i < 8; ++i) { d_off[i] = at; at += up(sizes[i]); }
+        std::unique_lock<std::mutex> lk(U.mu);
+        if (U.pipe_host_bytes < h_need) {
+            hipError_t e = hipStreamSynchronize(st);
+            if (e != hipSuccess) return finish(hip_fail(e, "cv_process_image"));
+            if (U.pipe_host) (void)hipHostFree(U.pipe_host);
+            U.pipe_host = nullptr; U.pipe_host_bytes = 0;
+            e = hipHostMalloc(&U.pipe_host, h_need, hipHostMallocDefault);
+            if (e != hipSuccess) return finish(fail(CV_ERR_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e)));
+            U.pipe_host_bytes = h_need;
+        }
+        if (U.pipe_dev.bytes < at) {
+            hipError_t e = hipStreamSynchronize(st);
+            if (e != hipSuccess) return finish(hip_fail(e, "cv_process_image"));
+            U.graph_invalidate();
+            s = U.pipe_dev.alloc(at, false);
+            if (!s.ok()) return finish(s);
+        }
+    }
+    char* hb = (char*)U.pipe_host;
+    char* db = (char*)U.pipe_dev.ptr;
+    uint8_t* d_img = (uint8_t*)(db + d_off[0]); uint8_t* d_small = (uint8_t*)(db + d_off[1]); float* d_lg = (float*)(db + d_off[2]);
+    uint8_t* d_mk = (uint8_t*)(db + d_off[3]); uint8_t* d_sq = (uint8_t*)(db + d_off[4]); uint8_t* d_bd = (uint8_t*)(db + d_off[5]);
+    float* d_pr = (float*)(db + d_off[6]); double* d_inv = (double*)(db + d_off[7]);
+    uint8_t* h_img = (uint8_t*)(hb + h_off[0]); uint8_t* h_mk = (uint8_t*)(hb + h_off[1]); float* h_lg = (float*)(hb + h_off[2]);
+    uint8_t* h_bd = (uint8_t*)(hb + h_off[3]); float* h_pr = (float*)(hb + h_off[4]); double* h_inv = (double*)(hb + h_off[5]);
+
+    std::memcpy(h_img, image, img_b);
+    hipError_t e = hipMemcpyAsync(d_img, h_img, img_b, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return finish(hip_fail(e, "cv_process_image: upload"));
+    {
+        std::lock_guard<std::mutex> lk(U.mu);
+        s = resize_on_stream(U, d_img, 1, h, w_, 3, d_small, 256, 256, st);
+        if (s.ok()) s = unet_forward(U, d_small, true, 1, d_lg, d_mk, threshold, st);
+    }
+    if (!s.ok()) return finish(s);
+    e = hipMemcpyAsync(h_mk, d_mk, mk_b, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && !U.pipe_event) e = hipEventCreateWithFlags(&U.pipe_event, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(U.pipe_event, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(h_lg, d_lg, lg_b, hipMemcpyDeviceToHost, st);     // travels while the host finds the quadrangle
+    if (e == hipSuccess) e = hipEventSynchronize(U.pipe_event);
+    if (e != hipSuccess) return finish(hip_fail(e, "cv_process_image: mask"));
+    if (out->mask) std::memcpy(out->mask, h_mk, mk_b);
+    int32_t quad[8];
+    bool found = find_quadrangle(h_mk, 256, 256, quad);
+    if (!found && fallback_quad) {
+        const int32_t whole[8] = {255, 0, 0, 0, 0, 255, 255, 255};            // TR, TL, BL, BR of the mask
+        std::memcpy(quad, whole, sizeof(quad));
+        found = true;
+    }
+    if (found) {
+        // _scale_quadrangle (core.py:413-417): np.array(approx * (orig_h / 256.0), dtype=float32) -- a double product rounded to float
+        float corners[8];
+        const double factor = (double)h / 256.0;
+        for (int i = 0; i < 8; ++i) { corners[i] = (float)((double)quad[i] * factor); out->quadrangle[i] = corners[i]; }
+        board_homographies(corners, 1, 512, 512, nullptr, h_inv);
+        e = hipMemcpyAsync(d_inv, h_inv, inv_b, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = extract_squares_u8(d_img, 1, h, w_, d_inv, d_sq, d_bd, st);
+        if (e != hipSuccess) return finish(hip_fail(e, "cv_process_image: warp"));
+        {
+            std::lock_guard<std::mutex> lk(C.mu);
+            s = resnet_forward(C, d_sq, true, 64, d_pr, true, st);
+        }
+        if (!s.ok()) return finish(s);
+        e = hipMemcpyAsync(h_bd, d_bd, bd_b, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(h_pr, d_pr, pr_b, hipMemcpyDeviceToHost, st);
+        if (e != hipSuccess) return finish(hip_fail(e, "cv_process_image: download"));
+    }
+    {   // the numeric guards synchronise the stream: everything above has landed afterwards
+        std::lock_guard<std::mutex> lk(U.mu);
+        s = U.guard_check(st);
+    }
+    if (s.ok() && found && &C != &U) {
+        std::lock_guard<std::mutex> lk(C.mu);
+        s = C.guard_check(st);
+    }
+    if (!s.ok()) return finish(s);
+    if (out->logits) std::memcpy(out->logits, h_lg, lg_b);
+    if (!found) return CV_OK;
+    if (out->board) std::memcpy(out->board, h_bd, bd_b);
+    if (out->probabilities) std::memcpy(out->probabilities, h_pr, pr_b);
+    int8_t labels[64];
+    decode_positions(h_pr, 1, flip, out->fen, out->original_fen, labels, out->fixes, &out->n_fixes);
+    if (out->labels) std::memcpy(out->labels, labels, sizeof(labels));
+    out->found = 1;
     return CV_OK;
 }
 
@@ -785,6 +904,13 @@ int cv_engine_import_calibration(cv_engine_t* eng, const char* model, const int3
         const int rc = impl_cv_engine_calibration(eng, model, const_cast<int32_t*>(exps), count, &ch, 1);
         if (changed) *changed = ch;
         return rc;
+    });
+}
+
+int cv_process_image(cv_engine_t* unet_engine, cv_engine_t* classifier_engine, const uint8_t* image, int h, int w, float threshold,
+                     int flip, int fallback_quad, cv_image_result_t* out, void* stream) {
+    return guarded("cv_process_image", [&]() -> int {
+        return impl_cv_process_image(unet_engine, classifier_engine, image, h, w, threshold, flip, fallback_quad, out, stream);
     });
 }
 

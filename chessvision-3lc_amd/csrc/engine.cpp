@@ -402,6 +402,8 @@ Engine::~Engine() {
     prof_clear();
     graph_clear();
     if (capture_stream) (void)hipStreamDestroy(capture_stream);
+    if (pipe_host) (void)hipHostFree(pipe_host);
+    if (pipe_event) (void)hipEventDestroy(pipe_event);
 }
 
 void Engine::graph_clear() {

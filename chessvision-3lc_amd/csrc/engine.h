@@ -189,6 +189,12 @@ class Engine {
     // forward (0 = UNet and the single-layer entry points, 1 = ResNet-18) under the engine mutex.
     DeviceBuffer splitk_ws[2];
     int ws_slot = 0;
+    // staging of cv_process_image: one page-locked host block and one device block, carved up per call (grown on demand)
+    void* pipe_host = nullptr;
+    size_t pipe_host_bytes = 0;
+    DeviceBuffer pipe_dev;
+    std::mutex pipe_mu;                                 // one cv_process_image at a time per extractor engine (the staging is shared)
+    hipEvent_t pipe_event = nullptr;
     DeviceBuffer area_tabs;                             // INTER_AREA tables of the last fractional resize geometry (cv_resize_area_u8)
     long long area_key = -1;
     size_t area_off[6] = {0, 0, 0, 0, 0, 0};

@@ -42,7 +42,7 @@ extern "C" {
 #endif
 
 #define CV_ABI_VERSION 3      /* 2: CV_PREC_F16R, CV_ERR_NUMERIC + cv_engine_numeric_status, cv_engine_set_chunk before cv_load_* only
-                                 3: cv_board_homographies, cv_engine_export/import_calibration (additions only) */
+                                 3: cv_board_homographies, cv_engine_export/import_calibration, cv_process_image (additions only) */
 
 enum cv_status {
     CV_OK = 0,
@@ -246,6 +246,36 @@ int cv_extract_squares_u8_dev(cv_engine_t* eng, const uint8_t* images, int n, in
  * Needs no GPU and no engine. */
 int cv_decode_positions(const float* probs, int n_boards, int flip, char* fen, char* original_fen, int8_t* labels,
                         int32_t* fixes, int32_t* n_fixes);
+
+/* ---- one image, host to host: the native form of ChessVision.process_image (core.py:152-195) ---------------------------------- */
+/* Everything a cgo / JNI / C++ host needs for the reference's per-image entry point in ONE call: INTER_AREA resize to 256x256
+ * (core.py:212), UNet forward, sigmoid / threshold mask (core.py:273, utils.py:101-112), contours -> quadrangle (core.py:357-411),
+ * height-only scaling (core.py:413-417), perspective warp + gray + flip (utils.py:115-132, core.py:298-300), the 64-way split
+ * (core.py:419-439), classifier forward + soft-max (core.py:236-242), arg-max, pawn rule and both FENs (core.py:309-355,
+ * 441-469).  Same device stages, in the same order, as the Python class runs them; the results are bit-identical to it.
+ *   unet_engine: engine with a UNet loaded; classifier_engine: engine with a ResNet-18 loaded (may be the same handle).
+ *   image: HOST (h, w, 3) uint8, channels as given (BGR in the reference); flip != 0: the board is seen from black's side
+ *   (square names h1..a8, constants.py:120-129); fallback_quad != 0: classify through the whole-image quadrangle when the mask
+ *   yields none (not a reference behaviour: random-init weights in tests and benchmarks).
+ *   out: HOST, caller-owned; every pointer may be NULL except the struct itself.  found = 0: no quadrangle, board / probabilities /
+ *   FEN fields are left untouched.
+ * Synchronises `stream` (twice: mask, results).  Staging buffers (page-locked host memory and device memory for the image and
+ * the results) belong to unet_engine and are reused across calls. */
+typedef struct cv_image_result {
+    float*   logits;          /* 256 x 256 float32: BoardExtractionResult.probabilities (raw logits, core.py:287,306) */
+    uint8_t* mask;            /* 256 x 256 uint8 0 / 255 */
+    float    quadrangle[8];   /* 4 x (x, y) in image pixels, reference vertex order (TR, TL, BL, BR) */
+    int32_t  found;           /* 1: a quadrangle was found (or taken as fallback) and the position fields are valid */
+    uint8_t* board;           /* 512 x 512 uint8: the rectified, gray, flipped board image */
+    float*   probabilities;   /* 64 x 13 float32 soft-max, squares in a8..h1 order */
+    int8_t*  labels;          /* 64 validated class indices (order "BKNPQRbknpqrf") */
+    char     fen[72];         /* piece placement after the pawn rule */
+    char     original_fen[72];
+    int32_t  fixes[16 * 4];   /* {0, square index, original class, corrected class} */
+    int32_t  n_fixes;
+} cv_image_result_t;
+int cv_process_image(cv_engine_t* unet_engine, cv_engine_t* classifier_engine, const uint8_t* image, int h, int w,
+                     float threshold, int flip, int fallback_quad, cv_image_result_t* out, void* stream);
 
 /* MFMA lane-map self test: computes D = A(16xK) * B(Kx16) with the kernels' fragment loaders for both
  * precisions and returns the max abs error against a host reference (used by tests; 0 expected). */

@@ -85,26 +85,73 @@ static int host_mode(void) {
 }
 
 #ifdef WITH_GPU
-static int gpu_mode(const char* blob_path, const char* squares_path) {
+/* a state dict from a flat file: int32 count, then per entry int32 name length, name, int32 ndim, 4 x int64 shape, float32 data */
+static cv_param_t* read_blob(const char* blob_path, int32_t* n_out) {
     FILE* f = fopen(blob_path, "rb");
-    if (!f) { perror(blob_path); return 1; }
+    if (!f) { perror(blob_path); return NULL; }
     int32_t n_params = 0;
-    if (fread(&n_params, 4, 1, f) != 1) return 1;
+    if (fread(&n_params, 4, 1, f) != 1) return NULL;
     cv_param_t* table = (cv_param_t*)calloc((size_t)n_params, sizeof(cv_param_t));
     for (int i = 0; i < n_params; ++i) {
         int32_t len = 0, ndim = 0;
-        if (fread(&len, 4, 1, f) != 1) return 1;
+        if (fread(&len, 4, 1, f) != 1) return NULL;
         char* name = (char*)calloc((size_t)len + 1, 1);
-        if (fread(name, 1, (size_t)len, f) != (size_t)len || fread(&ndim, 4, 1, f) != 1) return 1;
-        if (fread(table[i].shape, 8, 4, f) != 4) return 1;
+        if (fread(name, 1, (size_t)len, f) != (size_t)len || fread(&ndim, 4, 1, f) != 1) return NULL;
+        if (fread(table[i].shape, 8, 4, f) != 4) return NULL;
         size_t numel = 1;
         for (int d = 0; d < ndim; ++d) numel *= (size_t)table[i].shape[d];
         float* data = (float*)malloc(numel * sizeof(float));
-        if (fread(data, sizeof(float), numel, f) != numel) return 1;
+        if (fread(data, sizeof(float), numel, f) != numel) return NULL;
         table[i].name = name; table[i].data = data; table[i].ndim = ndim;
     }
     fclose(f);
-    f = fopen(squares_path, "rb");
+    *n_out = n_params;
+    return table;
+}
+
+/* the reference's per-image entry point from plain C: one photo (int32 h, int32 w, h*w*3 bytes) -> FEN, one call */
+static int image_mode(const char* unet_blob, const char* resnet_blob, const char* image_path) {
+    int32_t nu = 0, nr = 0;
+    cv_param_t* tu = read_blob(unet_blob, &nu);
+    cv_param_t* tr = read_blob(resnet_blob, &nr);
+    if (!tu || !tr) return 1;
+    FILE* f = fopen(image_path, "rb");
+    if (!f) { perror(image_path); return 1; }
+    int32_t hw[2];
+    if (fread(hw, 4, 2, f) != 2) return 1;
+    uint8_t* image = (uint8_t*)malloc((size_t)hw[0] * hw[1] * 3);
+    if (fread(image, 3, (size_t)hw[0] * hw[1], f) != (size_t)hw[0] * hw[1]) return 1;
+    fclose(f);
+    cv_engine_t* eng = NULL;
+    CHECK(cv_engine_create(0, CV_PREC_F16X3, &eng));
+    CHECK(cv_load_unet(eng, tu, nu));
+    CHECK(cv_load_resnet18(eng, tr, nr));
+    static float probs[64 * 13], logits[256 * 256];
+    static uint8_t mask[256 * 256], board[512 * 512];
+    cv_image_result_t res;
+    memset(&res, 0, sizeof(res));
+    res.logits = logits; res.mask = mask; res.board = board; res.probabilities = probs;
+    for (int rep = 0; rep < 3; ++rep)                                         /* eager, graph capture, graph replay */
+        CHECK(cv_process_image(eng, eng, image, hw[0], hw[1], 0.5f, 0, 1, &res, NULL));
+    printf("pi_found %d\npi_fen %s\npi_orig %s\npi_quad", (int)res.found, res.fen, res.original_fen);
+    for (int i = 0; i < 8; ++i) printf(" %.9g", res.quadrangle[i]);
+    unsigned long long msum = 0, bsum = 0;
+    for (int i = 0; i < 256 * 256; ++i) msum += mask[i];
+    for (int i = 0; i < 512 * 512; ++i) bsum += (unsigned long long)board[i] * (unsigned)(i % 251 + 1);
+    printf("\npi_mask_sum %llu\npi_board_checksum %llu\npi_probs", msum, bsum);
+    for (int i = 0; i < 64 * 13; ++i) printf(" %.9g", probs[i]);
+    printf("\n");
+    int rc = cv_process_image(eng, eng, NULL, 512, 512, 0.5f, 0, 0, &res, NULL);
+    printf("pi_null_image rc=%d msg=%s\n", rc, cv_last_error());
+    CHECK(cv_engine_destroy(eng));
+    return 0;
+}
+
+static int gpu_mode(const char* blob_path, const char* squares_path) {
+    int32_t n_params = 0;
+    cv_param_t* table = read_blob(blob_path, &n_params);
+    if (!table) return 1;
+    FILE* f = fopen(squares_path, "rb");
     if (!f) { perror(squares_path); return 1; }
     int32_t n = 0;
     if (fread(&n, 4, 1, f) != 1) return 1;
@@ -143,7 +190,8 @@ int main(int argc, char** argv) {
     if (argc >= 2 && strcmp(argv[1], "host") == 0) return host_mode();
 #ifdef WITH_GPU
     if (argc >= 4 && strcmp(argv[1], "gpu") == 0) return gpu_mode(argv[2], argv[3]);
+    if (argc >= 5 && strcmp(argv[1], "image") == 0) return image_mode(argv[2], argv[3], argv[4]);
 #endif
-    fprintf(stderr, "usage: consumer host | consumer gpu <state.blob> <squares.bin>\n");
+    fprintf(stderr, "usage: consumer host | consumer gpu <state.blob> <squares.bin> | consumer image <unet.blob> <resnet.blob> <image.bin>\n");
     return 2;
 }

@@ -87,3 +87,44 @@ def test_classifier_from_plain_c_matches_python_binding_and_oracle(tmp_path):
     with torch.no_grad():
         ref = torch.softmax(net(torch.from_numpy(squares).float().div(255)[:, None]), 1).numpy()
     assert np.abs(got - ref).max() <= 1e-3
+
+
+def _write_blob(path, sd):
+    with open(path, "wb") as f:
+        f.write(struct.pack("<i", len(sd)))
+        for name, arr in sd.items():
+            a = np.ascontiguousarray(arr, dtype=np.float32)
+            f.write(struct.pack("<i", len(name)) + name.encode() + struct.pack("<i", a.ndim))
+            f.write(struct.pack("<4q", *(list(a.shape) + [0] * (4 - a.ndim))))
+            f.write(a.tobytes())
+
+
+@pytest.mark.gpu
+def test_process_image_from_plain_c_equals_the_python_class(tmp_path):
+    """`cv_process_image`: the reference's per-image entry point (core.py:152-195) as ONE call from a C host -- photo in, mask /
+    quadrangle / board / probabilities / FEN out.  Same bits as `ChessVision.process_image` (which wraps the same call) and as
+    the batched `process_images`."""
+    from chessvision import ChessVision, synthetic
+
+    usd, rsd = synthetic.unet_state_dict(1, segmenting=True), synthetic.resnet18_state_dict(2)
+    _write_blob(tmp_path / "unet.blob", usd)
+    _write_blob(tmp_path / "resnet.blob", rsd)
+    image = synthetic.board_photo(77)
+    (tmp_path / "image.bin").write_bytes(struct.pack("<2i", image.shape[0], image.shape[1]) + image.tobytes())
+    exe = _build(tmp_path / "consumer_image", gpu=True)
+    out = subprocess.run([str(exe), "image", str(tmp_path / "unet.blob"), str(tmp_path / "resnet.blob"), str(tmp_path / "image.bin")],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = dict(ln.split(" ", 1) for ln in out.stdout.strip().splitlines() if " " in ln)
+    pe, pc = synthetic.save_checkpoints(tmp_path, segmenting=True)
+    cv = ChessVision(board_extractor_weights=str(pe), classifier_weights=str(pc))
+    want = cv.process_images([image], fallback_quad=True)[0]
+    assert lines["pi_found"] == "1" and want.position is not None
+    assert lines["pi_fen"] == want.position.fen and lines["pi_orig"] == want.position.original_fen
+    assert np.array_equal(np.array(lines["pi_quad"].split(), dtype=np.float64).astype(np.float32).reshape(4, 1, 2), want.board_extraction.quadrangle)
+    assert int(lines["pi_mask_sum"]) == int(want.board_extraction.binary_mask.astype(np.uint64).sum())
+    board = want.board_extraction.board_image.reshape(-1).astype(np.uint64)
+    assert int(lines["pi_board_checksum"]) == int((board * (np.arange(board.size, dtype=np.uint64) % 251 + 1)).sum())
+    probs = np.array(lines["pi_probs"].split(), dtype=np.float64).astype(np.float32).reshape(64, 13)
+    assert np.array_equal(probs, want.position.model_probabilities)
+    assert lines["pi_null_image"].startswith("rc=1 msg=")
