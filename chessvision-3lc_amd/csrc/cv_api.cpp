@@ -493,6 +493,7 @@ static int impl_cv_extract_squares_u8(cv_engine_t* eng, const uint8_t* images, i
     if (!s.ok()) return finish(s);
     if (!images || !inv_host || !squares || n <= 0 || h <= 0 || w_ <= 0)
         return finish(fail(CV_ERR_INVALID, "cv_extract_squares_u8: bad argument"));
+    if ((size_t)h * (size_t)w_ > ((size_t)1 << 30)) return finish(fail(CV_ERR_INVALID, "cv_extract_squares_u8: image too large (32-bit byte offsets)"));
     if (((uintptr_t)squares & 3) || ((uintptr_t)boards & 3)) return finish(fail(CV_ERR_INVALID, "cv_extract_squares_u8: outputs must be 4-byte aligned"));
     std::lock_guard<std::mutex> lk(eng->impl.mu);
     DeviceGuard g(eng->impl.device);
@@ -739,6 +740,7 @@ static int impl_cv_extract_squares_u8_dev(cv_engine_t* eng, const uint8_t* image
     if (!s.ok()) return finish(s);
     if (!images || !inv_dev || !squares || n <= 0 || h <= 0 || w_ <= 0)
         return finish(fail(CV_ERR_INVALID, "cv_extract_squares_u8_dev: bad argument"));
+    if ((size_t)h * (size_t)w_ > ((size_t)1 << 30)) return finish(fail(CV_ERR_INVALID, "cv_extract_squares_u8_dev: image too large (32-bit byte offsets)"));
     if (((uintptr_t)squares & 3) || ((uintptr_t)boards & 3) || ((uintptr_t)inv_dev & 7))
         return finish(fail(CV_ERR_INVALID, "cv_extract_squares_u8_dev: outputs must be 4-byte aligned, matrices 8-byte aligned"));
     DeviceGuard g(eng->impl.device);

@@ -554,7 +554,7 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
         const int64_t tiles_igemm = blocks_for(L.rows, p.M, conv_cfg_ct(cfg), conv_cfg_pt(cfg));
         const int64_t tiles_halo = blocks_for(L.rows, p.M, ct, 256);
         const int64_t tiles_now = halo ? tiles_halo : tiles_igemm;
-        const bool halo_split_ok = halo_capable && Ho != 8 && knobs().splitk_halo;
+        const bool halo_split_ok = halo_capable && ct == 64 && Ho != 8 && knobs().splitk_halo;   // the production tile only (the 128-row A/B tile is not split)
         const int nCb = L.nStages / 9;
         const double bytes_igemm = 2.0 * (double)p.M * (double)p.nCt * conv_cfg_ct(cfg) * sizeof(float);   // one split's partials, written + read
         const double bytes_halo = 2.0 * (double)p.M * (double)((L.rows + ct - 1) / ct * ct) * sizeof(float);
