@@ -115,3 +115,21 @@ def test_two_ranks_on_one_gpu_over_gloo_run_the_sharded_bench():
     assert line["config"]["pipeline_e2e_ranks_boards_per_sec_min"] == round(e2e["boards_per_sec_per_rank"]["min"], 1)
     r = e2e["boards_per_sec_per_rank"]
     assert 0 < r["min"] <= r["mean"] <= r["max"] and e2e["boards_per_sec_whole_job"] > 0
+
+
+@pytest.mark.gpu
+def test_four_ranks_on_one_gpu_over_gloo():
+    """World size 4 (BASELINE's 1/2/4/8 curve has no hardware here): four ranks share the one MI355X over gloo, 4 x 32 boards sharded
+    r::4; the rank-major gather re-interleaves to board order, every rank takes part in the collectives, rank 0 holds all 128 FENs."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "CV_FORCE_DIST")}
+    env["CV_DIST_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "4", "--boards", "32", "--steps", "1", "--warmup", "1",
+                          "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=2400)
+    assert out.returncode == 0, out.stderr[-4000:]
+    lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 4 and line["rccl_ranks_seen"] == 4 and line["config"]["global_boards_per_step"] == 128
+    assert line["sharding"]["gathered_in_order"] is True and line["calibration_sync"]["identical_across_ranks"] is True
+    e2e = line["pipeline_e2e_ranks"]
+    assert e2e["global_boards"] == 128 and e2e["fens_on_rank0"] == 128 and e2e["calibration_identical_across_ranks"] is True
