@@ -24,6 +24,8 @@ done
 python3 tools/process_image_latency.py --prec f16x3,f16x3+f16r,f32 > "$OUT/process_image_latency.txt" 2>&1
 python3 tools/process_image_breakdown.py > "$OUT/process_image_breakdown.txt" 2>&1
 python3 tools/byte_kernels.py > "$OUT/byte_kernels.txt" 2>&1
+bash tools/pmc_byte_kernels.sh "$OUT" > "$OUT/pmc_byte_kernels.log" 2>&1
+bash tools/pmc_sq_b1.sh "$OUT" > "$OUT/pmc_sq_b1.log" 2>&1
 rm -rf /tmp/rp_b1
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_b1 -o b1 -- python3 "$(cd "$OLDPWD" && pwd)/tools/b1_trace.py" f16x3 50 > /tmp/rp_b1.log 2>&1)
 find /tmp/rp_b1 -name '*kernel_stats.csv' -exec cp {} "$OUT/b1_kernel_stats.csv" \;
