@@ -124,3 +124,23 @@ def test_perspective_matrix_and_warp_agree_with_the_product_bit_for_bit():
     flat = np.array([[1, 1], [2, 2], [3, 3], [4, 4]], np.float32)
     assert not classical.get_perspective_transform(flat, dest).any() and not cref.perspective_matrix(flat, dest).any()
     assert not board_homographies(flat[None], (512, 512)).any()
+
+
+def test_native_homographies_match_the_oracle_on_random_and_degenerate_quadrangles():
+    """Property test of `cv_board_homographies` (C++) against the oracle's scalar restatement: random convex and non-convex
+    quadrangles, huge and tiny coordinates, repeated points and collinear points (singular system -> zero matrices on both sides),
+    other output sizes -- identical doubles, not merely close."""
+    from chessvision.hip_backend import board_homographies
+
+    rng = np.random.default_rng(99)
+    quads = [rng.uniform(-50, 900, (4, 2)).astype(np.float32) for _ in range(300)]
+    quads += [np.array([[1e4, 3], [2, 5], [7, 9e3], [8e3, 8e3]], np.float32), np.array([[0.125, 0.25], [0.5, 0.75], [0.875, 1], [1.5, 0.0625]], np.float32)]
+    quads += [np.array([[5, 5], [5, 5], [9, 1], [1, 9]], np.float32), np.array([[0, 0], [1, 1], [2, 2], [3, 3]], np.float32),
+              np.array([[0, 0], [10, 0], [20, 0], [5, 7]], np.float32)]
+    for size in ((512, 512), (256, 384)):
+        dest = np.array(((0, 0), (size[0], 0), (size[0], size[1]), (0, size[1])), np.float32)
+        inv, fwd = board_homographies(np.stack(quads), size, want_forward=True)
+        for k, q in enumerate(quads):
+            m = cref.perspective_matrix(q, dest)
+            assert np.array_equal(fwd[k], m), (k, q)
+            assert np.array_equal(inv[k], cref._invert3(m)), (k, q)
