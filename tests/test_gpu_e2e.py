@@ -200,9 +200,8 @@ def test_process_image_is_the_native_pipeline_and_matches_batched_api_and_oracle
             assert np.array_equal(p.model_probabilities, q.model_probabilities)
             assert p.fen == q.fen and p.original_fen == q.original_fen and p.square_names == q.square_names
             assert np.array_equal(p.squares, q.squares) and p.validation_fixes == q.validation_fixes
-        if True:                                            # the oracle's independent resize covers every shrink factor
-            ref = pipeline_ref.process_image(unet, resnet, im)
-            _compare(single, ref, stats, resnet, im, fallback_quad=False)
+        ref = pipeline_ref.process_image(unet, resnet, im)   # the oracle's independent resize covers every shrink factor (4:3 photo too)
+        _compare(single, ref, stats, resnet, im, fallback_quad=False)
     assert sum(s.position is not None for s in singles) >= 6 and stats["fen_checked"] >= 4, stats
     # the two halves on their own: extract_board, then classify_position on a board that did NOT come from this instance's last call
     ext = cv_model.extract_board(images[1])
