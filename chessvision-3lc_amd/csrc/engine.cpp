@@ -397,7 +397,6 @@ bool calibration_enabled() {
 Engine::Engine() {
     layer_names.push_back("input tensor");
     graphs_on = env_int("CV_GRAPH", 1) != 0;
-    fork_on = env_int("CV_FORK", 1) != 0;
 }
 Engine::~Engine() {
     prof_clear();
@@ -405,24 +404,6 @@ Engine::~Engine() {
     if (capture_stream) (void)hipStreamDestroy(capture_stream);
     if (pipe_host) (void)hipHostFree(pipe_host);
     if (pipe_event) (void)hipEventDestroy(pipe_event);
-    for (hipEvent_t ev : fork_ev)
-        if (ev) (void)hipEventDestroy(ev);
-    if (side_stream) (void)hipStreamDestroy(side_stream);
-}
-
-Status Engine::fork(hipStream_t main, int ev) {
-    if (!side_stream) CV_HIP(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
-    if (!fork_ev[ev]) CV_HIP(hipEventCreateWithFlags(&fork_ev[ev], hipEventDisableTiming));
-    CV_HIP(hipEventRecord(fork_ev[ev], main));
-    CV_HIP(hipStreamWaitEvent(side_stream, fork_ev[ev], 0));
-    return Status();
-}
-
-Status Engine::join(hipStream_t main, int ev) {
-    if (!fork_ev[ev]) CV_HIP(hipEventCreateWithFlags(&fork_ev[ev], hipEventDisableTiming));
-    CV_HIP(hipEventRecord(fork_ev[ev], side_stream));
-    CV_HIP(hipStreamWaitEvent(main, fork_ev[ev], 0));
-    return Status();
 }
 
 void Engine::graph_clear() {
@@ -617,7 +598,7 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
             p.kper = kper;
             p.prow = split_kind == 2 ? (L.rows + ct - 1) / ct * ct : p.nCt * conv_cfg_ct(cfg);
             const size_t need = (size_t)p.ksplit * (size_t)p.M * (size_t)p.prow * sizeof(float);
-            DeviceBuffer& ws = splitk_ws[ws_slot >= 0 && ws_slot < 3 ? ws_slot : 0];
+            DeviceBuffer& ws = splitk_ws[ws_slot & 1];
             if (ws.bytes < need) {
                 if (capture_flag()) return fail(1, "split-K buffer growth during graph capture");   // run_graphed falls back to an eager run
                 graph_invalidate();

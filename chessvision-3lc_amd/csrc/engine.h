@@ -186,17 +186,9 @@ class Engine {
     DeviceBuffer scratch;                               // small per-call parameter blocks (homographies)
     // f32 partial sums of split-K conv launches (grown on demand).  One buffer per model: the UNet pass and the ResNet-18 pass of one
     // engine may be enqueued on two streams (bench.py --overlap 1) and must not share scratch memory; ws_slot is set by the model's
-    // forward (0 = UNet and the single-layer entry points, 1 = ResNet-18, 2 = the side stream of a fork) under the engine mutex.
-    DeviceBuffer splitk_ws[3];
+    // forward (0 = UNet and the single-layer entry points, 1 = ResNet-18) under the engine mutex.
+    DeviceBuffer splitk_ws[2];
     int ws_slot = 0;
-    // Fork / join inside a forward (single boards): an independent launch (ResNet-18 shortcut convolution beside conv1) goes to the
-    // engine's side stream between two events; under graph capture the same calls become a fork and a join of the graph.  Slot 2 of the
-    // split-K scratch belongs to the side stream.  CV_FORK=0 keeps everything on one stream.
-    hipStream_t side_stream = nullptr;
-    hipEvent_t fork_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    bool fork_on = true;
-    Status fork(hipStream_t main, int ev);              // side stream starts behind everything enqueued on `main` so far
-    Status join(hipStream_t main, int ev);              // `main` continues behind everything enqueued on the side stream so far
     // staging of cv_process_image: one page-locked host block and one device block, carved up per call (grown on demand)
     void* pipe_host = nullptr;
     size_t pipe_host_bytes = 0;

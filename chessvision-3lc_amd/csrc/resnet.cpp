@@ -259,40 +259,20 @@ static Status resnet_chunk(Engine& e, const void* x, bool x_u8, int n, float* ou
         if (e.calibrating) CV_TRY(e.measure(R.pool_out.ref(n), s));
     }
     TensorRef cur = R.pool_out.ref(n);
-    // Small batches (a board's 64 squares): the 1x1 shortcut convolution of a down-sampling block is independent of the block's conv1 and
-    // neither fills the chip -- it runs on the engine's side stream between a fork and a join (a branch of the graph under capture).
-    const bool forked = e.fork_on && !e.profiling && !e.calibrating && n <= 512;
-    int n_fork = 0;
     for (int i = 0; i < 8; ++i) {
         Engine::ResNet::Block& B = R.blocks[i];
         TensorRef shortcut = cur;
-        bool pending_join = false;
         if (B.has_down) {
-            hipStream_t ds = s;
-            if (forked) {
-                CV_TRY(e.fork(s, 2 * n_fork));
-                ds = e.side_stream;
-                e.ws_slot = 2;
-                pending_join = true;
-            }
-            Status st;
             if (B.sc.only32) {                                 // f16r: f32 convolution from the trunk's twin to the shortcut's
                 TensorRef in32 = cur;
                 in32.base = cur.base32; in32.base32 = nullptr; in32.f32_only = 1;
-                st = e.run_conv(B.down, in32, B.sc.ref32(n), nullptr, false, ds);
+                CV_TRY(e.run_conv(B.down, in32, B.sc.ref32(n), nullptr, false, s));
             } else {
-                st = e.run_conv(B.down, cur, B.sc.ref(n), nullptr, false, ds);
-            }
-            e.ws_slot = 1;
-            if (!st.ok()) {
-                if (pending_join) (void)e.join(s, 2 * n_fork + 1);            // never leave the side stream un-joined (graph capture)
-                return st;
+                CV_TRY(e.run_conv(B.down, cur, B.sc.ref(n), nullptr, false, s));
             }
             shortcut = B.sc.ref(n);
         }
-        Status st1 = e.run_conv(B.conv1, cur, B.mid.ref(n), nullptr, true, s);
-        if (pending_join) { CV_TRY(e.join(s, 2 * n_fork + 1)); ++n_fork; }
-        CV_TRY(st1);
+        CV_TRY(e.run_conv(B.conv1, cur, B.mid.ref(n), nullptr, true, s));
         CV_TRY(e.run_conv(B.conv2, B.mid.ref(n), B.out.ref(n), &shortcut, true, s));
         cur = B.out.ref(n);
     }
