@@ -144,3 +144,19 @@ def test_native_homographies_match_the_oracle_on_random_and_degenerate_quadrangl
             m = cref.perspective_matrix(q, dest)
             assert np.array_equal(fwd[k], m), (k, q)
             assert np.array_equal(inv[k], cref._invert3(m)), (k, q)
+
+
+def test_fractional_inter_area_on_random_sizes_including_near_integer_factors():
+    """The table form has data-dependent structure: a leading / trailing partial cell only when it covers more than 1e-3 of a pixel,
+    a clamped last cell, one to three (shrink < 2) or many (shrink > 3) entries per destination pixel.  Random source sizes --
+    including sizes one pixel off an integer factor, where the partial cells are tiny -- give the same bytes in the product's
+    vectorised form and in the oracle's scalar form, for 1- and 3-channel images and non-square targets."""
+    rng = np.random.default_rng(123)
+    shapes = [(257, 511, 3), (511, 513, 3), (513, 257, 1), (767, 769, 3), (1023, 640, 3), (256, 300, 3), (300, 256, 3)]
+    shapes += [(int(rng.integers(256, 700)), int(rng.integers(256, 700)), 3) for _ in range(5)]
+    for shape in shapes:
+        photo = rng.integers(0, 256, shape, dtype=np.uint8)
+        got = classical.resize_area(photo, (256, 256))
+        assert np.array_equal(got, cref.resize_area(photo, (256, 256))), shape
+    photo = rng.integers(0, 256, (333, 444, 3), dtype=np.uint8)
+    assert np.array_equal(classical.resize_area(photo, (200, 100)), cref.resize_area(photo, (100, 200)))     # (width, height) vs (h, w)

@@ -102,6 +102,11 @@ def test_device_resize_matches_host_restatement(engines):
         want = np.stack([classical.resize_area(im, (256, 256)) for im in odd])
         assert np.array_equal(got, want), shape                              # device == host
         assert np.array_equal(got[0], cref.resize_area(odd[0], (256, 256)))  # ... == the independent oracle
+    for _ in range(8):                                                       # random sizes, tables rebuilt per geometry
+        h, w = int(rng.integers(256, 900)), int(rng.integers(256, 900))
+        odd = rng.integers(0, 256, (2, h, w, 3), dtype=np.uint8)
+        got = engines["f32"].resize_area_u8(torch.from_numpy(odd), (256, 256)).cpu().numpy()
+        assert np.array_equal(got, np.stack([classical.resize_area(im, (256, 256)) for im in odd])), (h, w)
 
 
 def test_device_warp_gray_flip_split_matches_host_chain(engines):
