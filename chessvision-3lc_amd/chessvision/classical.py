@@ -48,17 +48,24 @@ def _area_tab(src: int, dst: int):
     return idx, wgt, cnt
 
 
-def _linear_weights(src: int, dst: int) -> NDArray[np.float64]:
-    scale = src / dst
-    w = np.zeros((dst, src), dtype=np.float64)
-    for d in range(dst):
-        f = (d + 0.5) * scale - 0.5
-        i0 = int(np.floor(f))
-        t = f - i0
-        a, b = min(max(i0, 0), src - 1), min(max(i0 + 1, 0), src - 1)
-        w[d, a] += 1.0 - t
-        w[d, b] += t
-    return w
+def _area_linear_coeffs(src: int, dst: int):
+    """One axis of the bilinear form cv2.resize falls back to when INTER_AREA has to ENLARGE (OpenCV ``resize.cpp``: "true area
+    interpolation is only implemented for scale_x >= 1 && scale_y >= 1; in other cases it is emulated using some variant of bilinear
+    interpolation"): source index ``s = floor(d * scale)``, fraction ``f = (float)((d + 1) - (s + 1) * inv_scale)`` reduced to
+    [0, 1) (0 when not positive), both clamped at the last source pixel, and the 11-bit fixed-point pair
+    ``(short)round((1 - f) * 2048), (short)round(f * 2048)`` (INTER_RESIZE_COEF_BITS).  Returns (s0, s1, a0, a1) as int64 arrays."""
+    inv_scale = dst / src
+    scale = 1.0 / inv_scale
+    d = np.arange(dst, dtype=np.float64)
+    s0 = np.floor(d * scale).astype(np.int64)
+    f = ((d + 1.0) - (s0 + 1).astype(np.float64) * inv_scale).astype(np.float32)
+    f = np.where(f <= 0, np.float32(0), f - np.floor(f)).astype(np.float32)
+    last = s0 >= src - 1
+    f = np.where(last, np.float32(0), f).astype(np.float32)
+    s0 = np.where(last, src - 1, s0)
+    a0 = np.rint((np.float32(1.0) - f) * np.float32(2048.0)).astype(np.int64)
+    a1 = np.rint(f * np.float32(2048.0)).astype(np.int64)
+    return s0, np.minimum(s0 + 1, src - 1), a0, a1
 
 
 def resize_area(image: NDArray[np.uint8], size: tuple[int, int]) -> NDArray[np.uint8]:
@@ -69,8 +76,10 @@ def resize_area(image: NDArray[np.uint8], size: tuple[int, int]) -> NDArray[np.u
     ``buf = buf + S * alpha`` over the table entries of a destination column, vertical pass ``sum = beta * buf`` for the first source
     row and ``sum += beta * buf`` for the others, round half to even -- so that host, device (``pipeline.hip``) and the independent
     oracle agree bit for bit (round 4; before, a coverage-weighted mean in double: one grey level apart on 2.5 % of the pixels).
-    Enlarging (an image smaller than the target) goes through a plain bilinear blend, an approximation of OpenCV's fixed-point
-    bilinear path that INTER_AREA takes for scale < 1."""
+    Enlarging in either direction (a photo smaller than the target): OpenCV's fixed-point bilinear path with the AREA coefficient
+    rule (``_area_linear_coeffs``): horizontal pass ``S[s0] * a0 + S[s1] * a1`` in int32, vertical pass
+    ``(((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2`` (``VResizeLinear`` for 8-bit images) -- exact integers, so
+    host, device and the independent oracle agree byte for byte (round 5; before, a plain double-precision bilinear blend)."""
     w_out, h_out = size
     img = image if image.ndim == 3 else image[:, :, None]
     h, w, _ = img.shape
@@ -95,15 +104,16 @@ def resize_area(image: NDArray[np.uint8], size: tuple[int, int]) -> NDArray[np.u
             total[live] = term if j == 0 else total[live] + term
         out = np.clip(np.rint(total), 0, 255).astype(np.uint8)
     else:
-        wy = _linear_weights(h, h_out)
-        wx = _linear_weights(w, w_out)
-        acc = np.einsum("ys,swc->ywc", wy, img.astype(np.float64))
-        acc = np.einsum("xw,ywc->yxc", wx, acc)
-        out = np.clip(np.rint(acc), 0, 255).astype(np.uint8)
+        x0, x1, a0, a1 = _area_linear_coeffs(w, w_out)
+        y0, y1, b0, b1 = _area_linear_coeffs(h, h_out)
+        src = img.astype(np.int64)
+        rows = src[:, x0] * a0[None, :, None] + src[:, x1] * a1[None, :, None]           # (h, w_out, c), 11 fractional bits
+        acc = ((b0[:, None, None] * (rows[y0] >> 4)) >> 16) + ((b1[:, None, None] * (rows[y1] >> 4)) >> 16)
+        out = ((acc + 2) >> 2).astype(np.uint8)
     return out if image.ndim == 3 else out[:, :, 0]
 
 
-# ---- contours (cv2.findContours(mask, RETR_CCOMP, CHAIN_APPROX_*), core.py:360) -------------------------
+# ---- contours (cv2.findContours(mask, RETR_CCOMP, CHAIN_APPROX_TC89_KCOS), core.py:360) ----------------
 def _trace_border(f: NDArray[np.bool_], start: tuple[int, int], prev: tuple[int, int]) -> NDArray[np.int32]:
     """Suzuki-Abe border following (step 3 of Algorithm 1) from ``start`` with ``prev`` the background pixel
     the raster scan came from.  Returns the border as (x, y) points in traversal order."""
@@ -142,35 +152,118 @@ def _trace_border(f: NDArray[np.bool_], start: tuple[int, int], prev: tuple[int,
     return np.array(pts, dtype=np.int32)
 
 
-def find_contours(mask: NDArray[np.uint8]) -> list[NDArray[np.int32]]:
-    """Outer borders of the 8-connected foreground components, then hole borders (RETR_CCOMP returns both
-    levels as one flat list).  Every border pixel is returned (CHAIN_APPROX_NONE); the reference asks for
-    TC89_KCOS chain compression, which only thins the point list that ``approx_poly_dp`` consumes next."""
+# OpenCV's direction codes (0 = east, then counter-clockwise on screen: NE, N, NW, W, SW, S, SE) by (dy, dx)
+_CODE = {(0, 1): 0, (-1, 1): 1, (-1, 0): 2, (-1, -1): 3, (0, -1): 4, (1, -1): 5, (1, 0): 6, (1, 1): 7}
+_ABS_DIFF = (1, 2, 3, 4, 3, 2, 1, 0, 1, 2, 3, 4, 3, 2, 1)
+
+
+def _f32_bits(value: float) -> int:
+    """Bit pattern of ``(float)value`` as a signed 32-bit integer (OpenCV compares its k-cosines through ``Cv32suf.i``)."""
+    return int(np.array([value], dtype=np.float32).view(np.int32)[0])
+
+
+def tc89_kcos(points: NDArray[np.int32]) -> NDArray[np.int32]:
+    """``CHAIN_APPROX_TC89_KCOS`` as cv2.findContours applies it to a traced chain (OpenCV ``icvApproximateChainTC89``; reference
+    call site core.py:360).  ``points`` (n, 2) = every border pixel in tracing order.  Pass 0 keeps the points where the chain
+    code changes.  Pass 1 gives each its Teh-Chin region of support k -- grown while the chord p[i-k] p[i+k] lengthens and the
+    ratio (distance of p[i] to the chord) / (chord length) rises -- and its k-cosine: cos of the angle p[i-j] p[i] p[i+j] plus 1.1,
+    rounded to float32 and compared through its bit pattern, walked from j = k downwards while it grows.  Pass 2 suppresses points
+    that have a larger measure within k/2 chain steps (a suppressed point counts as 0 for the points after it).  Pass 3 removes
+    points of support 1 that do not beat both chain neighbours."""
+    pts = np.asarray(points).reshape(-1, 2).astype(np.int64)
+    n = len(pts)
+    if n <= 1:
+        return pts.astype(np.int32)
+    px, py = pts[:, 0].tolist(), pts[:, 1].tolist()
+    code = [_CODE[(py[(i + 1) % n] - py[i], px[(i + 1) % n] - px[i])] for i in range(n)]
+    s = [_ABS_DIFF[code[i] - code[i - 1] + 7] for i in range(n)]
+    kept = [i for i in range(n) if s[i] != 0]
+    if not kept:
+        return pts.astype(np.int32)
+    k = [0] * n
+    for i in kept:
+        x0, y0 = px[i], py[i]
+        kk, l, d_num = 1, 0, 0
+        while True:
+            i1, i2 = (i - kk) % n, (i + kk) % n
+            dx, dy = px[i2] - px[i1], py[i2] - py[i1]
+            lk = dx * dx + dy * dy
+            dk_num = (x0 - px[i1]) * dy - (y0 - py[i1]) * dx
+            d = d_num * lk - dk_num * l                       # exact integers; OpenCV's float cast keeps the sign
+            if kk > 1 and (l >= lk or (d_num > 0 and d <= 0) or (d_num < 0 and d >= 0)):
+                break
+            d_num, l = dk_num, lk
+            kk += 1
+            if kk > n:
+                return pts.astype(np.int32)                   # OpenCV asserts k <= len
+        kk -= 1
+        k[i] = kk
+        sv = 0
+        for j in range(kk, 0, -1):
+            i1, i2 = (i - j) % n, (i + j) % n
+            dx1, dy1, dx2, dy2 = px[i1] - x0, py[i1] - y0, px[i2] - x0, py[i2] - y0
+            if (dx1 == 0 and dy1 == 0) or (dx2 == 0 and dy2 == 0):
+                break
+            cos = float(np.float32(float(dx1 * dx2 + dy1 * dy2) /
+                                   float(np.sqrt(np.float64((dx1 * dx1 + dy1 * dy1) * (dx2 * dx2 + dy2 * dy2))))))
+            sk = _f32_bits(cos + 1.1)
+            if j < kk and sk <= sv:
+                break
+            sv = sk
+        s[i] = sv
+    survivors = []
+    for i in kept:                                            # pass 2
+        k2 = k[i] >> 1
+        if any(s[(i - j) % n] > s[i] or s[(i + j) % n] > s[i] for j in range(1, k2 + 1)):
+            s[i] = 0
+        else:
+            survivors.append(i)
+    final = []
+    for i in survivors:                                       # pass 3
+        if k[i] == 1 and (s[i] <= s[(i - 1) % n] or s[i] <= s[(i + 1) % n]):
+            s[i] = 0
+        else:
+            final.append(i)
+    return pts[final].astype(np.int32)
+
+
+def find_contours(mask: NDArray[np.uint8], tc89: bool = True, with_holes_flag: bool = False):
+    """``cv2.findContours(mask, RETR_CCOMP, CHAIN_APPROX_TC89_KCOS)[0]`` (reference core.py:360; ``tc89=False``: CHAIN_APPROX_NONE):
+    the outer border of every 8-connected foreground component and the border of every hole (4-connected background that does not
+    reach the frame), traced from OpenCV's start pixel in OpenCV's direction, in OpenCV's order -- it links a new contour in front
+    of its parent's children and lists the two-level tree in pre-order: outer borders from the LAST found in raster order to the
+    first, each followed by its holes, last found first."""
     f = np.asarray(mask) != 0
-    out: list[NDArray[np.int32]] = []
     lab, n = ndimage.label(f, structure=np.ones((3, 3), dtype=bool))
-    if n:
-        firsts = ndimage.minimum_position(np.arange(f.size).reshape(f.shape), lab, index=np.arange(1, n + 1))
-        for (y, x) in firsts:
-            out.append(_trace_border(f, (int(y), int(x)), (int(y), int(x) - 1)).reshape(-1, 1, 2))
-    # holes: 4-connected background components that do not touch the frame
+    index = np.arange(f.size).reshape(f.shape)
+    outer = ndimage.minimum_position(index, lab, index=np.arange(1, n + 1)) if n else []
+    holes_of: dict[int, list[tuple[int, int]]] = {}
     blab, bn = ndimage.label(~f)
     if bn:
         frame = set(np.unique(np.concatenate([blab[0], blab[-1], blab[:, 0], blab[:, -1]]))) - {0}
         ids = [k for k in range(1, bn + 1) if k not in frame]
         if ids:
-            firsts = ndimage.minimum_position(np.arange(f.size).reshape(f.shape), blab, index=ids)
-            for (y, x) in firsts:       # (y, x) = first hole pixel; the pixel to its left is foreground
-                out.append(_trace_border(f, (int(y), int(x) - 1), (int(y), int(x))).reshape(-1, 1, 2))
-    return out
+            for (y, x) in ndimage.minimum_position(index, blab, index=ids):      # raster order of the holes' first pixels
+                holes_of.setdefault(int(lab[y, x - 1]), []).append((int(y), int(x)))
+    out, flags = [], []
+    for comp in range(n, 0, -1):
+        y, x = outer[comp - 1]
+        out.append(_trace_border(f, (int(y), int(x)), (int(y), int(x) - 1)))
+        flags.append(False)
+        for (hy, hx) in reversed(holes_of.get(comp, [])):   # (hy, hx) = first hole pixel; the pixel to its left is foreground
+            out.append(_trace_border(f, (hy, hx - 1), (hy, hx)))
+            flags.append(True)
+    out = [(tc89_kcos(c) if tc89 else c).reshape(-1, 1, 2) for c in out]
+    return (out, flags) if with_holes_flag else out
 
 
 def contour_area(contour: NDArray[np.int32]) -> float:
+    """cv2.contourArea: the shoelace sum in double (exact for pixel coordinates)."""
     p = contour.reshape(-1, 2).astype(np.float64)
-    if len(p) < 3:
+    if len(p) == 0:
         return 0.0
     x, y = p[:, 0], p[:, 1]
-    return float(abs(np.dot(x, np.roll(y, -1)) - np.dot(y, np.roll(x, -1))) * 0.5)
+    return float(abs(np.dot(np.roll(x, 1), y) - np.dot(np.roll(y, 1), x)) * 0.5)
 
 
 def bounding_rect(contour: NDArray[np.int32]) -> tuple[int, int, int, int]:
@@ -180,62 +273,103 @@ def bounding_rect(contour: NDArray[np.int32]) -> tuple[int, int, int, int]:
 
 
 def arc_length(contour: NDArray[np.int32], closed: bool = True) -> float:
-    p = contour.reshape(-1, 2).astype(np.float64)
-    d = np.diff(np.vstack([p, p[:1]]) if closed else p, axis=0)
-    return float(np.sqrt((d * d).sum(axis=1)).sum())
+    """cv2.arcLength: OpenCV converts the points to Point2f and takes every segment's length in FLOAT (``std::sqrt`` of a float),
+    summing in double -- for a closed curve starting with the segment from the last point to the first."""
+    p = contour.reshape(-1, 2).astype(np.float32)
+    if len(p) <= 1:
+        return 0.0
+    d = p - np.roll(p, 1, axis=0)
+    if not closed:
+        d = d[1:]
+    seg = np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(np.float32)).astype(np.float32)
+    total = 0.0
+    for v in seg.tolist():                                    # sequential double sum, OpenCV's order
+        total += v
+    return total
 
 
 def approx_poly_dp(contour: NDArray[np.int32], epsilon: float) -> NDArray[np.int32]:
-    """Douglas-Peucker for a CLOSED curve, following cv2.approxPolyDP's strategy: (1) three farthest-point hops
-    from point 0 pick the initial split, (2) stack-driven refinement against ``epsilon``, (3) one clean-up sweep
-    that drops vertices lying within sqrt(0.5)*epsilon of the chord between their neighbours."""
-    src = contour.reshape(-1, 2).astype(np.int64)
+    """cv2.approxPolyDP(contour, epsilon, closed=True) for integer points (OpenCV ``approxPolyDP_<int>``): (1) three farthest-point
+    hops from point 0 pick the first split, (2) a stack of (start, end) slices drives Douglas-Peucker -- a slice's start point is
+    emitted when nothing inside is farther than epsilon from its chord, else it splits at the farthest point, (3) ONE clean-up pass
+    over the result, in place as OpenCV does it: a vertex within sqrt(0.5)*epsilon of the chord of its neighbours (chord not
+    axis-parallel, vertex between them) is dropped and its successor kept without being examined."""
+    src = [(int(x), int(y)) for x, y in np.asarray(contour).reshape(-1, 2)]
     count = len(src)
     if count == 0:
         return np.zeros((0, 1, 2), dtype=np.int32)
-    eps2 = float(epsilon) * float(epsilon)
+    eps = float(epsilon) * float(epsilon)
     pos, right_start, le_eps = 0, 0, False
+    start = (-1000000, -1000000)
     for _ in range(3):
+        max_dist = 0.0
         pos = (pos + right_start) % count
-        d = ((np.roll(src, -pos, axis=0) - src[pos]) ** 2).sum(axis=1)
-        j = int(np.argmax(d[1:])) + 1 if count > 1 else 0
-        right_start = j
-        le_eps = float(d[j]) <= eps2
-    if le_eps:
-        return src[pos].reshape(1, 1, 2).astype(np.int32)
-    a, b = pos % count, (right_start + pos) % count
-    stack = [(b, a), (a, b)]
+        start = src[pos]
+        for j in range(1, count):
+            pt = src[(pos + j) % count]
+            dist = float((pt[0] - start[0]) ** 2 + (pt[1] - start[1]) ** 2)
+            if dist > max_dist:
+                max_dist, right_start = dist, j
+        le_eps = max_dist <= eps
     dst: list[tuple[int, int]] = []
+    stack: list[tuple[int, int]] = []
+    if not le_eps:
+        a = pos % count
+        b = (right_start + a) % count
+        stack += [(b, a), (a, b)]
+    else:
+        dst.append(start)
+    split = right_start
     while stack:
         s, e = stack.pop()
         start, end = src[s], src[e]
-        if (s + 1) % count != e:
-            idx = np.arange(s + 1, e if e > s else e + count) % count
+        pos = (s + 1) % count
+        if pos != e:
+            max_dist = 0.0
             dx, dy = float(end[0] - start[0]), float(end[1] - start[1])
-            dist = np.abs((src[idx, 1] - start[1]) * dx - (src[idx, 0] - start[0]) * dy)
-            m = int(np.argmax(dist))
-            le = float(dist[m]) ** 2 <= eps2 * (dx * dx + dy * dy)
-            split = int(idx[m])
+            while pos != e:
+                pt = src[pos]
+                dist = abs((pt[1] - start[1]) * dx - (pt[0] - start[0]) * dy)
+                if dist > max_dist:
+                    max_dist, split = dist, pos
+                pos = (pos + 1) % count
+            le = max_dist * max_dist <= eps * (dx * dx + dy * dy)
         else:
-            le, split = True, s
+            le = True
         if le:
-            dst.append((int(start[0]), int(start[1])))
+            dst.append(start)
         else:
-            stack.append((split, e))
-            stack.append((s, split))
-    # clean-up sweep over the closed result: drop a vertex when it is (nearly) on the chord of its neighbours
-    pts = list(dst)
+            stack += [(split, e), (s, split)]
+    cnt = new_count = len(dst)
+    rpos = cnt - 1
+
+    def read():
+        nonlocal rpos
+        p = dst[rpos]
+        rpos = rpos + 1 if rpos + 1 < cnt else 0
+        return p
+
+    start = read()
+    wpos = rpos
+    pt = read()
     i = 0
-    while len(pts) > 2 and i < len(pts):
-        start, cur, end = pts[i - 1], pts[i], pts[(i + 1) % len(pts)]
-        dx, dy = end[0] - start[0], end[1] - start[1]
-        dist = abs((cur[0] - start[0]) * dy - (cur[1] - start[1]) * dx)
-        inner = (cur[0] - start[0]) * (end[0] - cur[0]) + (cur[1] - start[1]) * (end[1] - cur[1])
-        if dist * dist <= 0.5 * eps2 * (dx * dx + dy * dy) and dx != 0 and dy != 0 and inner >= 0:
-            del pts[i]
-        else:
-            i += 1
-    return np.array(pts, dtype=np.int32).reshape(-1, 1, 2)
+    while i < cnt and new_count > 2:
+        end = read()
+        dx, dy = float(end[0] - start[0]), float(end[1] - start[1])
+        dist = abs((pt[0] - start[0]) * dy - (pt[1] - start[1]) * dx)
+        inner = (pt[0] - start[0]) * (end[0] - pt[0]) + (pt[1] - start[1]) * (end[1] - pt[1])
+        if dist * dist <= 0.5 * eps * (dx * dx + dy * dy) and dx != 0 and dy != 0 and inner >= 0:
+            new_count -= 1
+            dst[wpos] = start = end
+            wpos = wpos + 1 if wpos + 1 < cnt else 0
+            pt = read()
+            i += 2
+            continue
+        dst[wpos] = start = pt
+        wpos = wpos + 1 if wpos + 1 < cnt else 0
+        pt = end
+        i += 1
+    return np.array(dst[:new_count], dtype=np.int32).reshape(-1, 1, 2)
 
 
 # ---- perspective (cv2.getPerspectiveTransform + cv2.warpPerspective, utils.py:131-132) -----------------
@@ -298,14 +432,16 @@ def invert3(m: NDArray[np.float64]) -> NDArray[np.float64]:
 
 def warp_perspective(image: NDArray[np.uint8], m: NDArray[np.float64], size: tuple[int, int]) -> NDArray[np.uint8]:
     """cv2.warpPerspective(image, M, size) with its defaults (INTER_LINEAR, BORDER_CONSTANT 0) in OpenCV's fixed-point form
-    (``imgwarp.cpp``: WarpPerspectiveInvoker + remapBilinear).  The destination is walked in blocks of min(128, w) columns; with
+    (``imgwarp.cpp``: WarpPerspectiveInvoker + remapBilinear).  The destination is walked in blocks of min(1024 / min(16, h), w)
+    columns (BLOCK_SZ = 32: 64 x 16 blocks on a 512-px board; the 128 x 32 blocks belong to warpAffine); with
     ``blk`` the block's first column and ``x1`` the column inside it: X0 = M0*blk + M1*y + M2, W = W0 + M6*x1, W = 32 / W (0 if
     W == 0), X = round_half_even(clamp((X0 + M0*x1) * W)) -- source coordinates in 1/32 pixel (``INTER_BITS = 5``); the integer
     pixel X >> 5 saturates to int16; integer bilinear weights (32-a)(32-b)*32 ... a*b*32 that sum to 2^15
     (``INTER_REMAP_COEF_BITS``), pixel = (sum + 2^14) >> 15, i.e. round half UP; taps outside the image read 0."""
     w_out, h_out = size
     inv = invert3(m)
-    bw = min(128, w_out)
+    bh = min(16, h_out)                                     # WarpPerspectiveInvoker: BLOCK_SZ = 32, bh0 = min(BLOCK_SZ / 2, height),
+    bw = min(1024 // bh, w_out)                             # bw0 = min(BLOCK_SZ * BLOCK_SZ / bh0, width): 64 columns for the 512-px board
     cols = np.arange(w_out)
     blk = ((cols // bw) * bw).astype(np.float64)[None, :]
     x1 = (cols % bw).astype(np.float64)[None, :]

@@ -22,7 +22,7 @@ import torch
 
 _LIB_NAME = "libchessvision_hip.so"
 PREC_F32, PREC_F16, PREC_F16X3, PREC_F16R = 0, 1, 2, 3
-ABI_VERSION = 3
+ABI_VERSION = 4
 _PRECISIONS = {"f32": PREC_F32, "fp32": PREC_F32, "float32": PREC_F32, "f16": PREC_F16, "fp16": PREC_F16,
                "float16": PREC_F16, "f16x3": PREC_F16X3, "split": PREC_F16X3, "f16r": PREC_F16R}
 _PREC_NAMES = {PREC_F32: "f32", PREC_F16: "f16", PREC_F16X3: "f16x3", PREC_F16R: "f16r"}
@@ -87,6 +87,8 @@ SYMBOLS = [
     ("cv_selftest_mfma", _i, [_vp, ctypes.POINTER(_f), ctypes.POINTER(_f)]),
     ("cv_find_quadrangle", _i, [_vp, _i, _i, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(_i)]),
     ("cv_find_quadrangles", _i, [_vp, _i, _i, _i, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), _i]),
+    ("cv_find_contours", _i, [_vp, _i, _i, _i, ctypes.POINTER(ctypes.c_int32), ctypes.c_int64, ctypes.POINTER(ctypes.c_int32),
+                              ctypes.POINTER(ctypes.c_int32), ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]),
     ("cv_resize_area_u8", _i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     ("cv_extract_squares_u8", _i, [_vp, _vp, _i, _i, _i, ctypes.POINTER(ctypes.c_double), _vp, _vp, _vp]),
     ("cv_extract_squares_u8_dev", _i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
@@ -179,6 +181,29 @@ def find_quadrangle(mask: np.ndarray):
     if not found.value:
         return None
     return np.array(list(quad), dtype=np.int32).reshape(4, 1, 2)
+
+
+def find_contours(mask: np.ndarray, tc89: bool = True):
+    """``cv2.findContours(mask, RETR_CCOMP, CHAIN_APPROX_TC89_KCOS if tc89 else CHAIN_APPROX_NONE)[0]`` (reference core.py:360)
+    from the native contour stage: list of (n,1,2) int32 contours in OpenCV's order, and the list of their hole flags."""
+    lib = load_library()
+    m = np.ascontiguousarray(mask, dtype=np.uint8)
+    if m.ndim != 2:
+        raise HipBackendError("find_contours expects a 2-D uint8 mask")
+    h, w = m.shape
+    cap_pts, cap_c = 4 * h * w + 16, h * w + 16
+    xy = np.zeros((cap_pts, 2), dtype=np.int32)
+    counts = np.zeros(cap_c, dtype=np.int32)
+    holes = np.zeros(cap_c, dtype=np.int32)
+    n = ctypes.c_int64(0)
+    i32p = ctypes.POINTER(ctypes.c_int32)
+    _check(lib.cv_find_contours(m.ctypes.data_as(_vp), h, w, 1 if tc89 else 0, xy.ctypes.data_as(i32p), cap_pts,
+                                counts.ctypes.data_as(i32p), holes.ctypes.data_as(i32p), cap_c, ctypes.byref(n)))
+    out, at = [], 0
+    for k in range(n.value):
+        out.append(xy[at:at + counts[k]].reshape(-1, 1, 2).copy())
+        at += int(counts[k])
+    return out, [bool(v) for v in holes[:n.value]]
 
 
 def find_quadrangles(masks: np.ndarray, n_threads: int = 0) -> list:

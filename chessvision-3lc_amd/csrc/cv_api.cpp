@@ -16,6 +16,8 @@ namespace cv {
 void decode_positions(const float* probs, int n_boards, int flip, char* fen, char* original_fen, int8_t* labels,
                       int32_t* fixes, int32_t* n_fixes);
 bool find_quadrangle(const uint8_t* mask, int h, int w, int32_t quad[8]);
+long find_contours_flat(const uint8_t* mask, int h, int w, bool tc89, int32_t* xy, long cap_pts, int32_t* counts, int32_t* holes,
+                        long cap_contours);
 hipError_t resize_area_u8(const uint8_t* src, int n, int h, int w, int c, uint8_t* dst, int oh, int ow, hipStream_t s);
 void resize_area_table(int ssize, int dsize, std::vector<int>& ofs, std::vector<int>& si, std::vector<float>& alpha);
 hipError_t resize_area_u8_tab(const uint8_t* src, int n, int h, int w, int c, uint8_t* dst, int oh, int ow, const int* xofs,
@@ -422,6 +424,17 @@ static int impl_cv_op_upsample_bilinear2x(cv_engine_t* eng, const float* x, int 
 static int impl_cv_find_quadrangle(const uint8_t* mask, int h, int w, int32_t quad[8], int* found) {
     if (!mask || !quad || !found || h <= 0 || w <= 0) return finish(fail(CV_ERR_INVALID, "cv_find_quadrangle: bad argument"));
     *found = find_quadrangle(mask, h, w, quad) ? 1 : 0;
+    return CV_OK;
+}
+
+static int impl_cv_find_contours(const uint8_t* mask, int h, int w, int method, int32_t* xy, int64_t cap_points, int32_t* counts,
+                                 int32_t* holes, int64_t cap_contours, int64_t* n_contours) {
+    if (!mask || !xy || !counts || !holes || !n_contours || h <= 0 || w <= 0 || cap_points < 0 || cap_contours < 0 ||
+        (method != 0 && method != 1))
+        return finish(fail(CV_ERR_INVALID, "cv_find_contours: bad argument"));
+    const long n = find_contours_flat(mask, h, w, method == 1, xy, (long)cap_points, counts, holes, (long)cap_contours);
+    if (n < 0) return finish(fail(CV_ERR_INVALID, "cv_find_contours: output capacity too small"));
+    *n_contours = n;
     return CV_OK;
 }
 
@@ -880,6 +893,13 @@ int cv_op_upsample_bilinear2x(cv_engine_t* eng, const float* x, int n, int c, in
 
 int cv_find_quadrangle(const uint8_t* mask, int h, int w, int32_t quad[8], int* found) {
     return guarded("cv_find_quadrangle", [&]() -> int { return impl_cv_find_quadrangle(mask, h, w, quad, found); });
+}
+
+int cv_find_contours(const uint8_t* mask, int h, int w, int method, int32_t* xy, int64_t cap_points, int32_t* counts,
+                     int32_t* holes, int64_t cap_contours, int64_t* n_contours) {
+    return guarded("cv_find_contours", [&]() -> int {
+        return impl_cv_find_contours(mask, h, w, method, xy, cap_points, counts, holes, cap_contours, n_contours);
+    });
 }
 
 int cv_find_quadrangles(const uint8_t* masks, int n, int h, int w, int32_t* quads, int32_t* found, int n_threads) {

@@ -100,8 +100,9 @@ __global__ __launch_bounds__(256) void resize_area_tab_kernel(const uint8_t* __r
     }
 }
 
+// inv_x / inv_y: (scale, inv_scale) of each axis as the HOST computed them (inv_scale = dsize / ssize, scale = 1 / inv_scale)
 __global__ void resize_area_u8_kernel(const uint8_t* __restrict__ src, int n, int h, int w, int c,
-                                      uint8_t* __restrict__ dst, int oh, int ow) {
+                                      uint8_t* __restrict__ dst, int oh, int ow, double2 inv_x, double2 inv_y) {
 #pragma clang fp contract(off)                          // keep mul/add unfused: matches the numpy checker bit for bit
     const size_t total = (size_t)n * oh * ow * c;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -121,7 +122,7 @@ __global__ void resize_area_u8_kernel(const uint8_t* __restrict__ src, int n, in
         return;
     }
     // (a fractional SHRINK never reaches this kernel: resize_area_tab_kernel reproduces OpenCV's float32 table form; the branch below
-    // stays for callers without tables)  enlarging: bilinear
+    // stays for callers without tables)
     const double sy = (double)h / oh, sx = (double)w / ow;
     double acc = 0.0;
     if (oh <= h && ow <= w) {
@@ -138,13 +139,25 @@ __global__ void resize_area_u8_kernel(const uint8_t* __restrict__ src, int n, in
             acc += wy * row;
         }
     } else {
-        const double fy = (oy + 0.5) * sy - 0.5, fx = (ox + 0.5) * sx - 0.5;
-        const int iy = (int)floor(fy), ix = (int)floor(fx);
-        const double ty = fy - iy, tx = fx - ix;
-        const int ya = min(max(iy, 0), h - 1), yb = min(max(iy + 1, 0), h - 1);
-        const int xa = min(max(ix, 0), w - 1), xb = min(max(ix + 1, 0), w - 1);
-        acc = (1 - ty) * ((1 - tx) * s[((size_t)ya * w + xa) * c + ch] + tx * s[((size_t)ya * w + xb) * c + ch]) +
-              ty * ((1 - tx) * s[((size_t)yb * w + xa) * c + ch] + tx * s[((size_t)yb * w + xb) * c + ch]);
+        // Enlarging in either direction: OpenCV has no area algorithm there and runs its 8-bit bilinear resizer with the AREA
+        // coefficient rule (resize.cpp): s = floor(d * scale), f = (float)((d + 1) - (s + 1) * inv_scale) reduced to [0, 1), both
+        // clamped at the last source pixel, 11-bit coefficients round((1 - f) * 2048), round(f * 2048); horizontal pass in int32,
+        // vertical pass (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2 (VResizeLinear<uchar>).  Integers: exact.
+        auto axis = [](int d, double scale, double inv_scale, int ssize, int& s0, int& s1, int& c0, int& c1) {
+            int sx = (int)floor(d * scale);
+            float f = (float)((double)(d + 1) - (double)(sx + 1) * inv_scale);
+            f = f <= 0.f ? 0.f : f - floorf(f);
+            if (sx >= ssize - 1) { f = 0.f; sx = ssize - 1; }
+            s0 = sx; s1 = sx + 1 < ssize ? sx + 1 : ssize - 1;
+            c0 = (int)rintf((1.f - f) * 2048.f); c1 = (int)rintf(f * 2048.f);
+        };
+        int x0, x1, a0, a1, y0, y1, b0, b1;
+        axis(ox, inv_x.x, inv_x.y, w, x0, x1, a0, a1);
+        axis(oy, inv_y.x, inv_y.y, h, y0, y1, b0, b1);
+        const int r0 = (int)s[((size_t)y0 * w + x0) * c + ch] * a0 + (int)s[((size_t)y0 * w + x1) * c + ch] * a1;
+        const int r1 = (int)s[((size_t)y1 * w + x0) * c + ch] * a0 + (int)s[((size_t)y1 * w + x1) * c + ch] * a1;
+        dst[idx] = (uint8_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2);
+        return;
     }
     const double v = rint(acc);
     dst[idx] = (uint8_t)(v < 0.0 ? 0.0 : v > 255.0 ? 255.0 : v);
@@ -168,10 +181,12 @@ __global__ __launch_bounds__(256) void extract_squares_u8_kernel(const uint8_t* 
     const double* m = inv + (size_t)img * 9;
     const double m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3], m4 = m[4], m5 = m[5], m6 = m[6], m7 = m[7], m8 = m[8];
     // cv2.flip(board, 1) undone: flipped pixel bx is warp-space column xs = 511 - bx.  The lane's four columns xs = xs3 .. xs3+3
-    // (xs3 = 508 - bx0, a multiple of 4) lie in ONE 128-column block of OpenCV's walk, whose start column enters the arithmetic:
+    // (xs3 = 508 - bx0, a multiple of 4) lie in ONE 64-column block of OpenCV's walk (WarpPerspectiveInvoker: BLOCK_SZ = 32, bh0 =
+    // min(16, h), bw0 = min(32 * 32 / bh0, w) = 64 for the 512 x 512 board; the 128 x 32 blocks are warpAffine's), whose start column
+    // enters the arithmetic:
     //   X0 = M0*blk + M1*y + M2;  W = W0 + M6*x1;  W = W ? 32/W : 0;  X = round((X0 + M0*x1) * W)   (x1 = column inside the block)
     const int xs3 = B - 4 - bx0;
-    const double blk = (double)(xs3 & ~127), ys = (double)by;
+    const double blk = (double)(xs3 & ~63), ys = (double)by;
     const double X0 = (m0 * blk + m1 * ys) + m2;
     const double Y0 = (m3 * blk + m4 * ys) + m5;
     const double W0 = (m6 * blk + m7 * ys) + m8;
@@ -180,7 +195,7 @@ __global__ __launch_bounds__(256) void extract_squares_u8_kernel(const uint8_t* 
     uint32_t packed = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {                                       // flipped pixel bx0 + j  <->  column xs3 + 3 - j
-        const double x1 = (double)((xs3 & 127) + 3 - j);
+        const double x1 = (double)((xs3 & 63) + 3 - j);
         double W = W0 + m6 * x1;
         W = W != 0.0 ? 32.0 / W : 0.0;
         const double fxs = (X0 + m0 * x1) * W;
@@ -272,7 +287,9 @@ hipError_t resize_area_u8(const uint8_t* src, int n, int h, int w, int c, uint8_
         return hipGetLastError();
     }
     const size_t total = (size_t)n * oh * ow * c;
-    hipLaunchKernelGGL(resize_area_u8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, n, h, w, c, dst, oh, ow);
+    const double isx = (double)ow / (double)w, isy = (double)oh / (double)h;
+    hipLaunchKernelGGL(resize_area_u8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, n, h, w, c, dst, oh, ow,
+                       double2{1.0 / isx, isx}, double2{1.0 / isy, isy});
     return hipGetLastError();
 }
 hipError_t extract_squares_u8(const uint8_t* images, int n, int h, int w, const double* inv, uint8_t* squares,

@@ -41,8 +41,9 @@
 extern "C" {
 #endif
 
-#define CV_ABI_VERSION 3      /* 2: CV_PREC_F16R, CV_ERR_NUMERIC + cv_engine_numeric_status, cv_engine_set_chunk before cv_load_* only
-                                 3: cv_board_homographies, cv_engine_export/import_calibration, cv_process_image (additions only) */
+#define CV_ABI_VERSION 4      /* 2: CV_PREC_F16R, CV_ERR_NUMERIC + cv_engine_numeric_status, cv_engine_set_chunk before cv_load_* only
+                                 3: cv_board_homographies, cv_engine_export/import_calibration, cv_process_image (additions only)
+                                 4: cv_find_contours (addition); cv_find_quadrangle follows CHAIN_APPROX_TC89_KCOS */
 
 enum cv_status {
     CV_OK = 0,
@@ -199,15 +200,21 @@ int cv_op_upsample_bilinear2x(cv_engine_t* eng, const float* x, int n, int c, in
                               void* stream);
 
 /* ---- classical stages either side of the CNNs (SURVEY.md section 8f "next" rows) ------------------------------ */
-/* Binary mask (h*w uint8, 0 / non-0) -> board quadrangle, host-side C++: contours (outer + holes), the reference's
- * area / bounding-box filter when more than one contour, closed-curve Douglas-Peucker at 10 % of the perimeter, first
- * 4-vertex result, reference vertex rotation.  Replaces ChessVision._find_quadrangle (core.py:357-411: cv2.findContours,
- * contourArea, boundingRect, arcLength, approxPolyDP).  quad = 4 x (x, y) in mask pixels; *found = 0 when none.
- * Needs no GPU and no engine. */
+/* Binary mask (h*w uint8, 0 / non-0) -> board quadrangle, host-side C++: contours (outer + holes, RETR_CCOMP order) compressed
+ * by CHAIN_APPROX_TC89_KCOS, the reference's area / bounding-box filter when more than one contour, closed-curve
+ * Douglas-Peucker at 10 % of the (float-segment) perimeter, first 4-vertex result, reference vertex rotation.  Replaces
+ * ChessVision._find_quadrangle (core.py:357-411: cv2.findContours, contourArea, boundingRect, arcLength, approxPolyDP), each in
+ * OpenCV's own arithmetic and order.  quad = 4 x (x, y) in mask pixels; *found = 0 when none.  Needs no GPU and no engine. */
 int cv_find_quadrangle(const uint8_t* mask, int h, int w, int32_t quad[8], int* found);
 /* The same for n masks (n,h,w) on n_threads host threads (0 = hardware concurrency, capped at 32);
  * quads: n x 8 int32, found: n x int32. */
 int cv_find_quadrangles(const uint8_t* masks, int n, int h, int w, int32_t* quads, int32_t* found, int n_threads);
+/* The contours themselves, as cv2.findContours(mask, RETR_CCOMP, method)[0] lists them (core.py:360): method 0 =
+ * CHAIN_APPROX_NONE, 1 = CHAIN_APPROX_TC89_KCOS.  Points of all contours back to back in xy (x, y pairs, room for cap_points
+ * points), per contour its point count and a hole flag (room for cap_contours each); *n_contours receives the count.
+ * CV_ERR_INVALID when a capacity is too small (h*w contours of 4*h*w points in total always suffice). */
+int cv_find_contours(const uint8_t* mask, int h, int w, int method, int32_t* xy, int64_t cap_points, int32_t* counts,
+                     int32_t* holes, int64_t cap_contours, int64_t* n_contours);
 
 /* (n,h,w,channels) uint8 -> (n,out_h,out_w,channels) uint8, INTER_AREA semantics (cv2.resize at core.py:212): exact
  * box mean with round-half-up for integer shrink factors, coverage-weighted mean otherwise.  DEVICE pointers. */

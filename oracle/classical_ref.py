@@ -7,7 +7,9 @@ Deliberately the slow, literal form (loops and float64) -- small inputs only.
 
     stage                               reference call site                         here
     cv2.resize(INTER_AREA), 512 -> 256  chessvision/core.py:212                     resize_area_int (integer factors),
-                                                                                    resize_area (any shrink: OpenCV's float32 table form)
+                                                                                    resize_area (any shrink: OpenCV's float32 table form),
+                                                                                    resize_area_enlarge (a photo below 256 px: the
+                                                                                    fixed-point bilinear path with AREA coefficients)
     sigmoid > threshold -> 0 / 255      core.py:273, utils.py:101-112               binary_mask
     cv2.cvtColor(BGR2GRAY)              core.py:299                                 bgr_to_gray
     cv2.flip(board, 1)                  core.py:300                                 flip_lr
@@ -17,9 +19,8 @@ Deliberately the slow, literal form (loops and float64) -- small inputs only.
 
     getPerspectiveTransform + warpPerspective   utils.py:115-132                    perspective_matrix, warp_perspective
 
-NOT restated independently (the end-to-end oracle takes it from the product's numpy host path and says so): the contour chain
-(findContours / contourArea / boundingRect / arcLength / approxPolyDP -- pinned instead on the reference's own 631 label masks,
-tests/test_contour_cpp.py).
+The contour chain (findContours / contourArea / boundingRect / arcLength / approxPolyDP, core.py:357-411) is restated in plain C:
+``oracle/c_ref/contours_ref.c`` (binding ``oracle/contours_c.py``), also independent of the product.
 """
 from __future__ import annotations
 
@@ -98,6 +99,49 @@ def resize_area(image: np.ndarray, out_hw: tuple[int, int]) -> np.ndarray:
                 buf[dx] = acc
             total = (beta * buf).astype(np.float32) if total is None else (total + (beta * buf).astype(np.float32)).astype(np.float32)
         out[dy] = np.clip(np.rint(total), 0, 255).astype(np.uint8)
+    return out
+
+
+def _linear_area_axis(ssize: int, dsize: int):
+    """The per-axis table cv2.resize builds for its bilinear path in AREA mode (imgproc/src/resize.cpp, the loop over dx / dy with
+    ``area_mode = interpolation == INTER_AREA``), restated literally: sx = cvFloor(dx * scale); fx = (float)((dx + 1) - (sx + 1) *
+    inv_scale); fx = fx <= 0 ? 0 : fx - cvFloor(fx); if sx >= ssize - 1: fx = 0, sx = ssize - 1; coefficients
+    saturate_cast<short>((1 - fx) * 2048) and saturate_cast<short>(fx * 2048) (float products, round half to even)."""
+    inv_scale = float(dsize) / float(ssize)
+    scale = 1.0 / inv_scale
+    tab = []
+    for d in range(dsize):
+        sx = int(np.floor(d * scale))
+        fx = np.float32((d + 1) - (sx + 1) * inv_scale)
+        fx = np.float32(0.0) if fx <= 0 else np.float32(fx - np.floor(fx))
+        if sx >= ssize - 1:
+            fx, sx = np.float32(0.0), ssize - 1
+        c0 = int(np.rint(np.float32(np.float32(1.0) - fx) * np.float32(2048.0)))
+        c1 = int(np.rint(fx * np.float32(2048.0)))
+        tab.append((sx, min(max(c0, -32768), 32767), min(max(c1, -32768), 32767)))
+    return tab
+
+
+def resize_area_enlarge(image: np.ndarray, out_hw: tuple[int, int]) -> np.ndarray:
+    """cv2.resize(image, (w, h), interpolation=INTER_AREA) when at least one direction ENLARGES (core.py:212 on a photo smaller than
+    256 pixels).  OpenCV has no area algorithm for that case and runs its 8-bit bilinear resizer with the AREA coefficient rule
+    (``_linear_area_axis``): ``HResizeLinear`` -- D[dx] = S[sx] * a0 + S[sx + 1] * a1 in int, the right neighbour not read where a1
+    is forced to 0 -- over the two source rows sy, sy + 1 (clipped to the image), then ``VResizeLinear<uchar>``:
+    dst = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2.  Pure integer arithmetic, one pixel at a time."""
+    h, w, c = image.shape
+    oh, ow = out_hw
+    xtab, ytab = _linear_area_axis(w, ow), _linear_area_axis(h, oh)
+    out = np.zeros((oh, ow, c), np.uint8)
+    for dy in range(oh):
+        sy, b0, b1 = ytab[dy]
+        r0, r1 = image[min(sy, h - 1)], image[min(sy + 1, h - 1)]
+        for dx in range(ow):
+            sx, a0, a1 = xtab[dx]
+            sx1 = sx + 1 if sx + 1 < w else sx
+            for ch in range(c):
+                d0 = int(r0[sx, ch]) * a0 + int(r0[sx1, ch]) * a1
+                d1 = int(r1[sx, ch]) * a0 + int(r1[sx1, ch]) * a1
+                out[dy, dx, ch] = (((b0 * (d0 >> 4)) >> 16) + ((b1 * (d1 >> 4)) >> 16) + 2) >> 2
     return out
 
 
@@ -236,7 +280,8 @@ def _invert3(m: np.ndarray) -> np.ndarray:
 
 def warp_perspective(image: np.ndarray, m: np.ndarray, size: tuple[int, int]) -> np.ndarray:
     """cv2.warpPerspective(image, M, (w, h)) with its defaults (INTER_LINEAR, BORDER_CONSTANT 0), in OpenCV's fixed-point form
-    (imgwarp.cpp: WarpPerspectiveInvoker + remapBilinear).  The destination is walked in blocks of min(128, w) x min(32, h) pixels;
+    (imgwarp.cpp: WarpPerspectiveInvoker + remapBilinear).  The destination is walked in blocks of bw0 x bh0 pixels, bh0 = min(16, h), bw0 = min(1024 / bh0, w)
+    (WarpPerspectiveInvoker's BLOCK_SZ is 32 -- 64 x 16 blocks on the 512-px board; BLOCK_SZ = 64 / 128 x 32 blocks are warpAffine's);
     for the block starting at column ``bx`` and the row ``y``: X0 = M0*bx + M1*y + M2 (likewise Y0, W0), and for the pixel ``x1``
     columns into the block W = W0 + M6*x1, W = 32 / W (0 when W is 0), X = round_half_even(clamp((X0 + M0*x1) * W, INT_MIN, INT_MAX))
     -- source coordinates in 1/32 pixel (``INTER_BITS = 5``).  The association (block start first, then the in-block column) is
@@ -247,7 +292,8 @@ def warp_perspective(image: np.ndarray, m: np.ndarray, size: tuple[int, int]) ->
     inv = _invert3(np.asarray(m, np.float64))
     img = image if image.ndim == 3 else image[:, :, None]
     h, w, ch = img.shape
-    bw = min(128, w_out)
+    block_rows = min(32 // 2, h_out)                         # const int BLOCK_SZ = 32; bh0 = min(BLOCK_SZ/2, height)
+    bw = min((32 * 32) // block_rows, w_out)                 # bw0 = min(BLOCK_SZ*BLOCK_SZ/bh0, width)
     cols = np.arange(w_out)
     bx = ((cols // bw) * bw).astype(np.float64)[None, :]              # block start column of every destination column
     x1 = (cols % bw).astype(np.float64)[None, :]

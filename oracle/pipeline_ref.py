@@ -6,17 +6,15 @@ TEST INFRASTRUCTURE (see ``oracle/__init__.py``).  The reference pipeline (``che
 and keeps the two models behind opaque callables (``core.py:53-54``).  Here it is written out stage by stage:
 
 * the two CNNs are ``oracle.unet_ref.UNet`` / ``oracle.resnet_ref.ResNet18`` on torch CPU fp32;
-* resize (integer factors), sigmoid / threshold, the perspective matrix and warp (OpenCV's arithmetic in OpenCV's order of
+* resize (integer factors, fractional shrinks, enlarging), sigmoid / threshold, the perspective matrix and warp (OpenCV's arithmetic in OpenCV's order of
   operations: LU solve, cofactor inverse, block-wise 1/32-pixel coordinates, integer weights, round half up -- the product's
   device warp must equal it byte for byte), gray, flip, the 64-way split, soft-max, arg-max, FEN and the pawn rule are the
   INDEPENDENT restatements of ``oracle/classical_ref.py`` -- they share no code with the product's host path
   (``chessvision/classical.py``, ``fen.py``, ``ChessVision`` statics) nor with its device / C++ path;
-* ONE stage is not independent and is taken from the product's numpy host path: the mask -> quadrangle chain
-  (``ChessVision._find_quadrangle`` = Suzuki border following, area / box filter, Douglas-Peucker; pinned on the reference's
-  own 631 label masks against ``coordinates.json``, tests/test_contour_cpp.py).  For it the end-to-end test compares two
-  implementations (C++ versus numpy) of ONE reading of OpenCV; a shared misreading there is caught only by the 631-mask
-  fixture, not here.  (Photos smaller than 256 pixels, which INTER_AREA enlarges through OpenCV's bilinear path, also use the
-  product's approximation of it.)
+* the mask -> quadrangle chain (findContours RETR_CCOMP + CHAIN_APPROX_TC89_KCOS, contourArea / boundingRect filter, arcLength,
+  approxPolyDP, rotation; ``core.py:357-411``) is ``oracle/c_ref/contours_ref.c`` through ``oracle/contours_c.py``: a literal
+  raster-scan restatement of the published algorithms in plain C that shares nothing with the product's run-based C++ or its
+  scipy-label numpy form (round 5; until round 4 this stage was borrowed from the product).
 
 ``fallback_quad`` mirrors the option of ``process_images``: boards whose mask yields no quadrangle are classified through
 the whole-image quadrangle (TR, TL, BL, BR of the 256x256 mask) so that random-init weights still exercise the classifier.
@@ -29,6 +27,7 @@ import numpy as np
 import torch
 
 from . import classical_ref as cref
+from . import contours_c
 
 
 def process_image(unet, resnet, image: np.ndarray, threshold: float = 0.5, flip: bool = False, fallback_quad: bool = False):
@@ -37,9 +36,7 @@ def process_image(unet, resnet, image: np.ndarray, threshold: float = 0.5, flip:
     if h >= 256 and w >= 256:
         small = cref.resize_area(image, (256, 256))                            # integer and fractional shrinks, independent of the product
     else:
-        from chessvision import classical                                      # enlarging: the product's bilinear approximation
-
-        small = classical.resize_area(image, (256, 256))
+        small = cref.resize_area_enlarge(image, (256, 256))                    # a photo below 256 px: OpenCV's fixed-point bilinear path
     x = torch.from_numpy(small.astype(np.float32) / np.float32(255.0)).permute(2, 0, 1)[None]   # core.py:215-216
     with torch.no_grad():
         logits = unet(x)[0, 0].numpy().astype(np.float32)
@@ -52,12 +49,11 @@ def process_from_mask(resnet, image: np.ndarray, mask: np.ndarray, logits: np.nd
     """The chain downstream of the binary mask (reference core.py:277-307 + classify_position).  Also called by the end-to-end
     tests with the PRODUCT's mask when a pixel whose logit sits within the logit tolerance of the threshold flipped, so that
     quadrangle, warp, classifier and FEN of that board are still compared instead of skipped."""
-    from chessvision import ChessVision                                        # the shared contour stage + result records only
-    from chessvision.cv_types import BoardExtractionResult, ChessVisionResult
+    from chessvision.cv_types import BoardExtractionResult, ChessVisionResult     # result records only
 
     t0 = time.time() if t0 is None else t0
     h = image.shape[0]
-    quad = ChessVision._find_quadrangle(mask)                                  # shared (see the module docstring)
+    quad = contours_c.find_quadrangle(mask)                                    # independent plain-C restatement
     if quad is None and fallback_quad:
         quad = np.array([[[255, 0]], [[0, 0]], [[0, 255]], [[255, 255]]], dtype=np.int32)
     if quad is None:

@@ -1,0 +1,168 @@
+"""CPU: the mask -> quadrangle chain of the reference (chessvision/core.py:357-411) -- findContours(RETR_CCOMP,
+CHAIN_APPROX_TC89_KCOS), contourArea / boundingRect filter, arcLength, approxPolyDP, rotation -- in three implementations that share
+no code: the product's C++ (csrc/contour.cpp: run-based components, borders traced from component starts), the product's numpy
+host form (chessvision/classical.py: scipy labels) and the independent oracle (oracle/c_ref/contours_ref.c: the published
+raster-scan relabelling, literal).  Integer output: the bar is bit-exact."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+from chessvision import classical
+from chessvision.core import ChessVision
+from oracle import contours_c as oc
+
+from ragged import label_masks, ragged_set
+
+
+@pytest.fixture(scope="module")
+def hb():
+    import __graft_entry__ as ge
+
+    ge.build()
+    from chessvision import hip_backend
+
+    return hip_backend
+
+
+def _same_lists(a, b):
+    return len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def _same_quad(a, b):
+    if a is None or b is None:
+        return a is None and b is None
+    return np.array_equal(np.asarray(a).reshape(4, 2), np.asarray(b).reshape(4, 2))
+
+
+def test_tc89_known_answers():
+    """What cv2.findContours(.., CHAIN_APPROX_TC89_KCOS) is known to return: a filled axis-parallel rectangle comes back as its four
+    corners, top-left first, then DOWN the left side (OpenCV traces outer borders counter-clockwise on screen); an isolated pixel
+    as itself; the border of a hole runs on the surrounding foreground pixels."""
+    m = np.zeros((20, 20), np.uint8)
+    m[3:10, 4:12] = 255
+    c, holes = oc.find_contours(m, oc.TC89_KCOS)
+    assert holes == [False] and c[0].reshape(-1, 2).tolist() == [[4, 3], [4, 9], [11, 9], [11, 3]]
+    full, _ = oc.find_contours(m, oc.NONE)
+    assert len(full[0]) == 2 * (7 + 8) - 4 and full[0].reshape(-1, 2)[:3].tolist() == [[4, 3], [4, 4], [4, 5]]
+    one = np.zeros((9, 9), np.uint8)
+    one[4, 5] = 1
+    c, _ = oc.find_contours(one, oc.TC89_KCOS)
+    assert [x.reshape(-1, 2).tolist() for x in c] == [[[5, 4]]]
+    m[5:8, 6:9] = 0                                            # a 3 x 3 hole: its border = the 12 foreground pixels 4-adjacent to it
+    c, holes = oc.find_contours(m, oc.NONE)
+    assert holes == [False, True] and len(c[1]) == 12 and c[1].reshape(-1, 2)[0].tolist() == [5, 5]
+    ring = {(x, y) for x, y in c[1].reshape(-1, 2).tolist()}
+    assert ring == {(6, 4), (7, 4), (8, 4), (9, 5), (9, 6), (9, 7), (8, 8), (7, 8), (6, 8), (5, 7), (5, 6), (5, 5)}
+
+
+def test_ccomp_order_is_newest_outer_first_each_followed_by_its_holes(hb):
+    m = np.zeros((60, 60), np.uint8)
+    m[2:20, 2:30] = 255                                        # component A (found first) with two holes
+    m[5:8, 5:8] = 0
+    m[5:8, 15:18] = 0
+    m[30:55, 10:50] = 255                                      # component B (found second) with one hole that holds an island
+    m[35:50, 15:45] = 0
+    m[40:44, 25:30] = 255                                      # island C (found last): a top-level contour under RETR_CCOMP
+    for finder in (lambda x: oc.find_contours(x, oc.NONE), lambda x: hb.find_contours(x, False),
+                   lambda x: classical.find_contours(x, False, True)):
+        c, holes = finder(m)
+        firsts = [tuple(x.reshape(-1, 2)[0].tolist()) for x in c]
+        assert holes == [False, False, True, False, True, True]
+        assert firsts == [(25, 40), (10, 30), (14, 35), (2, 2), (14, 5), (4, 5)]     # C, B, B's hole, A, A's second hole, A's first
+
+
+def test_arc_length_takes_float_segments_and_starts_with_the_closing_one():
+    c = np.array([[0, 0], [1, 2], [4, 3], [2, 7]], np.int32)
+    segs = [np.float32(np.sqrt(np.float32(dx * dx + dy * dy))) for dx, dy in ((2, 7), (1, 2), (3, 1), (2, 4))]
+    want = 0.0
+    for s in segs:
+        want += float(s)
+    assert oc.arc_length(c) == classical.arc_length(c) == want
+    assert want != float(np.sqrt([53.0, 5.0, 10.0, 20.0]).sum())              # the double-precision perimeter differs in the last bits
+
+
+def test_product_equals_the_independent_oracle_on_ragged_masks(hb):
+    """>= 1000 masks with real-UNet-like damage: every contour list (CHAIN_APPROX_NONE and TC89_KCOS, OpenCV's order, hole flags) and
+    every quadrangle of the C++ product equals the oracle's."""
+    found = compared = 0
+    for mask, i, kind in ragged_set(1040):
+        for method in (oc.NONE, oc.TC89_KCOS):
+            a, ha = oc.find_contours(mask, method)
+            b, hb_ = hb.find_contours(mask, bool(method))
+            assert ha == hb_ and _same_lists(a, b), (i, kind, method, len(a), len(b))
+        qa, qb = oc.find_quadrangle(mask), hb.find_quadrangle(mask)
+        assert _same_quad(qa, qb), (i, kind, qa, qb)
+        compared += 1
+        found += qa is not None
+    assert compared == 1040 and found >= 700, (compared, found)
+
+
+def test_numpy_host_form_equals_the_oracle(hb):
+    n = 0
+    for mask, i, kind in ragged_set(48, seed=7):
+        for method in (oc.NONE, oc.TC89_KCOS):
+            a, ha = oc.find_contours(mask, method)
+            b, hb_ = classical.find_contours(mask, bool(method), True)
+            assert ha == hb_ and _same_lists(a, b), (i, kind, method)
+        for c in a[:2]:
+            assert oc.arc_length(c) == classical.arc_length(c) and oc.contour_area(c) == classical.contour_area(c)
+            for eps in (0.7, 3.0, 0.02 * oc.arc_length(c), 0.1 * oc.arc_length(c)):
+                assert np.array_equal(oc.approx_poly_dp(c, eps), classical.approx_poly_dp(c, eps)), (i, kind, eps)
+        assert _same_quad(oc.find_quadrangle(mask), ChessVision._find_quadrangle(mask)), (i, kind)
+        n += 1
+    assert n == 48
+
+
+def test_label_masks_all_three_agree_and_hit_the_annotations(hb):
+    masks = label_masks()
+    quads = hb.find_quadrangles(masks)
+    for i in range(len(masks)):
+        assert _same_quad(quads[i], oc.find_quadrangle(masks[i])), i
+    for i in range(0, len(masks), 25):
+        assert _same_quad(quads[i], ChessVision._find_quadrangle(masks[i])), i
+
+
+def test_compression_changes_epsilon_but_not_the_label_mask_quadrangles(hb):
+    """What CHAIN_APPROX_TC89_KCOS changes downstream (rounds 1-4 kept every border pixel): the perimeter arcLength sees is shorter
+    -- so is epsilon = 0.1 * perimeter -- and approxPolyDP can only pick dominant points.  On the reference's clean label masks the
+    quadrangle is the same either way; on ragged masks it is not always: the count is reported."""
+    masks = label_masks()
+    ratio = []
+    for i in range(0, len(masks), 7):
+        full, _ = oc.find_contours(masks[i], oc.NONE)
+        tc, _ = oc.find_contours(masks[i], oc.TC89_KCOS)
+        ratio.append(oc.arc_length(full[0]) / oc.arc_length(tc[0]))
+        assert len(tc[0]) < len(full[0]) / 4
+    assert 1.0 <= min(ratio) and max(ratio) < 1.09, (min(ratio), max(ratio))
+    differ = total = 0
+    for mask, i, kind in ragged_set(400, seed=11):
+        full, _ = oc.find_contours(mask, oc.NONE)
+        big = max(full, key=len)
+        q_none = oc.approx_poly_dp(big, 0.1 * oc.arc_length(big))
+        q_tc = oc.find_quadrangle(mask)
+        if q_tc is None or len(q_none) != 4:
+            differ += (q_tc is None) != (len(q_none) != 4)
+        else:
+            differ += not np.array_equal(np.sort(q_none.reshape(4, 2), axis=0), np.sort(q_tc.reshape(4, 2), axis=0))
+        total += 1
+    print(f"quadrangle differs between CHAIN_APPROX_NONE and TC89_KCOS on {differ} of {total} ragged masks")
+    assert total == 400
+
+
+def test_enlarging_inter_area_host_equals_oracle():
+    """INTER_AREA on a photo smaller than the 256-px target (core.py:212): OpenCV's fixed-point bilinear path with the AREA coefficient
+    rule; the product's host form and the independent oracle agree byte for byte (the device form: tests/test_gpu_pipeline.py)."""
+    from oracle import classical_ref as cref
+
+    rng = np.random.default_rng(3)
+    sizes = [(100, 80), (200, 300), (255, 255), (300, 200), (17, 33), (256, 100)] + \
+            [tuple(int(v) for v in rng.integers(20, 256, 2)) for _ in range(4)]
+    for h, w in sizes:
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        assert np.array_equal(classical.resize_area(img, (256, 256)), cref.resize_area_enlarge(img, (256, 256))), (h, w)
+    flat = np.full((90, 70, 3), 201, np.uint8)
+    assert np.unique(classical.resize_area(flat, (256, 256))).tolist() == [201]
+    ramp = np.repeat(np.arange(128, dtype=np.uint8)[None, :, None], 128, axis=0).repeat(3, axis=2)
+    up = classical.resize_area(ramp, (256, 256))
+    assert np.all(np.diff(up[0, :, 0].astype(int)) >= 0) and up[0, 0, 0] == 0 and up[0, -1, 0] == 127

@@ -109,6 +109,24 @@ def test_device_resize_matches_host_restatement(engines):
         assert np.array_equal(got, np.stack([classical.resize_area(im, (256, 256)) for im in odd])), (h, w)
 
 
+def test_device_resize_enlarging_matches_host_and_oracle(engines):
+    """INTER_AREA on photos smaller than 256 px (reference core.py:212): OpenCV's fixed-point bilinear path with the AREA coefficient
+    rule.  device == host == independent oracle, byte for byte, on 8 random sizes below 256 px, mixed enlarge / shrink geometries and
+    the whole path through ``process_images``."""
+    import torch
+
+    from chessvision import classical
+    from oracle import classical_ref as cref
+
+    rng = np.random.default_rng(15)
+    sizes = [tuple(int(v) for v in rng.integers(24, 256, 2)) for _ in range(8)] + [(100, 400), (400, 100), (256, 128), (255, 257)]
+    for h, w in sizes:
+        img = rng.integers(0, 256, (2, h, w, 3), dtype=np.uint8)
+        got = engines["f32"].resize_area_u8(torch.from_numpy(img), (256, 256)).cpu().numpy()
+        assert np.array_equal(got, np.stack([classical.resize_area(im, (256, 256)) for im in img])), (h, w)      # device == host
+        assert np.array_equal(got[0], cref.resize_area_enlarge(img[0], (256, 256))), (h, w)                       # == oracle
+
+
 def test_device_warp_gray_flip_split_matches_host_chain(engines):
     import torch
 
