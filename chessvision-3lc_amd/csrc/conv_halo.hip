@@ -44,9 +44,16 @@ namespace cv {
 #define CV_HALO_TH8_SINGLE 0      // experiment (with -DCV_HALO_TH64=8): 8 x 16 patch with ONE halo buffer = 47 KB -> THREE workgroups per CU
 #endif
 constexpr int halo_waves_per_eu(int ct, int th, bool dbh) { return (CV_HALO_TH8_SINGLE && ct == 64 && th == 8 && !dbh) ? 3 : 2; }
-template <typename T, int CT, int TH, int WGC, int NW, int TPS, int NSW, int IMG, bool PERSIST, bool DBH = true, bool FUSE0 = false>
+// CHAIN (single halo buffer, f16, 64 -> 64 channels, 16 x 16 maps = one patch per image): the "channel blocks" of the K loop are
+// FOUR CONVOLUTIONS in a row (ResNet-18 layer1 = two BasicBlocks).  At every block boundary the epilogue of convolution c -- BN,
+// (+ f32 residual), ReLU -- rounds to f16 and writes the result over the halo buffer IN PLACE (every wave has drained its reads of
+// it by then; the zero border stays), which is then the resident input of convolution c + 1; the weight stream simply continues.
+// The three intermediate tensors never travel to HBM as f16; the f32 trunk twin does (written after convolution 1, read back by
+// the same lanes after convolution 3): round 5, profiles/r05_tuning.md.
+template <typename T, int CT, int TH, int WGC, int NW, int TPS, int NSW, int IMG, bool PERSIST, bool DBH = true, bool FUSE0 = false, bool CHAIN = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(halo_waves_per_eu(CT, TH, DBH), halo_waves_per_eu(CT, TH, DBH)))) void conv3x3_halo_kernel(const ConvParams p) {
     static_assert(!FUSE0 || (!DBH && !PERSIST && IMG == 0 && CT == 64 && NW == 4 && __is_same(T, split_t)), "fused producer: split-f16 64-channel single-halo tile");
+    static_assert(!CHAIN || (!DBH && !PERSIST && !FUSE0 && IMG == 0 && CT == 64 && TH == 16 && NW == 4 && __is_same(T, half_t)), "chained convolutions: f16 64-channel single-halo tile over whole 16 x 16 images");
     static_assert(TPS == 1 && (NSW == 3 || NSW == 4), "stage shape");
     constexpr int SPC = 9 / TPS;                        // stages per channel block
     constexpr int WGP = NW / WGC;                       // wave groups along the patch rows
@@ -420,6 +427,75 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(halo_wa
     const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
 
+    // ---- CHAIN: epilogue of convolution c, straight from the accumulator layout -------------------------------------
+    // lane (q, l15) holds channels 16 q .. 16 q + 15 of the pixels (patch row wrow0 + g, column l15), g = 0 .. FP-1: 64 contiguous
+    // bytes of an f32 plane / 32 of an f16 plane / two 16-byte chunks of the pixel's halo row per g.
+    constexpr int kChainStores = CHAIN ? 4 * FP : 0;            // f32 stores of convolution 1's epilogue (vmcnt bookkeeping)
+    auto chain_epilogue = [&](int c) __attribute__((always_inline)) {
+        if constexpr (CHAIN) {
+            const bool has_res = (c & 1) != 0, last = c == 3;   // wave-uniform
+            const float* const scp = p.ch_scale[c] + q * 16;
+            const float* const shp = p.ch_shift[c] + q * 16;
+            float sc[16], sh[16];
+#pragma unroll
+            for (int i = 0; i < 16; i += 4) {
+                const f4 a = *reinterpret_cast<const f4*>(scp + i);
+                const f4 b = *reinterpret_cast<const f4*>(shp + i);
+                sc[i] = a[0]; sc[i + 1] = a[1]; sc[i + 2] = a[2]; sc[i + 3] = a[3];
+                sh[i] = b[0]; sh[i + 1] = b[1]; sh[i + 2] = b[2]; sh[i + 3] = b[3];
+            }
+            // padded-plane pixel of (patch row wrow0, column l15) of image n; planes are yHp x yWp pixels of 64 channels
+            const unsigned pix0 = (unsigned)((n * p.yHp + wrow0 + 1) * p.yWp + l15 + 1);
+            // residual: two patch rows in flight (the whole tile's 64 registers do not fit beside the accumulators and the next
+            // stage's weight fragments)
+            f4 r[2][4];
+            const float* const rb = reinterpret_cast<const float*>(last ? p.ch_y32_mid : p.ch_res0) + q * 16;
+            auto fetch_res = [&](int g) __attribute__((always_inline)) {
+#pragma unroll
+                for (int f = 0; f < 4; ++f) r[g & 1][f] = *reinterpret_cast<const f4*>(rb + (size_t)(pix0 + (unsigned)(g * p.yWp)) * 64 + f * 4);
+            };
+            if (has_res) fetch_res(0);
+            const float rm = p.ch_res_mul[c >> 1];
+            float* const o32 = reinterpret_cast<float*>(last ? p.y32 : p.ch_y32_mid) + q * 16;
+            half_t* const o16 = reinterpret_cast<half_t*>(p.y) + q * 16;
+            const int hx = l15 + 1;
+            float bad = 0.f;
+#pragma unroll
+            for (int g = 0; g < FP; ++g) {
+                if (has_res && g + 1 < FP) fetch_res(g + 1);
+                float v[16];
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float t = acc[f][g][k] * sc[f * 4 + k] + sh[f * 4 + k];
+                        if (has_res) t = __builtin_fmaf(r[g & 1][f][k], rm, t);
+                        v[f * 4 + k] = __builtin_fmaxf(t, 0.f);
+                    }
+                half8 h0, h1;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    h0[j] = (half_t)v[j]; h1[j] = (half_t)v[8 + j];
+                    bad = __builtin_fmaf((float)h0[j], 0.f, bad); bad = __builtin_fmaf((float)h1[j], 0.f, bad);
+                }
+                const size_t pix = (size_t)(pix0 + (unsigned)(g * p.yWp));
+                if (has_res) {
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) *reinterpret_cast<f4*>(o32 + pix * 64 + f * 4) = f4{v[f * 4], v[f * 4 + 1], v[f * 4 + 2], v[f * 4 + 3]};
+                }
+                if (last) {
+                    *reinterpret_cast<half8*>(o16 + pix * 64) = h0;
+                    *reinterpret_cast<half8*>(o16 + pix * 64 + 8) = h1;
+                } else {
+                    char* const row = halo + ((wrow0 + g + 1) * 18 + hx) * 128;
+                    *reinterpret_cast<half8*>(row + (((2 * q) ^ (hx & 7)) << 4)) = h0;
+                    *reinterpret_cast<half8*>(row + (((2 * q + 1) ^ (hx & 7)) << 4)) = h1;
+                }
+            }
+            if (bad != bad && p.flag) atomicMin(p.flag, p.ch_layer_id[c]);
+        }
+    };
+
     Frags F0, F1;
     int s = 0;
     auto issue_prologue_halo = [&]() __attribute__((always_inline)) {
@@ -470,7 +546,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(halo_wa
         // one or two stages ago.  Roles: the halo waves drain theirs at tap 7 (its last pieces leave at tap 5; the
         // next block's pixel reads start in the head of tap 8).
         // the next halo is younger than W(s+1): double buffered, issued at tap 0; single buffer, issued at tap 7
-        const bool halo_young = !kRoles && !FUSE0 && more_cb && (DBH ? (J >= 1 && J <= NSW - 1) : J == 8);
+        const bool halo_young = !kRoles && !FUSE0 && !CHAIN && more_cb && (DBH ? (J >= 1 && J <= NSW - 1) : J == 8);
+        // CHAIN: the sixteen f32 stores of convolution 1's epilogue are younger than the weight stage issued in its tap 8 and older than
+        // the one issued in tap 0 of convolution 2: the first two barriers of convolution 2 may leave them in flight as well
+        const bool chain_young = CHAIN && J <= 1 && cb == 2;
 #if CV_STAMP
         const unsigned long long st_a = __builtin_amdgcn_s_memtime();
 #endif
@@ -481,6 +560,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(halo_wa
             if (J == 7) wait_vm_barrier<0>();
             else wait_vm_barrier<63>();
         } else if (halo_young) wait_vm_barrier<FLY + H>();
+        else if (chain_young) wait_vm_barrier<FLY + kChainStores>();
         else wait_vm_barrier<FLY>();
         __builtin_amdgcn_sched_barrier(0);
 #if CV_STAMP
@@ -497,7 +577,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(halo_wa
             else if (DBH && J < 6 && more_cb) issue_halo(cb + 1, HB ^ 1, std::integral_constant<int, J * HPS>{}, std::integral_constant<int, HPS>{});
         } else {
             issue_w(s + NSW < nS ? s + NSW : nS - 1, NSW == 3 ? J % 3 : wslot / WSTAGE);
-            if (kRefillIssue && !FUSE0 && more_cb) issue_halo(cb + 1, 0, std::integral_constant<int, 0>{}, std::integral_constant<int, H>{});
+            if (kRefillIssue && !FUSE0 && !CHAIN && more_cb) issue_halo(cb + 1, 0, std::integral_constant<int, 0>{}, std::integral_constant<int, H>{});
             if (DBH && J == 0 && more_cb) issue_halo(cb + 1, HB ^ 1, std::integral_constant<int, 0>{}, std::integral_constant<int, H>{});
         }
 #endif
@@ -512,7 +592,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(halo_wa
 #if CV_SCHED_HINTS
         if constexpr (!kRoles) {
 #pragma unroll
-            for (int i = 0; i < LW + (kRefillIssue && !FUSE0 ? H : 0); ++i) {
+            for (int i = 0; i < LW + (kRefillIssue && !FUSE0 && !CHAIN ? H : 0); ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);           // one LDS-DMA (VMEM read)
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           // one MFMA
             }
@@ -530,6 +610,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(halo_wa
                     // this wave passed tap 8's barrier, so every wave passed tap 7's, before which all reads of the old halo
                     // were drained: the buffer is free.  Produce the next block's halo, then publish it.
                     produce0(cb + 1);
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                } else if constexpr (CHAIN) {
+                    // same argument: nobody reads the halo any more.  Convolution cb's output replaces it, then the accumulators restart.
+                    chain_epilogue(cb);
+#pragma unroll
+                    for (int f = 0; f < FC; ++f)
+#pragma unroll
+                        for (int g = 0; g < FP; ++g) acc[f][g] = f4{0.f, 0.f, 0.f, 0.f};
                     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 } else {
                     // everybody's pieces of the next halo have landed (only the weight stage issued after them may still fly)
@@ -594,6 +682,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(halo_wa
         o[4] = st_head; o[5] = st_t0 - st_k0; o[6] = st_tail;
     }
 #endif
+    if constexpr (CHAIN) {                               // convolution 3: + the first block's f32 output, ReLU -> f32 twin and f16 copy
+        chain_epilogue(3);
+        return;
+    }
     // the epilogue works on the tile just finished; the DMA side moves on to the next one
     const int eCt = ctTile, eTx = tx, eTy = ty, eN = n;
     const unsigned nxt_tile = tile + nwg;
@@ -982,6 +1074,10 @@ hipError_t conv_halo_prepare() {
     CV_FOR_EACH_HALO(X, float)
     CV_FOR_EACH_HALO(X, split_t)
 #undef X
+#if CV_HALO_TH64 == 16 && CV_HALO_NSW64 == 3
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<half_t, 64, 16, 1, 4, 1, 3, 0, false, false, false, true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+#endif
     return hipSuccess;
 }
 
@@ -999,6 +1095,20 @@ bool conv_halo_supported(int ct, int Ho, int Wo) {
 }
 
 bool conv_halo_has_th8(int ct) { return ct == 64 && CV_HALO_TH64 == 16; }
+
+// four chained 64 -> 64 convolutions on whole 16 x 16 images (ConvParams::chain): one workgroup per image, 69.6 KB of LDS
+bool conv_halo_has_chain() { return CV_HALO_TH64 == 16 && CV_HALO_NSW64 == 3; }
+hipError_t conv_halo_chain_launch(const ConvParams& p, int n_images, hipStream_t stream) {
+#if CV_HALO_TH64 == 16 && CV_HALO_NSW64 == 3
+    if (!p.chain || p.nStages != 36 || p.Ho != 16 || p.Wo != 16 || p.yCs != 64 || p.xCs != 64 || p.ksplit > 1 || n_images < 1) return hipErrorInvalidValue;
+    auto kern = conv3x3_halo_kernel<half_t, 64, 16, 1, 4, 1, 3, 0, false, false, false, true>;
+    const size_t lds = halo_lds<64, 16, 4, 1, 3, 0>();
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_images), dim3(256), lds, stream, p);
+    return hipGetLastError();
+#else
+    return hipErrorInvalidValue;
+#endif
+}
 
 hipError_t conv_halo_launch(int ct, int dt, const ConvParams& p, int n_images, hipStream_t stream, int th) {
     const int img = (p.Ho == 8 && p.Wo == 8) ? 8 : 0;

@@ -33,5 +33,8 @@ bool conv_halo_has_th8(int ct);                          // the 8 x 16 patch var
 // th: patch rows of the tile, 16 (default) or 8 (twice the workgroups: launches with few patches)
 hipError_t conv_halo_launch(int ct, int dt, const ConvParams& p, int n_images, hipStream_t stream, int th = 16);
 int conv_cfg_pt(int cfg);
+// ConvParams::chain: four chained 3x3 convolutions 64 -> 64 over whole 16 x 16 images in one launch (f16 kernels, f16r trunk)
+bool conv_halo_has_chain();
+hipError_t conv_halo_chain_launch(const ConvParams& p, int n_images, hipStream_t stream);
 
 }  // namespace cv

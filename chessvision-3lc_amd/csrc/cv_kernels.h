@@ -128,6 +128,18 @@ struct ConvParams {
     float* partial;
     int ksplit, kper;
     int prow;                 // channels per pixel row of `partial` (= padded GEMM rows)
+    // CHAIN launch of conv_halo.hip (f16r ResNet-18 layer1: four 3x3 convolutions 64 -> 64 on 16 x 16 maps = two BasicBlocks in ONE
+    // launch, the image resident in LDS between them): `w` holds the 36 weight stages of convolutions 0..3 back to back, `x` is the
+    // f16 copy of the trunk entering the stage.  Convolution c = 0, 2: relu(bn(conv)) stays in LDS as f16.  c = 1: + ch_res0
+    // (f32 twin of the input) * ch_res_mul[0], ReLU -> f32 to ch_y32_mid (the first block's output twin) and f16 into LDS.
+    // c = 3: + ch_y32_mid * ch_res_mul[1], ReLU -> y32 (f32 twin) and y (f16 copy).  All tensors 18 x 18 x 64 padded planes.
+    int chain;                // 0 = off
+    const float* ch_scale[4]; // per-convolution epilogue constants (range factors folded, as `scale` / `shift`)
+    const float* ch_shift[4];
+    const char* ch_res0;
+    char* ch_y32_mid;
+    float ch_res_mul[2];
+    unsigned ch_layer_id[4];  // numeric-guard ids of the four convolutions
 };
 
 }  // namespace cv

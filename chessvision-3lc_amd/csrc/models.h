@@ -43,6 +43,10 @@ struct Engine::ResNet {
         Activation mid, out, sc;                     // conv1 output, block output, shortcut (if downsampled)
     } blocks[8];
     Activation stem_out, pool_out;
+    // f16r: layer1 (two BasicBlocks = four 3x3 convolutions 64 -> 64 on 16 x 16 maps) as ONE launch with the image resident in LDS
+    // (conv_halo.hip: CHAIN).  chain_w = the four layers' packed weight stages back to back.  CV_RESNET_CHAIN=0 switches it off.
+    DeviceBuffer chain_w;
+    bool chain_ok = false;
     std::vector<Activation*> acts;
     std::map<std::string, TensorRef> taps;
     int64_t macs = 0;

@@ -6,6 +6,8 @@
 // BasicBlock = conv1-bn1-ReLU-conv2-bn2-(+shortcut)-ReLU: both BNs, the residual add and both ReLUs are conv
 // epilogues here; the squares of many boards are batched so the 2x2 / 4x4 stages still form large GEMMs.
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
 
 #include "engine.h"
 #include "models.h"
@@ -21,6 +23,7 @@ Status bn_fold_public(const ParamMap& pm, const std::string& prefix, int c, std:
 Status reject_unknown_keys_public(const ParamMap& pm, const std::vector<std::string>& known, const char* model);
 
 static Status resnet_reserve(Engine& e, int n);
+static Status layer1_chain(Engine& e, int n, hipStream_t s);
 static Status resnet_chunk(Engine& e, const void* x, bool x_u8, int n, float* out, bool softmax, hipStream_t s);
 
 static void bn_keys(std::vector<std::string>& out, const std::string& p) {
@@ -157,6 +160,18 @@ Status resnet_load(Engine& e, const ParamMap& pm) {
     }
     CV_TRY(reject_unknown_keys_public(pm, known, "resnet18(in_chans=1, num_classes=13)"));
     R.macs = macs;
+    {   // f16r: layer1 as one chained launch -- the four layers' weight stages (9 taps x 64 rows x 128 B each) back to back
+        static const bool on = [] { const char* v = std::getenv("CV_RESNET_CHAIN"); return !(v && v[0] == '0'); }();
+        ConvLayer* L[4] = {&R.blocks[0].conv1, &R.blocks[0].conv2, &R.blocks[1].conv1, &R.blocks[1].conv2};
+        bool fits = on && e.trunk32 && dt == kF16 && conv_halo_has_chain();
+        const size_t one = (size_t)9 * 64 * 128;
+        for (ConvLayer* l : L) fits = fits && l->dt == kF16 && l->ct == 64 && l->rows == 64 && l->nStages == 9 && l->nCt == 1 && l->w.bytes >= one && l->halo_ok;
+        if (fits) {
+            CV_TRY(R.chain_w.alloc(4 * one, false));
+            for (int i = 0; i < 4; ++i) CV_HIP(hipMemcpy((char*)R.chain_w.ptr + i * one, L[i]->w.ptr, one, hipMemcpyDeviceToDevice));
+            R.chain_ok = true;
+        }
+    }
     e.resnet = std::move(m);
 
     // range calibration on 128 squares: noise, flat grey levels, gradients and checkers (what board crops look like)
@@ -211,8 +226,11 @@ static Status resnet_reserve(Engine& e, int n) {
         for (int bi = 0; bi < 2; ++bi) {
             Engine::ResNet::Block& B = R.blocks[l * 2 + bi];
             const std::string p = "layer" + std::to_string(l + 1) + "." + std::to_string(bi);
-            R.taps[p + ".act1"] = B.mid.ref(S);
-            R.taps[p] = B.out.ref(S);
+            // chained layer1 (f16r): conv1's output of both blocks and the f16 copy of the first block's output live in LDS only --
+            // no tap for the former, the latter is read from its f32 twin
+            const bool chained = R.chain_ok && l == 0;
+            if (!chained) R.taps[p + ".act1"] = B.mid.ref(S);
+            R.taps[p] = (chained && bi == 0) ? B.out.ref32(S) : B.out.ref(S);
             if (B.has_down) R.taps[p + ".downsample"] = B.sc.only32 ? B.sc.ref32(S) : B.sc.ref(S);
         }
         R.taps["layer" + std::to_string(l + 1)] = R.blocks[l * 2 + 1].out.ref(S);
@@ -259,7 +277,13 @@ static Status resnet_chunk(Engine& e, const void* x, bool x_u8, int n, float* ou
         if (e.calibrating) CV_TRY(e.measure(R.pool_out.ref(n), s));
     }
     TensorRef cur = R.pool_out.ref(n);
-    for (int i = 0; i < 8; ++i) {
+    int first_block = 0;
+    if (R.chain_ok && !e.calibrating) {                // the calibration passes run layer by layer (every tensor is measured)
+        CV_TRY(layer1_chain(e, n, s));
+        cur = R.blocks[1].out.ref(n);
+        first_block = 2;
+    }
+    for (int i = first_block; i < 8; ++i) {
         Engine::ResNet::Block& B = R.blocks[i];
         TensorRef shortcut = cur;
         if (B.has_down) {
@@ -281,6 +305,55 @@ static Status resnet_chunk(Engine& e, const void* x, bool x_u8, int n, float* ou
     begin("head_avgpool_fc", 13.0 * 512 * n, (double)n * (cur.H * cur.W * 512 * dtype_size(head_dt) + 13 * 4));
     CV_TRY(end("head_avgpool_fc", head_avgpool_fc(head_dt, cur, (const float*)R.fc_w.ptr, (const float*)R.fc_b.ptr, out,
                                                    softmax ? 1 : 0, e.guard_ptr(), R.head_id, s)));
+    return Status();
+}
+
+// layer1.0 and layer1.1 in one launch (f16r engine): pool_out (f16 copy + f32 twin) -> blocks[1].out (f16 copy + f32 twin), the first
+// block's f32 output twin as the only intermediate in memory.  Same arithmetic as the four run_conv launches: f16 products, f32
+// accumulation, BN affine and residual in f32, one rounding to f16 per tensor.
+static Status layer1_chain(Engine& e, int n, hipStream_t s) {
+    Engine::ResNet& R = *e.resnet;
+    Engine::ResNet::Block &B0 = R.blocks[0], &B1 = R.blocks[1];
+    const TensorRef x = R.pool_out.ref(n), y0 = B0.out.ref(n), y1 = B1.out.ref(n);
+    if (!x.base || !x.base32 || !y0.base32 || !y1.base || !y1.base32 || x.Cs != 64 || y1.Cs != 64 || x.H != 16 || x.W != 16)
+        return fail(3, "layer1 chain: trunk tensors are not in the f16r layout");
+    // tensor exponents exactly as the layer-by-layer path folds them
+    CV_TRY(B0.conv1.set_exps(x.exp, B0.mid.exp, s));
+    CV_TRY(B0.conv2.set_exps(B0.mid.exp, B0.out.exp, s));
+    CV_TRY(B1.conv1.set_exps(B0.out.exp, B1.mid.exp, s));
+    CV_TRY(B1.conv2.set_exps(B1.mid.exp, B1.out.exp, s));
+    ConvLayer* L[4] = {&B0.conv1, &B0.conv2, &B1.conv1, &B1.conv2};
+    ConvParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.x = reinterpret_cast<const char*>(x.base);
+    p.w = reinterpret_cast<const char*>(R.chain_w.ptr);
+    p.y = reinterpret_cast<char*>(y1.base);
+    p.y32 = reinterpret_cast<char*>(y1.base32);
+    p.M = n * 256; p.Ho = 16; p.Wo = 16;
+    p.xHp = 18; p.xWp = 18; p.stride = 1; p.xCs = 64; p.xCoffBytes = 0;
+    p.yHp = 18; p.yWp = 18; p.yCs = 64; p.yCoff = 0;
+    p.Cout = 64; p.rows = 64; p.nStages = 36; p.nCt = 1; p.relu = 1;
+    p.flag = e.guard_ptr();
+    p.layer_id = B1.conv2.layer_id;
+    p.chain = 4;
+    for (int i = 0; i < 4; ++i) {
+        p.ch_scale[i] = reinterpret_cast<const float*>(L[i]->scale.ptr);
+        p.ch_shift[i] = reinterpret_cast<const float*>(L[i]->shift.ptr);
+        p.ch_layer_id[i] = L[i]->layer_id;
+    }
+    p.ch_res0 = reinterpret_cast<const char*>(x.base32);
+    p.ch_y32_mid = reinterpret_cast<char*>(y0.base32);
+    p.ch_res_mul[0] = std::ldexp(1.f, x.exp - B0.out.exp);
+    p.ch_res_mul[1] = std::ldexp(1.f, B0.out.exp - B1.out.exp);
+    if (e.profiling) {
+        // compulsory bytes: f16 input + its f32 twin, the first block's f32 output written and read back, f32 + f16 output, weights
+        const double px = (double)n * 256 * 64;
+        e.prof_begin("layer1 (4 convs, chained)", true, 4.0 * 9 * 64 * 64 * 256 * (double)n, s, px * (2 + 4 + 4 + 4 + 4 + 2) + 4.0 * 9 * 64 * 64 * 2);
+        e.prof.back().kernel = "conv3x3_halo_kernel<half_t,64,16x16,CHAIN4>";
+    }
+    const hipError_t err = conv_halo_chain_launch(p, n, s);
+    if (e.profiling) e.prof_end(s);
+    if (err != hipSuccess) return hip_fail(err, "layer1 chain launch");
     return Status();
 }
 
