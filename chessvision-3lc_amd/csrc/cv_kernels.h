@@ -35,6 +35,9 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 // f16(v - hi) as ONE mixed-precision FMA (v_fma_mixlo / mixhi_f16: fma(f16 hi, -1, f32 v) rounded to f16 -- v - hi is exact in f32,
 // so the single rounding equals the convert-back / subtract / convert chain the compiler emits for the C expression, which costs
 // ~3 more instructions per value; r03_tuning.md steps 20-21).  hp / lp = the packed f16 pairs (element 0 in the low half).
+// NOT for code where the scheduler may place it between INDEPENDENT MFMAs (epilogues that consume the accumulators are fine): the
+// compiler does not look inside inline asm when it pads MFMA hazards, and pointwise.hip: shortcut1x1s2_kernel gave run-to-run
+// different results with it until the C form replaced it (round 5, r05_tuning.md).
 __device__ __forceinline__ void split_pair(float v0, float v1, unsigned& hp, unsigned& lp) {
     typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
     const h2_t h = {(_Float16)v0, (_Float16)v1};

@@ -41,6 +41,13 @@ struct Engine::ResNet {
         ConvLayer conv1, conv2, down;
         bool has_down = false;
         Activation mid, out, sc;                     // conv1 output, block output, shortcut (if downsampled)
+        // f16r: the shortcut convolution as a dedicated split-f16 kernel between the f32 twins (pointwise.hip: shortcut1x1s2);
+        // `down` (the same layer on the f32-input MFMA through the generic kernel) remains for the calibration passes and CV_SHORTCUT_FAST=0
+        bool fast_sc = false;
+        DeviceBuffer sc_wpk, sc_scale, sc_shift;
+        std::vector<float> h_sc_scale, h_sc_shift;   // BN affine with the weight rows' exponents folded in
+        int sc_in_exp = 1 << 20, sc_out_exp = 1 << 20;   // exponents the device copies are folded for
+        unsigned sc_id = 0;
     } blocks[8];
     Activation stem_out, pool_out;
     // f16r: layer1 (two BasicBlocks = four 3x3 convolutions 64 -> 64 on 16 x 16 maps) as ONE launch with the image resident in LDS

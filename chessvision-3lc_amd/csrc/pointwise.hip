@@ -899,4 +899,103 @@ hipError_t mfma_probe_f32(const float* a, const float* b, float* d, hipStream_t 
     return hipGetLastError();
 }
 
+// ---- f16r engine: ResNet stage-boundary shortcut (conv 1x1 / stride 2 + BN) from f32 twin to f32 twin ---------------------------
+// reference: timm BasicBlock.downsample = [Conv2d(C, 2C, 1, stride 2, bias=False), BatchNorm2d] (notebooks/model-summary.ipynb).
+// The shortcut IS the residual trunk at a stage boundary, so it runs at f32 grade: both operands are split into f16 hi + lo (the
+// pixel values on the fly from the f32 twin, the weights at load time, rows normalised) and every k-step is three f16 MFMAs
+// hi.hi + lo.hi + hi.lo with f32 accumulation -- the arithmetic of the f16x3 engine.  Round 4 ran these three layers on the f32-input
+// MFMA through the generic implicit-GEMM kernel: 0.28 + 0.20 + 0.16 ms per 16384 squares for 1.1 % of the network's MACs (K = Cin is
+// two to eight stages: all prologue); here a wave owns 16 output pixels x 128 channels, reads each pixel's Cin floats once and
+// streams the packed weight fragments from L2; HBM-bound (Cin floats in, 2 Cin floats out per output pixel).
+template <int CIN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void shortcut1x1s2_kernel(const float* __restrict__ x, int n, int H, int W, const half8* __restrict__ wpk,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            float* __restrict__ y, unsigned* flag, unsigned layer_id) {
+    constexpr int COUT = 2 * CIN, KS = CIN / 32, CG = COUT / 128;
+    const int Ho = H / 2, Wo = W / 2, M = n * Ho * Wo;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, l15 = lane & 15;
+    const int task = blockIdx.x * 4 + wave;                      // (group of 16 output pixels, group of 128 output channels)
+    const int cg = task % CG, pg = task / CG;
+    if (pg * 16 >= M) return;
+    int m = pg * 16 + l15;
+    const bool live = m < M;
+    if (!live) m = M - 1;
+    const int ox = m % Wo, oy = (m / Wo) % Ho, img = m / (Wo * Ho);
+    const float* const xp = x + ((size_t)(img * (H + 2) + 2 * oy + 1) * (W + 2) + 2 * ox + 1) * CIN + q * 8;
+    f4 acc[8];
+#pragma unroll
+    for (int f = 0; f < 8; ++f) acc[f] = f4{0.f, 0.f, 0.f, 0.f};
+    // Two k-steps at a time, every load of the batch issued before its first MFMA (4 pixel + 32 weight-fragment loads = 144
+    // registers in flight): left to itself the compiler interleaves load / wait / MFMA one fragment at a time and a wave spends its
+    // life in ~32 dependent L2 round trips (measured: 0.38 ms per 16384 squares for layer2.0, slower than the generic kernel).
+#pragma unroll
+    for (int kb = 0; kb < KS; kb += 2) {
+        f4 xv[2][2];
+        half8 wa[2][16];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            xv[u][0] = *reinterpret_cast<const f4*>(xp + (kb + u) * 32);
+            xv[u][1] = *reinterpret_cast<const f4*>(xp + (kb + u) * 32 + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const half8* const wp = wpk + ((size_t)(cg * KS + kb + u) * 16) * 64 + lane;      // [cg][ks][fragment 8][hi | lo][lane]
+#pragma unroll
+            for (int i = 0; i < 16; ++i) wa[u][i] = wp[i * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            // B fragment: k = 8 q + j of this k-step = eight consecutive input channels of pixel l15, split into f16 hi + lo.  Plain C on
+            // purpose: the inline-asm pair conversion (cv_kernels.h: split_pair) next to independent MFMAs gave run-to-run different
+            // results here -- the compiler cannot see the hazard between an in-flight MFMA's source registers and an asm's output
+            half8 bh, bl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = j < 4 ? xv[u][0][j] : xv[u][1][j - 4];
+                bh[j] = (half_t)v;
+                bl[j] = (half_t)(v - (float)bh[j]);
+            }
+#pragma unroll
+            for (int f = 0; f < 8; ++f) {
+                acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[u][2 * f], bh, acc[f], 0, 0, 0);
+                acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[u][2 * f + 1], bh, acc[f], 0, 0, 0);
+                acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[u][2 * f], bl, acc[f], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // lane (q, l15): channels 128 cg + 32 q + 4 f + r of pixel l15 (the weight rows were packed in that order): 128 contiguous bytes
+    const int c0 = cg * 128 + q * 32;
+    float* const yp = y + ((size_t)(img * (Ho + 2) + oy + 1) * (Wo + 2) + ox + 1) * COUT + c0;
+    float bad = 0.f;
+#pragma unroll
+    for (int f = 0; f < 8; ++f) {
+        const f4 sc = *reinterpret_cast<const f4*>(scale + c0 + f * 4), sh = *reinterpret_cast<const f4*>(shift + c0 + f * 4);
+        f4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { o[r] = acc[f][r] * sc[r] + sh[r]; bad = __builtin_fmaf(o[r], 0.f, bad); }
+        if (live) *reinterpret_cast<f4*>(yp + f * 4) = o;
+    }
+    if (live && bad != bad && flag) atomicMin(flag, layer_id);
+}
+
+hipError_t shortcut1x1s2(const TensorRef& x32, const void* wpk, const float* scale, const float* shift, const TensorRef& y32,
+                         unsigned* flag, unsigned layer_id, hipStream_t s) {
+    if (!x32.f32_only || !y32.f32_only || x32.Coff || y32.Coff || x32.Cs != x32.C || y32.Cs != y32.C || y32.C != 2 * x32.C ||
+        x32.H != 2 * y32.H || x32.W != 2 * y32.W || x32.N != y32.N)
+        return hipErrorInvalidValue;
+    const int cin = x32.C, M = x32.N * y32.H * y32.W;
+    const int tasks = ((M + 15) / 16) * (2 * cin / 128);
+    const dim3 grid((unsigned)((tasks + 3) / 4)), block(256);
+    const float* xb = reinterpret_cast<const float*>(x32.base);
+    float* yb = reinterpret_cast<float*>(y32.base);
+    const half8* w = reinterpret_cast<const half8*>(wpk);
+    if (cin == 64) hipLaunchKernelGGL(shortcut1x1s2_kernel<64>, grid, block, 0, s, xb, x32.N, x32.H, x32.W, w, scale, shift, yb, flag, layer_id);
+    else if (cin == 128) hipLaunchKernelGGL(shortcut1x1s2_kernel<128>, grid, block, 0, s, xb, x32.N, x32.H, x32.W, w, scale, shift, yb, flag, layer_id);
+    else if (cin == 256) hipLaunchKernelGGL(shortcut1x1s2_kernel<256>, grid, block, 0, s, xb, x32.N, x32.H, x32.W, w, scale, shift, yb, flag, layer_id);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 }  // namespace cv

@@ -134,6 +134,50 @@ Status resnet_load(Engine& e, const ParamMap& pm) {
                 B.sc.shape(res[l], res[l], w, dt);
                 B.sc.want32 = B.sc.only32 = e.trunk32;
                 R.acts.push_back(&B.sc);
+                // measured (profiles/r05_tuning.md step 4): 0.31 / 0.21 / 0.15 ms per 16384 squares against 0.28 / 0.20 / 0.16 for `down` on the
+                // f32-input MFMA -- both sit on the stride-2 read of the f32 twin (~2.6-3.2 TB/s), not on arithmetic: OFF unless CV_SHORTCUT_FAST=1
+                static const bool fast_on = [] { const char* v = std::getenv("CV_SHORTCUT_FAST"); return v && v[0] == '1'; }();
+                if (e.trunk32 && dt == kF16 && fast_on && w == 2 * cin && (cin == 64 || cin == 128 || cin == 256)) {
+                    // split-f16 image of the 1x1 weights for shortcut1x1s2: rows normalised to [0.5, 1) (exponent into the scale), hi / lo halves,
+                    // [channel group of 128][k-step of 32][fragment 8][hi | lo][lane 64][8]; MFMA row i of fragment f = channel 32 (i/4) + 4 f + i%4
+                    const float* wd;
+                    CV_TRY(need_public(pm, p + ".downsample.0.weight", {w, cin, 1, 1}, &wd));
+                    std::vector<float> sc, sh;
+                    CV_TRY(bn_fold_public(pm, p + ".downsample.1", w, sc, sh));
+                    std::vector<int> rex((size_t)w, 0);
+                    B.h_sc_scale.assign((size_t)w, 0.f); B.h_sc_shift.assign((size_t)w, 0.f);
+                    for (int ch = 0; ch < w; ++ch) {
+                        float mx = 0.f;
+                        for (int k = 0; k < cin; ++k) {
+                            if (!std::isfinite(wd[(size_t)ch * cin + k])) return fail(1, p + ".downsample.0: non-finite weight in the state dict");
+                            mx = std::max(mx, std::fabs(wd[(size_t)ch * cin + k]));
+                        }
+                        if (mx > 0.f) (void)std::frexp(mx, &rex[ch]);
+                        B.h_sc_scale[ch] = std::ldexp(sc[ch], rex[ch]);
+                        B.h_sc_shift[ch] = sh[ch];
+                    }
+                    const int KS = cin / 32, CG = w / 128;
+                    std::vector<_Float16> pk((size_t)CG * KS * 16 * 64 * 8);
+                    for (int cg = 0; cg < CG; ++cg)
+                        for (int ks = 0; ks < KS; ++ks)
+                            for (int f = 0; f < 8; ++f)
+                                for (int lane = 0; lane < 64; ++lane) {
+                                    const int i = lane & 15, q = lane >> 4;
+                                    const int ch = cg * 128 + (i / 4) * 32 + f * 4 + (i % 4);
+                                    for (int j = 0; j < 8; ++j) {
+                                        const float v = std::ldexp(wd[(size_t)ch * cin + ks * 32 + q * 8 + j], -rex[ch]);
+                                        const _Float16 hi = (_Float16)v;
+                                        const size_t at = ((((size_t)(cg * KS + ks) * 8 + f) * 2) * 64 + lane) * 8 + j;
+                                        pk[at] = hi;
+                                        pk[at + 64 * 8] = (_Float16)(v - (float)hi);
+                                    }
+                                }
+                    CV_TRY(B.sc_wpk.upload(pk.data(), pk.size() * sizeof(_Float16)));
+                    CV_TRY(B.sc_scale.alloc((size_t)w * sizeof(float), false));
+                    CV_TRY(B.sc_shift.alloc((size_t)w * sizeof(float), false));
+                    B.sc_id = B.down.layer_id;
+                    B.fast_sc = true;
+                }
                 macs += (int64_t)cin * w * res[l] * res[l];
             }
             B.mid.shape(res[l], res[l], w, dt);
@@ -287,10 +331,36 @@ static Status resnet_chunk(Engine& e, const void* x, bool x_u8, int n, float* ou
         Engine::ResNet::Block& B = R.blocks[i];
         TensorRef shortcut = cur;
         if (B.has_down) {
-            if (B.sc.only32) {                                 // f16r: f32 convolution from the trunk's twin to the shortcut's
+            if (B.sc.only32) {                                 // f16r: f32-grade convolution from the trunk's twin to the shortcut's
                 TensorRef in32 = cur;
                 in32.base = cur.base32; in32.base32 = nullptr; in32.f32_only = 1;
-                CV_TRY(e.run_conv(B.down, in32, B.sc.ref32(n), nullptr, false, s));
+                if (B.fast_sc && !e.calibrating) {
+                    const TensorRef out32 = B.sc.ref32(n);
+                    if (B.sc_in_exp != in32.exp || B.sc_out_exp != out32.exp) {          // fold the tensor exponents (ConvLayer::set_exps)
+                        if (capture_flag()) return fail(1, "shortcut constants re-folded during graph capture");
+                        CV_HIP(hipStreamSynchronize(s));
+                        std::vector<float> sc(B.h_sc_scale.size()), sh(sc.size());
+                        for (size_t k = 0; k < sc.size(); ++k) {
+                            sc[k] = std::ldexp(B.h_sc_scale[k], in32.exp - out32.exp);
+                            sh[k] = std::ldexp(B.h_sc_shift[k], -out32.exp);
+                            if (!std::isfinite(sc[k]) || !std::isfinite(sh[k])) return fail(1, "shortcut: range factors leave the f32 range");
+                        }
+                        CV_HIP(hipMemcpy(B.sc_scale.ptr, sc.data(), sc.size() * sizeof(float), hipMemcpyHostToDevice));
+                        CV_HIP(hipMemcpy(B.sc_shift.ptr, sh.data(), sh.size() * sizeof(float), hipMemcpyHostToDevice));
+                        B.sc_in_exp = in32.exp; B.sc_out_exp = out32.exp;
+                    }
+                    const double opx = (double)n * out32.H * out32.W;
+                    if (e.profiling) {
+                        e.prof_begin(B.down.name, true, opx * in32.C * out32.C, s, opx * (in32.C + out32.C) * 4.0 + (double)in32.C * out32.C * 4.0);
+                        e.prof.back().kernel = "shortcut1x1s2_kernel<" + std::to_string(in32.C) + ">";
+                    }
+                    const hipError_t err = shortcut1x1s2(in32, B.sc_wpk.ptr, (const float*)B.sc_scale.ptr, (const float*)B.sc_shift.ptr, out32,
+                                                         e.guard_ptr(), B.sc_id, s);
+                    if (e.profiling) e.prof_end(s);
+                    if (err != hipSuccess) return hip_fail(err, "shortcut1x1s2");
+                } else {
+                    CV_TRY(e.run_conv(B.down, in32, B.sc.ref32(n), nullptr, false, s));
+                }
             } else {
                 CV_TRY(e.run_conv(B.down, cur, B.sc.ref(n), nullptr, false, s));
             }
