@@ -206,6 +206,24 @@ def pipeline_e2e(dtype: str, n_boards: int = 256, n_checked: int = 8):
     return block, images[:n_checked], res[:n_checked]
 
 
+class _DeviceMemory:
+    """Device-wide memory in use (total - free of hipMemGetInfo: every process on the GPU counts, the engines' hipMalloc'd workspaces
+    included), sampled at the points where the footprint peaks; ``peak_gb`` is the largest sample this rank saw."""
+
+    def __init__(self, device):
+        self.device, self.peak, self.total = device, 0, 0
+
+    def sample(self):
+        free, total = torch.cuda.mem_get_info(self.device)
+        self.total = total
+        self.peak = max(self.peak, total - free)
+        return total - free
+
+    @property
+    def peak_gb(self):
+        return self.peak / 1e9
+
+
 class _LazyPhotos:
     """The global list of synthetic board photos; a photo is only rendered when its index is touched (a rank touches its shard)."""
 
@@ -223,7 +241,7 @@ class _LazyPhotos:
         return self.cache[i]
 
 
-def pipeline_e2e_sharded(dtype, boards_per_rank, rank, world, device, cvd):
+def pipeline_e2e_sharded(dtype, boards_per_rank, rank, world, device, cvd, mem=None):
     """BASELINE configs[4] literally: ONE list of world * B photos, ``distributed.process_images_sharded`` (rank r processes
     photos r::world through host staging, resize, UNet, contours, warp, ResNet-18, FEN; probabilities / quadrangles / masks are
     all-gathered and re-interleaved).  Every rank times its own shard; the block carries min / mean / max over the ranks and
@@ -247,6 +265,8 @@ def pipeline_e2e_sharded(dtype, boards_per_rank, rank, world, device, cvd):
         warm = _LazyPhotos(min(96, boards_per_rank) * world)
         warm.cache = photos.cache
         cvd.process_images_sharded(cv, warm, fallback_quad=True, gather=False, return_crops=False)
+        if mem is not None:
+            mem.sample()                                              # every rank's engines are loaded and their workspaces grown
         best = None
         for _ in range(3):
             tm = {}
@@ -256,13 +276,29 @@ def pipeline_e2e_sharded(dtype, boards_per_rank, rank, world, device, cvd):
             total = time.perf_counter() - t0
             if best is None or total < best[0]:
                 best = (total, tm["shard_s"], tm["gather_s"], res)
-    total, shard_s, gather_s, res = best
+        total, shard_s, gather_s, res = best
+        # The gathered list must be in the caller's order: rank 0 recomputes the first photo of every OTHER rank's shard itself
+        # (and one from the middle of each) and compares FEN and probabilities with what the gather delivered for that index.
+        order_checked = order_bad = 0
+        if rank == 0 and world > 1:
+            import numpy as np
+            picks = sorted({r for r in range(1, world)} | {r + world * (boards_per_rank // 2) for r in range(1, world)})
+            picks = [i for i in picks if i < n_global]
+            own = cv.process_images([photos[i] for i in picks], fallback_quad=True, return_crops=False)
+            for i, mine in zip(picks, own):
+                got = res[i]
+                same = (got is not None and got.position is not None and mine.position is not None and got.position.fen == mine.position.fen and
+                        float(np.abs(got.position.model_probabilities - mine.position.model_probabilities).max()) <= 1e-6)
+                order_checked += 1
+                order_bad += not same
     rate = cvd.stats_over_ranks(boards_per_rank / shard_s, device)
     whole = n_global / cvd.max_over_ranks(total, device)
     gather = cvd.stats_over_ranks(gather_s, device)
     fens = sum(r is not None and r.position is not None for r in res)
     return {"boards_per_sec_per_rank": {k: round(v, 1) for k, v in rate.items()}, "boards_per_sec_whole_job": round(whole, 1),
-            "gather_s": {k: round(v, 4) for k, v in gather.items()}, "global_boards": n_global, "fens_on_rank0": fens,
+            "gather_s": {k: round(v, 4) for k, v in gather.items()}, "gather_s_per_rank": [round(v, 4) for v in cvd.list_over_ranks(gather_s, device)],
+            "shard_s_per_rank": [round(v, 4) for v in cvd.list_over_ranks(shard_s, device)],
+            "global_boards": n_global, "fens_on_rank0": fens, "order_checked_on_rank0": order_checked, "order_mismatches": order_bad,
             "calibration_identical_across_ranks": cal["identical_across_ranks"],
             "note": "host photos in, FEN out on every rank (best of 3 calls); per-rank rate = shard boards / that rank's process_images time; "
                     "whole job = all boards / slowest rank's call including the all_gather of probabilities, quadrangles and masks"}
@@ -495,6 +531,9 @@ def flatten_evidence(result):
     put(cfg, "rccl_ranks_seen", result.get("rccl_ranks_seen"))
     put(cfg, "dist_backend", result.get("dist_backend"))
     put(cfg, "init_s_max_over_ranks", pick(result, "init_s", "max"))
+    put(cfg, "device_memory_peak_used_gb", pick(result, "device_memory", "peak_used_gb_max_over_ranks"))
+    put(cfg, "pipeline_e2e_ranks_order_mismatches", pick(result, "pipeline_e2e_ranks", "order_mismatches"))
+    put(cfg, "pipeline_e2e_ranks_gather_s_max", pick(result, "pipeline_e2e_ranks", "gather_s", "max"))
     put(cfg, "calibration_identical_across_ranks", pick(result, "calibration_sync", "identical_across_ranks"))
     put(cfg, "sharding_gathered_in_order", pick(result, "sharding", "gathered_in_order"))
     put(cfg, "parity_unet_logit_max_abs_err", pick(result, "parity_vs_oracle", "unet_logit_max_abs_err"))
@@ -598,7 +637,10 @@ def main():
     eng = make_engine(args.dtype)
     calibration = cvd.sync_calibration(eng, device)              # every rank computes with rank 0's tensor exponents
     torch.cuda.synchronize(device)
-    init_s = cvd.stats_over_ranks(time.perf_counter() - t_init, device)   # weights: generate (rank 0) + broadcast + pack + calibrate
+    init_mine = time.perf_counter() - t_init
+    init_s = cvd.stats_over_ranks(init_mine, device)   # weights: generate (rank 0) + broadcast + pack + calibrate
+    init_per_rank = cvd.list_over_ranks(init_mine, device)
+    mem = _DeviceMemory(device)
 
     # ---- synthetic inputs, resident in HBM before the timed region ----
     # ONE global batch of world * B boards, board i drawn from its own seed; rank r holds boards r::world of it (SURVEY.md
@@ -617,6 +659,7 @@ def main():
     streams = [torch.cuda.Stream(device), torch.cuda.Stream(device)] if args.overlap else None
 
     elapsed, out = measure(eng, x, sq, args.steps, args.warmup, device, cvd, streams)
+    mem.sample()                                          # every rank's workspace has grown to its chunk
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
 
@@ -631,14 +674,22 @@ def main():
     e2e_ranks = None
     if world > 1 and not args.no_extras:
         e2e_prec = args.e2e_precision or (args.dtype if "+" in args.dtype or args.dtype == "f16r" else f"{args.dtype}+f16r")
-        e2e_ranks = pipeline_e2e_sharded(e2e_prec, B, rank, world, device, cvd)
+        # the sharded pipeline loads its own engines: the throughput engine's workspace (27 GB at the default chunks) is released first so
+        # that eight ranks sharing ONE device (the gloo test of configs[4]'s global shape) stay inside its 288 GB; rank 0 reloads it for
+        # the roofline pass below
+        eng.close()
+        eng = None
+        e2e_ranks = pipeline_e2e_sharded(e2e_prec, B, rank, world, device, cvd, mem)
         e2e_ranks["precision"] = e2e_prec
+    peak_mem = cvd.max_over_ranks(mem.peak_gb, device)
 
     if rank != 0:
         cvd.barrier(device)                              # leave together with rank 0 (it still profiles and reports)
         cvd.shutdown()
         return
 
+    if eng is None:
+        eng = make_engine(args.dtype)
     roof, roof_hbm, launches, conv_ms, conv_n, all_ms = rooflines(eng, x, sq, args.dtype, B)
     if not args.no_extras:
         try:
@@ -670,7 +721,11 @@ def main():
                    "resnet_chunk": eff_resnet, "parallelism": f"replicas x{world}, boards sharded, weights RCCL-broadcast once",
                    "gflop_per_board": round(2 * macs_board / 1e9, 3)},
         "rccl_ranks_seen": rccl_ranks, "dist_backend": cvd.backend_name(),
-        "init_s": {k: round(v, 3) for k, v in init_s.items()}, "calibration_sync": calibration,
+        "init_s": {k: round(v, 3) for k, v in init_s.items()}, "init_s_per_rank": [round(v, 3) for v in init_per_rank],
+        "calibration_sync": calibration,
+        "device_memory": {"peak_used_gb_max_over_ranks": round(peak_mem, 2), "device_total_gb": round(mem.total / 1e9, 2),
+                          "note": "hipMemGetInfo total - free, device-wide (ranks sharing one GPU under CV_DIST_BACKEND=gloo all count), sampled after "
+                                  "the timed steps and after the sharded pipeline's warm-up"},
         "sharding": {"global_boards": world * B, "rule": "rank r owns boards r::world", "gathered_in_order": shard_ok},
         "host_threads_per_rank": cvd.host_threads(),
         "e2e_tflops": round(2 * macs_board * value / 1e12, 2),

@@ -237,6 +237,16 @@ def stats_over_ranks(value: float, device: torch.device) -> dict:
     return {"min": min(vals), "mean": sum(vals) / len(vals), "max": max(vals)}
 
 
+def list_over_ranks(value: float, device: torch.device) -> list:
+    """The per-rank scalar of every rank, in rank order (every rank gets the same list)."""
+    if not dist.is_initialized():
+        return [float(value)]
+    t = torch.tensor([value], dtype=torch.float64, device=_coll_device(device))
+    got = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(got, t)
+    return [float(g.item()) for g in got]
+
+
 def count_ranks(device: torch.device) -> int:
     """All-reduce of a one per rank: the number of ranks that really took part in a collective (1 without a process group)."""
     if not dist.is_initialized():

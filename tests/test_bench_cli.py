@@ -133,3 +133,36 @@ def test_four_ranks_on_one_gpu_over_gloo():
     assert line["sharding"]["gathered_in_order"] is True and line["calibration_sync"]["identical_across_ranks"] is True
     e2e = line["pipeline_e2e_ranks"]
     assert e2e["global_boards"] == 128 and e2e["fens_on_rank0"] == 128 and e2e["calibration_identical_across_ranks"] is True
+
+
+@pytest.mark.gpu
+def test_eight_ranks_on_one_gpu_run_configs4_global_shape():
+    """BASELINE configs[4] at its REAL global shape, functionally, on the one GPU there is: `CV_DIST_BACKEND=gloo python bench.py --gpus 8
+    --boards 256` = 2048 boards sharded r::8 over eight ranks that share the MI355X (RCCL refuses that; gloo carries the collectives),
+    f16x3 UNet + fp16 classifier in the sharded host pipeline.  Asserted: one JSON line; all 2048 FENs on rank 0 and in the caller's
+    order (rank 0 recomputes photos of every other rank's shard and compares); identical calibration on all ranks; `init_s` and
+    `gather_s` per rank in the line; the device-wide memory peak (eight workspaces on one device) below 288 GB; start-up of the slowest
+    of eight ranks within 1.5x of... the fastest (the ranks pack and calibrate side by side: a serialised start-up would show as 8x).
+    No scaling claim: eight ranks time-share one GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "CV_FORCE_DIST")}
+    env["CV_DIST_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--boards", "256", "--steps", "1", "--warmup", "1",
+                          "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=3000)
+    assert out.returncode == 0, out.stderr[-4000:]
+    lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["rccl_ranks_seen"] == 8 and line["dist_backend"] == "gloo"
+    assert line["config"]["global_boards_per_step"] == 2048 and line["sharding"]["gathered_in_order"] is True
+    assert line["calibration_sync"]["identical_across_ranks"] is True
+    assert len(line["init_s_per_rank"]) == 8 and min(line["init_s_per_rank"]) > 0
+    e2e = line["pipeline_e2e_ranks"]
+    assert e2e["global_boards"] == 2048 and e2e["fens_on_rank0"] == 2048 and e2e["precision"] == "f16x3+f16r"
+    assert e2e["order_checked_on_rank0"] == 14 and e2e["order_mismatches"] == 0
+    assert e2e["calibration_identical_across_ranks"] is True
+    assert len(e2e["gather_s_per_rank"]) == 8 and len(e2e["shard_s_per_rank"]) == 8 and max(e2e["gather_s_per_rank"]) > 0
+    mem = line["device_memory"]
+    assert 20.0 < mem["peak_used_gb_max_over_ranks"] < 288.0 and mem["device_total_gb"] > 250.0, mem
+    assert line["config"]["device_memory_peak_used_gb"] == mem["peak_used_gb_max_over_ranks"]
+    print("configs[4] on one device:", {"init_s": line["init_s"], "peak_gb": mem["peak_used_gb_max_over_ranks"], "gather_s": e2e["gather_s"],
+                                        "boards_per_sec_whole_job": e2e["boards_per_sec_whole_job"]})
