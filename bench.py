@@ -36,7 +36,7 @@ import torch  # noqa: E402  (importing torch does not initialise the GPU)
 PEAK_TFLOPS = {"f32": 157.3, "f16": 2500.0, "f16x3": 2500.0 / 3.0, "f16r": 2500.0}
 MFMA_PER_MAC = {"f32": 1, "f16": 1, "f16x3": 3, "f16r": 1}
 HBM_PEAK_GBS = 8000.0
-PMC_FILE = "profiles/r04_pmc_traffic.json"
+PMC_FILE = "profiles/r05_pmc_traffic.json"
 
 
 def log(*a):
@@ -64,19 +64,41 @@ def relaunch_under_torchrun(args, argv) -> int:
     return subprocess.run(cmd, env=env).returncode          # children inherit stdout: rank 0's JSON line is relayed as is
 
 
+def kernel_source_hash():
+    """sha256 over chessvision-3lc_amd/csrc (*.hip, *.h, *.cpp, Makefile; names included, sorted) -- the same digest
+    tools/pmc_traffic.py stores next to the counters it reduces."""
+    import hashlib
+
+    root = ROOT / "chessvision-3lc_amd" / "csrc"
+    h = hashlib.sha256()
+    for f in sorted(p for p in root.iterdir() if p.suffix in (".hip", ".h", ".cpp") or p.name == "Makefile"):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()
+
+
 def pmc_traffic(dtype, unet_chunk, resnet_chunk, unet_launches, resnet_launches):
     """Per-launch HBM bytes of the conv family from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE
     runs of the same chunk sizes, gfx950-corrected, tools/pmc_collect.sh).  Not measured by this run: the field carries its
-    source; None when no matching profile is committed."""
+    source, and it is only reported while the kernels are the ones the counters were collected on -- the profile stores the
+    sha256 of csrc/ at collection time and a different digest today gives (None, reason).  Returns (bytes per launch | None,
+    reason | None)."""
     path = ROOT / PMC_FILE
-    if not path.exists() or (unet_chunk, resnet_chunk) != (64, 16384):
-        return None
+    if not path.exists():
+        return None, f"{PMC_FILE} is not committed"
+    if (unet_chunk, resnet_chunk) != (64, 16384):
+        return None, "the committed counters are for chunks of 64 boards / 16384 squares"
     t = json.load(open(path))
     u, r = t.get(f"{dtype}_unet"), t.get(f"{dtype}_resnet18")
     if not u or not r:
-        return None
+        return None, f"no {dtype} counters in {PMC_FILE}"
+    now = kernel_source_hash()
+    for blk in (u, r):
+        if blk.get("kernel_source_sha256") != now:
+            return None, (f"stale: {PMC_FILE} was collected on kernel sources {str(blk.get('kernel_source_sha256'))[:12]}, this tree is "
+                          f"{now[:12]} -- re-run tools/pmc_collect.sh")
     total = u["hbm_bytes_per_launch"] * unet_launches + r["hbm_bytes_per_launch"] * resnet_launches
-    return total / max(1, unet_launches + resnet_launches)
+    return total / max(1, unet_launches + resnet_launches), None
 
 
 # ---- CPU baseline leg: the ONLY place bench.py touches oracle/ (as the checker and the timed CPU port) -------------------
@@ -702,8 +724,11 @@ def main():
     # effective chunk sizes from the number of passes (the f32 engine halves the classifier chunk to stay under 4 GiB per tensor)
     eff_unet = B // launches["chunks"]["unet"]
     eff_resnet = B * 64 // launches["chunks"]["resnet18"]
-    traffic = None if bilinear else pmc_traffic(args.dtype, args.unet_chunk, args.resnet_chunk, launches["unet"], launches["resnet18"])
+    traffic, traffic_why = (None, "bilinear variant: no counters committed") if bilinear else \
+        pmc_traffic(args.dtype, args.unet_chunk, args.resnet_chunk, launches["unet"], launches["resnet18"])
     roof["traffic"] = traffic
+    if traffic is None:
+        roof["traffic_null_reason"] = traffic_why
     roof["traffic_source"] = (f"{PMC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950-corrected; a committed profile "
                               "of this workload, NOT collected by this run)") if traffic is not None else None
     roof["traffic_unit"] = "HBM bytes per conv launch; algorithmic_bytes = compulsory bytes per launch (cv_profile_entry_bytes)"

@@ -6,8 +6,21 @@ usage: python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter
 """
 import collections
 import csv
+import hashlib
 import json
 import sys
+from pathlib import Path
+
+
+def kernel_source_hash():
+    """sha256 over the sources the kernels are built from (chessvision-3lc_amd/csrc: *.hip, *.h, *.cpp, Makefile), file names included,
+    sorted: bench.py recomputes it and reports `traffic: null` when the committed counters were collected on other kernels."""
+    root = Path(__file__).resolve().parent.parent / "chessvision-3lc_amd" / "csrc"
+    h = hashlib.sha256()
+    for f in sorted(p for p in root.iterdir() if p.suffix in (".hip", ".h", ".cpp") or p.name == "Makefile"):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()
 
 
 def per_dispatch(path, counter):
@@ -51,6 +64,7 @@ def main():
         allres = json.load(open(out))
     except (OSError, ValueError):
         allres = {}
+    res["kernel_source_sha256"] = kernel_source_hash()
     allres[label] = res
     json.dump(allres, open(out, "w"), indent=1)
     print(json.dumps(res))
