@@ -274,7 +274,7 @@ class ChessVision:
             st["board"].copy_(board_dev[0], non_blocking=True)
             eng.check_numerics()                                              # synchronises the stream: logits and board have landed
             board = st["board"].numpy().copy()
-            self._last_board = (board, squares_dev)                           # process_image classifies exactly this board next
+            self._last_board = (board, squares_dev, board.copy())             # process_image classifies exactly this board next (identity + content)
             return BoardExtractionResult(board_image=board, binary_mask=binary_mask, quadrangle=scaled,
                                          probabilities=st["logits"].numpy().copy())
 
@@ -285,8 +285,10 @@ class ChessVision:
         squares = self.extract_squares(board_image)
         with self._native_lock, torch.no_grad():
             last = self._last_board
-            if last is not None and last[0] is board_image:                   # the board this instance just rectified: its squares
-                squares_dev = last[1]                                         # are still on the device
+            # the board this instance just rectified AND still the same pixels (a caller may draw on the array it was handed before
+            # classifying it: the reference classifies what it is given): its squares are still on the device
+            if last is not None and last[0] is board_image and np.array_equal(last[2], board_image):
+                squares_dev = last[1]
             else:
                 st = self._staging()
                 np.copyto(st["squares"].numpy(), squares[..., 0])

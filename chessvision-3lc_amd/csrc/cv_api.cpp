@@ -544,10 +544,12 @@ static int impl_cv_engine_calibration(cv_engine_t* eng, const char* model, int32
     }
     if (!exps || capacity != n) return finish(fail(CV_ERR_INVALID, "calibration vector does not match this model (" + std::to_string(n) + " entries expected)"));
     if (e.dt == kF32) return CV_OK;                               // the f32 engine stores real values: nothing to set
+    // validate the WHOLE vector before the first write: a rejected import leaves the engine exactly as it was
+    for (int i = 0; i < n; ++i)
+        if (exps[i] < -60 || exps[i] > 60) return finish(fail(CV_ERR_INVALID, "exponent out of range (entry " + std::to_string(i) + ")"));
     bool changed = false;
     for (size_t i = 0; i < acts->size(); ++i) {
         Activation* a = (*acts)[i];
-        if (exps[2 * i] < -60 || exps[2 * i] > 60 || exps[2 * i + 1] < -60 || exps[2 * i + 1] > 60) return finish(fail(CV_ERR_INVALID, "exponent out of range"));
         if (a->fixed_exp) continue;
         if (a->exp != exps[2 * i] || (a->split_c && a->exp2 != exps[2 * i + 1])) changed = true;
         a->exp = exps[2 * i];

@@ -435,6 +435,8 @@ Status resnet_forward(Engine& e, const void* x, bool x_u8, int n, float* out, bo
     if (n <= e.resnet->cap && n <= 512) {                // one small chunk (a board's 64 squares): the launch sequence replays as a hipGraph
         Engine::GraphKey key;
         key.model = 1; key.n = n; key.flags = (x_u8 ? 1 : 0) | (softmax ? 2 : 0); key.x = x; key.out = out;
+        e.resnet->last_n = n;                            // a graph replay skips resnet_chunk's host side (see unet_forward)
+        e.ws_slot = 1;
         return e.run_graphed(key, s, [&](hipStream_t st) { return resnet_chunk(e, x, x_u8, n, out, softmax, st); });
     }
     const size_t in_stride = (size_t)64 * 64 * (x_u8 ? 1 : 4);

@@ -448,6 +448,8 @@ Status unet_forward(Engine& e, const void* x, bool x_u8, int batch, float* logit
         Engine::GraphKey key;
         key.model = 0; key.n = batch; key.flags = x_u8 ? 1 : 0; key.x = x; key.out = logits; key.mask = mask;
         std::memcpy(&key.thr_bits, &thr, sizeof(float));
+        e.unet->last_n = batch;                          // a graph replay skips unet_chunk's host side: what cv_get_activation reports
+        e.ws_slot = 0;                                   // must not depend on whether this call replayed
         return e.run_graphed(key, s, [&](hipStream_t st) { return unet_chunk(e, x, x_u8, batch, logits, mask, thr, st); });
     }
     const size_t in_stride = (size_t)3 * 256 * 256 * (x_u8 ? 1 : 4);

@@ -360,3 +360,42 @@ def test_graph_replay_of_small_forwards_is_transparent():
         assert torch.equal(out_u.cpu(), after_new_values)
     eng.check_numerics()
     eng.close()
+
+
+def test_activation_taps_report_the_batch_of_the_last_forward_also_after_a_graph_replay():
+    """a hipGraph replay skips the host side of the chunk functions, where `last_n` used to be set -- after an eager forward
+    of 2 images followed by a replayed forward of 1, the taps reported N = 2 over buffers that held 1 image."""
+    from chessvision.hip_backend import HipEngine
+
+    eng = HipEngine(precision="f16x3")
+    eng.load_unet(synth.make_unet(seed=1).state_dict())
+    eng.load_resnet18(synth.make_resnet(seed=2).state_dict())
+    one, two = synth.unet_input(seed=51, batch=1).cuda(), synth.unet_input(seed=52, batch=2).cuda()
+    s64, s128 = synth.squares_input(seed=53, n=64).cuda(), synth.squares_input(seed=54, n=128).cuda()
+    for _ in range(3):                                       # eager, capture, replay of the small shapes
+        eng.unet_forward(one); eng.resnet18_forward(s64)
+    eng.unet_forward(two); eng.resnet18_forward(s128)        # another batch in between (eager)
+    assert eng.activation("unet", "inc").shape[0] == 2 and eng.activation("resnet18", "layer4").shape[0] == 128
+    eng.unet_forward(one); eng.resnet18_forward(s64)         # replayed
+    assert eng.activation("unet", "inc").shape[0] == 1 and eng.activation("resnet18", "layer4").shape[0] == 64
+    eng.close()
+
+
+def test_rejected_calibration_import_leaves_the_engine_untouched():
+    """an out-of-range exponent at tensor i used to return an error AFTER tensors 0..i-1 were overwritten."""
+    from chessvision.hip_backend import HipBackendError, HipEngine
+
+    net = synth.make_resnet(seed=2)
+    eng = HipEngine(precision="f16x3", resnet_chunk=128)
+    eng.load_resnet18(net.state_dict())
+    x = synth.squares_input(seed=61, n=64).cuda()
+    before = eng.resnet18_forward(x).cpu()
+    cal = eng.export_calibration("resnet18")
+    bad = cal.copy()
+    bad[:-2] += 1                                            # legal changes in front ...
+    bad[-2] = 99                                             # ... of an illegal last entry
+    with pytest.raises(HipBackendError):
+        eng.import_calibration("resnet18", bad)
+    assert np.array_equal(eng.export_calibration("resnet18"), cal)
+    assert torch.equal(eng.resnet18_forward(x).cpu(), before)
+    eng.close()

@@ -219,3 +219,20 @@ def test_concurrent_request_threads_share_one_lazy_instance(tmp_path_factory):
         if w.position is not None:
             assert g.position.fen == w.position.fen
             assert np.array_equal(g.position.model_probabilities, w.position.model_probabilities)
+
+
+def test_classify_position_sees_in_place_edits_of_the_extracted_board(cv_model):
+    """`classify_position(result.board_image)` reuses the squares that are still on the device -- but only while the
+    array still holds the pixels that were rectified.  A caller that edits the board in place (masks a square, draws on it) gets the
+    edited board classified, as the reference does (it classifies the array it is handed, core.py:225-249)."""
+    img = _board_photo(3)
+    ext = cv_model.extract_board(img)
+    assert ext.board_image is not None
+    untouched = cv_model.classify_position(ext.board_image)                 # device squares reused: same pixels
+    ext2 = cv_model.extract_board(img)
+    ext2.board_image[:256, :256] = 255 - ext2.board_image[:256, :256]         # edit in place between the two calls
+    edited = cv_model.classify_position(ext2.board_image)
+    fresh = cv_model.classify_position(ext2.board_image.copy())              # a different array object: always staged from the host
+    assert np.array_equal(edited.model_probabilities, fresh.model_probabilities)
+    assert np.array_equal(edited.squares, fresh.squares)
+    assert not np.array_equal(edited.model_probabilities, untouched.model_probabilities)
