@@ -43,12 +43,29 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def visible_gpus() -> int:
+    """GPUs this process tree may use, WITHOUT bringing the HIP runtime up in the parent (it only launches children): the visibility
+    variables when set, else the KFD topology (nodes with SIMDs are GPUs); torch's count only when neither can be read."""
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([t for t in v.split(",") if t.strip() != ""])
+    try:
+        n = 0
+        for node in Path("/sys/class/kfd/kfd/topology/nodes").iterdir():
+            props = dict(line.split()[:2] for line in (node / "properties").read_text().splitlines() if len(line.split()) >= 2)
+            n += int(props.get("simd_count", "0")) > 0
+        if n:
+            return n
+    except (OSError, ValueError):
+        pass
+    return torch.cuda.device_count()
+
+
 def relaunch_under_torchrun(args, argv) -> int:
     """--gpus N > 1 without a launcher: start N ranks as a CHILD process tree (never exec: a process that has touched the GPU
     must not be replaced, and this parent has not touched it yet) and hand back its return code."""
-    # The count may bring up the HIP runtime in THIS process on ROCm (there is no NVML-style shortcut), which is harmless because
-    # the ranks are only ever started as child processes below -- never turn this into an os.exec*.
-    n_dev = torch.cuda.device_count()
+    n_dev = visible_gpus()
     share = os.environ.get("CV_DIST_BACKEND") == "gloo"      # gloo ranks may share a GPU (the N > 1 path on a one-GPU box)
     if n_dev < args.gpus and not (share and n_dev >= 1):
         log(f"bench.py: --gpus {args.gpus} but only {n_dev} device(s) visible")

@@ -430,14 +430,68 @@ def invert3(m: NDArray[np.float64]) -> NDArray[np.float64]:
                      [(d * h - e * g) * r, (b * g - a * h) * r, (a * e - b * d) * r]], dtype=np.float64)
 
 
-def warp_perspective(image: NDArray[np.uint8], m: NDArray[np.float64], size: tuple[int, int]) -> NDArray[np.uint8]:
-    """cv2.warpPerspective(image, M, size) with its defaults (INTER_LINEAR, BORDER_CONSTANT 0) in OpenCV's fixed-point form
+def warp_mode() -> str:
+    """Which reading of cv2.warpPerspective the pipeline follows: ``fixed`` (default) = the classic fixed-point ``WarpPerspectiveInvoker`` +
+    ``remapBilinear`` walk that every OpenCV release up to 4.10 runs for 8-bit images; ``float`` = the float-coordinate linear kernels that
+    joined the 4.x line around 4.11 (the reference pins opencv-python 4.11.0.86): coordinates, weights and blend in float32.  Set by
+    the environment variable CV_WARP, read by the host path here, the device kernel (csrc/pipeline.hip) and the oracle alike;
+    INTEGRATION.md section D shows how a maintainer with cv2 installed finds out which one their build matches."""
+    import os
+
+    mode = os.environ.get("CV_WARP", "fixed").strip().lower() or "fixed"
+    if mode not in ("fixed", "float"):
+        raise ValueError(f"CV_WARP must be 'fixed' or 'float', not {mode!r}")
+    return mode
+
+
+def warp_perspective_float(image: NDArray[np.uint8], m: NDArray[np.float64], size: tuple[int, int]) -> NDArray[np.uint8]:
+    """The ``float`` reading (see ``warp_mode``): the inverse of M (double, cofactor form) is rounded to float32; per destination pixel
+    w = (x*M6 + y*M7) + M8, sx = ((x*M0 + y*M1) + M2) / w, sy likewise -- every operation rounded to float32, no fused multiply-add;
+    ix = floor(sx), a = sx - ix (same for y); the four taps (BORDER_CONSTANT 0 outside the image) blend as v0 = p00 + a*(p01 - p00),
+    v1 = p10 + a*(p11 - p10), v = v0 + b*(v1 - v0) in float32; the pixel is v rounded half to even and saturated."""
+    w_out, h_out = size
+    f = np.float32
+    inv = invert3(m).astype(np.float32)
+    xs = np.arange(w_out, dtype=np.float32)[None, :]
+    ys = np.arange(h_out, dtype=np.float32)[:, None]
+    with np.errstate(all="ignore"):
+        den = (xs * inv[2, 0] + ys * inv[2, 1]).astype(f) + inv[2, 2]
+        sx = (((xs * inv[0, 0] + ys * inv[0, 1]).astype(f) + inv[0, 2]).astype(f) / den).astype(f)
+        sy = (((xs * inv[1, 0] + ys * inv[1, 1]).astype(f) + inv[1, 2]).astype(f) / den).astype(f)
+        ok = np.isfinite(sx) & np.isfinite(sy) & (np.abs(sx) < 1e9) & (np.abs(sy) < 1e9)
+        sx = np.where(ok, sx, f(-4.0)).astype(f)
+        sy = np.where(ok, sy, f(-4.0)).astype(f)
+    fx, fy = np.floor(sx), np.floor(sy)
+    a, b = (sx - fx).astype(f)[..., None], (sy - fy).astype(f)[..., None]
+    ix, iy = fx.astype(np.int64), fy.astype(np.int64)
+    img = image if image.ndim == 3 else image[:, :, None]
+    h, w, c = img.shape
+    padded = np.zeros((h + 2, w + 2, c), dtype=np.float32)
+    padded[1:-1, 1:-1] = img
+
+    def tap(yy, xx):
+        inside = (yy >= 0) & (yy < h) & (xx >= 0) & (xx < w)
+        return padded[np.clip(yy + 1, 0, h + 1), np.clip(xx + 1, 0, w + 1)] * inside[..., None].astype(f)
+
+    p00, p01, p10, p11 = tap(iy, ix), tap(iy, ix + 1), tap(iy + 1, ix), tap(iy + 1, ix + 1)
+    v0 = (p00 + (a * (p01 - p00).astype(f)).astype(f)).astype(f)
+    v1 = (p10 + (a * (p11 - p10).astype(f)).astype(f)).astype(f)
+    v = (v0 + (b * (v1 - v0).astype(f)).astype(f)).astype(f)
+    out = np.clip(np.rint(v), 0, 255).astype(np.uint8)
+    return out if image.ndim == 3 else out[:, :, 0]
+
+
+def warp_perspective(image: NDArray[np.uint8], m: NDArray[np.float64], size: tuple[int, int], mode: str | None = None) -> NDArray[np.uint8]:
+    """cv2.warpPerspective(image, M, size) with its defaults (INTER_LINEAR, BORDER_CONSTANT 0); ``mode`` (default: ``warp_mode()``) picks
+    the reading -- ``float``: ``warp_perspective_float``; ``fixed``: OpenCV's fixed-point form
     (``imgwarp.cpp``: WarpPerspectiveInvoker + remapBilinear).  The destination is walked in blocks of min(1024 / min(16, h), w)
     columns (BLOCK_SZ = 32: 64 x 16 blocks on a 512-px board; the 128 x 32 blocks belong to warpAffine); with
     ``blk`` the block's first column and ``x1`` the column inside it: X0 = M0*blk + M1*y + M2, W = W0 + M6*x1, W = 32 / W (0 if
     W == 0), X = round_half_even(clamp((X0 + M0*x1) * W)) -- source coordinates in 1/32 pixel (``INTER_BITS = 5``); the integer
     pixel X >> 5 saturates to int16; integer bilinear weights (32-a)(32-b)*32 ... a*b*32 that sum to 2^15
     (``INTER_REMAP_COEF_BITS``), pixel = (sum + 2^14) >> 15, i.e. round half UP; taps outside the image read 0."""
+    if (mode or warp_mode()) == "float":
+        return warp_perspective_float(image, m, size)
     w_out, h_out = size
     inv = invert3(m)
     bh = min(16, h_out)                                     # WarpPerspectiveInvoker: BLOCK_SZ = 32, bh0 = min(BLOCK_SZ / 2, height),

@@ -20,6 +20,7 @@
 #include <stdint.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 namespace cv {
@@ -249,6 +250,56 @@ __global__ __launch_bounds__(256) void extract_squares_u8_kernel(const uint8_t* 
     *reinterpret_cast<uint32_t*>(squares + ((size_t)img * 64 + sq) * 4096 + (size_t)(by & 63) * 64 + (bx0 & 63)) = packed;
 }
 
+// CV_WARP=float: the float-coordinate reading of cv2.warpPerspective (chessvision/classical.py: warp_mode) -- same outputs, same
+// layout; one lane per pixel of the flipped board.  Every operation is a separately rounded float32 operation (no contraction), in the
+// order the host form and the oracle use: the three agree byte for byte.
+__global__ __launch_bounds__(256) void extract_squares_u8_float_kernel(const uint8_t* __restrict__ images, int n, int h, int w,
+                                                                       const double* __restrict__ inv, uint8_t* __restrict__ squares,
+                                                                       uint8_t* __restrict__ boards) {
+#pragma clang fp contract(off)
+    constexpr int B = 512;
+    const int img = blockIdx.z;
+    const int bx = blockIdx.x * 64 + (threadIdx.x & 63), by = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const double* md = inv + (size_t)img * 9;
+    float m[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) m[i] = (float)md[i];
+    const float fx = (float)(B - 1 - bx), fy = (float)by;               // cv2.flip(board, 1) undone
+    const float den = (fx * m[6] + fy * m[7]) + m[8];
+    const float sx = ((fx * m[0] + fy * m[1]) + m[2]) / den;
+    const float sy = ((fx * m[3] + fy * m[4]) + m[5]) / den;
+    uint32_t gray = 0;
+    if (isfinite(sx) && isfinite(sy) && fabsf(sx) < 1e9f && fabsf(sy) < 1e9f) {
+        const float flx = floorf(sx), fly = floorf(sy);
+        const int ix = (int)flx, iy = (int)fly;
+        const float al = sx - flx, be = sy - fly;
+        const uint8_t* s = images + (size_t)img * h * w * 3;
+        unsigned v[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            auto tap = [&](int yy, int xx) -> float {
+                return (yy >= 0 && yy < h && xx >= 0 && xx < w) ? (float)s[((size_t)yy * w + xx) * 3 + c] : 0.f;
+            };
+            const float p00 = tap(iy, ix), p01 = tap(iy, ix + 1), p10 = tap(iy + 1, ix), p11 = tap(iy + 1, ix + 1);
+            const float top = p00 + al * (p01 - p00);
+            const float bot = p10 + al * (p11 - p10);
+            const float r = rintf(top + be * (bot - top));
+            v[c] = (unsigned)(r < 0.f ? 0.f : r > 255.f ? 255.f : r);
+        }
+        gray = (v[0] * 3735u + v[1] * 19235u + (v[2] * 9798u + (1u << 14))) >> 15;
+    } else {
+        gray = (1u << 14) >> 15;                                          // border value 0 in every channel
+    }
+    if (boards) boards[((size_t)img * B + by) * B + bx] = (uint8_t)gray;
+    const int sq = (by >> 6) * 8 + (bx >> 6);
+    squares[((size_t)img * 64 + sq) * 4096 + (size_t)(by & 63) * 64 + (bx & 63)] = (uint8_t)gray;
+}
+
+static bool warp_float_mode() {
+    static const bool on = [] { const char* v = std::getenv("CV_WARP"); return v && (v[0] == 'f' || v[0] == 'F') && (v[1] == 'l' || v[1] == 'L'); }();
+    return on;
+}
+
 // host side of the fractional shrink: OpenCV's computeResizeAreaTab for one axis (source indices in PIXELS, float weights, CSR offsets)
 void resize_area_table(int ssize, int dsize, std::vector<int>& ofs, std::vector<int>& si, std::vector<float>& alpha) {
     const double scale = (double)ssize / dsize;
@@ -297,6 +348,12 @@ hipError_t extract_squares_u8(const uint8_t* images, int n, int h, int w, const 
     // grid.z = boards: jobs of the pipeline carry <= a few hundred boards (65535 is the limit)
     for (int off = 0; off < n; off += 32768) {
         const int cnt = n - off < 32768 ? n - off : 32768;
+        if (warp_float_mode()) {
+            hipLaunchKernelGGL(extract_squares_u8_float_kernel, dim3(8, 128, (unsigned)cnt), dim3(256), 0, s,
+                               images + (size_t)off * h * w * 3, cnt, h, w, inv + (size_t)off * 9, squares + (size_t)off * 64 * 4096,
+                               boards ? boards + (size_t)off * 512 * 512 : nullptr);
+            continue;
+        }
         hipLaunchKernelGGL(extract_squares_u8_kernel, dim3(8, 32, (unsigned)cnt), dim3(256), 0, s,
                            images + (size_t)off * h * w * 3, cnt, h, w, inv + (size_t)off * 9, squares + (size_t)off * 64 * 4096,
                            boards ? boards + (size_t)off * 512 * 512 : nullptr);

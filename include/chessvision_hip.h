@@ -126,7 +126,14 @@ int cv_engine_numeric_status(cv_engine_t* eng, void* stream);
 int cv_engine_export_calibration(cv_engine_t* eng, const char* model, int32_t* exps, int capacity, int* count);
 int cv_engine_import_calibration(cv_engine_t* eng, const char* model, const int32_t* exps, int count, int* changed);
 
-/* ---- forward (the hot path) ---------------------------------------------------------------------- */
+/* ---- forward (the hot path) ----------------------------------------------------------------------
+ * Reproducibility: a forward is bit-identical run to run, across engines, processes and ranks FOR THE SAME BATCH SHAPE.  The launch
+ * plan depends on the batch (tile choice; launches too small to fill the chip split their K loop over several workgroups and sum
+ * the f32 partials in a fixed order), so the same image inside a batch of 1 and inside a batch of 64 goes through different f32
+ * summation orders: results agree to the f32 rounding of a dot product (logits within ~1e-5 for f16x3 / f32; within the storage
+ * rounding, ~5e-3, for the f16 modes), arg-max and FEN agree, bits do not.  cv_process_image (batch 1 / 64 squares) and a job of
+ * ChessVision.process_images (64 boards per pass) therefore agree to that tolerance, not bit for bit.  CV_SPLITK=0 in the
+ * environment removes the split launches (the largest source of the variation) at the cost of single-image latency. */
 /* x: (batch,3,256,256) float32 NCHW in [0,1]  ->  logits: (batch,1,256,256) float32.
  * Same tensor contract as `self.board_extractor(image_batch)` (core.py:220). */
 int cv_unet_forward(cv_engine_t* eng, const float* x, int batch, float* logits, void* stream);

@@ -327,9 +327,49 @@ def warp_perspective(image: np.ndarray, m: np.ndarray, size: tuple[int, int]) ->
     return out if image.ndim == 3 else out[:, :, 0]
 
 
-def extract_board(image: np.ndarray, quad: np.ndarray, size: tuple[int, int] = (512, 512)) -> np.ndarray:
+def warp_perspective_float(image: np.ndarray, m: np.ndarray, size: tuple[int, int], rows: range | None = None) -> np.ndarray:
+    """The OTHER reading of cv2.warpPerspective(INTER_LINEAR, BORDER_CONSTANT 0) for 8-bit images: the float-coordinate linear kernels
+    of the recent 4.x line (around 4.11, the version the reference pins) instead of the fixed-point walk.  Restated as the formula
+    they publish, one pixel at a time in numpy float32 scalars (each operation rounds to float32; no fused multiply-add): the inverse
+    matrix (double) cast to float; w = x*M6 + y*M7 + M8; sx = (x*M0 + y*M1 + M2) / w; ix = floor(sx), alpha = sx - ix; likewise y; taps
+    outside the image are 0; v = lerp(lerp(p00, p01, alpha), lerp(p10, p11, alpha), beta) with lerp(a, b, t) = a + t*(b - a); round half
+    to even.  Which of the two readings an installed cv2 follows cannot be determined here; CV_WARP selects.
+    ``rows``: compute only these destination rows (the others stay 0) -- the scalar loop takes ~15 s per 512 x 512 board."""
+    w_out, h_out = size
+    f = np.float32
+    M = [f(v) for v in _invert3(np.asarray(m, np.float64)).reshape(9)]
+    img = image if image.ndim == 3 else image[:, :, None]
+    h, w, ch = img.shape
+    out = np.zeros((h_out, w_out, ch), np.uint8)
+
+    def px(yy, xx, c):
+        return f(img[yy, xx, c]) if 0 <= yy < h and 0 <= xx < w else f(0.0)
+
+    with np.errstate(all="ignore"):
+        for y in (rows if rows is not None else range(h_out)):
+            fy_ = f(y)
+            for x in range(w_out):
+                fx_ = f(x)
+                den = f(f(fx_ * M[6]) + f(fy_ * M[7])) + M[8]
+                sx = f(f(f(fx_ * M[0]) + f(fy_ * M[1])) + M[2]) / den
+                sy = f(f(f(fx_ * M[3]) + f(fy_ * M[4])) + M[5]) / den
+                if not (np.isfinite(sx) and np.isfinite(sy)) or abs(sx) >= 1e9 or abs(sy) >= 1e9:
+                    continue                                  # maps nowhere: border value
+                ix, iy = int(np.floor(sx)), int(np.floor(sy))
+                al, be = f(sx - f(ix)), f(sy - f(iy))
+                for c in range(ch):
+                    p00, p01, p10, p11 = px(iy, ix, c), px(iy, ix + 1, c), px(iy + 1, ix, c), px(iy + 1, ix + 1, c)
+                    top = f(p00 + f(al * f(p01 - p00)))
+                    bot = f(p10 + f(al * f(p11 - p10)))
+                    v = f(top + f(be * f(bot - top)))
+                    out[y, x, c] = int(min(255.0, max(0.0, np.rint(v))))
+    return out if image.ndim == 3 else out[:, :, 0]
+
+
+def extract_board(image: np.ndarray, quad: np.ndarray, size: tuple[int, int] = (512, 512), mode: str = "fixed") -> np.ndarray:
     """``utils.extract_perspective`` of the reference (utils.py:115-132): quadrangle (TR, TL, BL, BR order as the reference's
     ``_rotate_quadrangle`` leaves it) -> destination corners ((0,0), (w,0), (w,h), (0,h)) -> warp."""
     w, h = size
     dest = np.array(((0, 0), (w, 0), (w, h), (0, h)), np.float64)
-    return warp_perspective(image, perspective_matrix(np.asarray(quad, np.float32).reshape(4, 2), dest), size)
+    warp = warp_perspective_float if mode == "float" else warp_perspective
+    return warp(image, perspective_matrix(np.asarray(quad, np.float32).reshape(4, 2), dest), size)

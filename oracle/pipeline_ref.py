@@ -60,7 +60,10 @@ def process_from_mask(resnet, image: np.ndarray, mask: np.ndarray, logits: np.nd
         ext = BoardExtractionResult(board_image=None, binary_mask=mask, quadrangle=None, probabilities=logits)
         return ChessVisionResult(board_extraction=ext, position=None, processing_time=time.time() - t0)
     scaled = np.array(quad * (h / 256.0), dtype=np.float32)                     # height only, core.py:416
-    board = cref.flip_lr(cref.bgr_to_gray(cref.extract_board(image, scaled, (512, 512))))
+    import os
+
+    warp_mode = os.environ.get("CV_WARP", "fixed").strip().lower() or "fixed"      # which reading of cv2.warpPerspective
+    board = cref.flip_lr(cref.bgr_to_gray(cref.extract_board(image, scaled, (512, 512), mode=warp_mode)))
     position = classify_board(resnet, board, flip)
     ext = BoardExtractionResult(board_image=board, binary_mask=mask, quadrangle=scaled, probabilities=logits)
     return ChessVisionResult(board_extraction=ext, position=position, processing_time=time.time() - t0)

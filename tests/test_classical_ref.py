@@ -160,3 +160,28 @@ def test_fractional_inter_area_on_random_sizes_including_near_integer_factors():
         assert np.array_equal(got, cref.resize_area(photo, (256, 256))), shape
     photo = rng.integers(0, 256, (333, 444, 3), dtype=np.uint8)
     assert np.array_equal(classical.resize_area(photo, (200, 100)), cref.resize_area(photo, (100, 200)))     # (width, height) vs (h, w)
+
+
+def test_float_reading_of_warp_perspective_host_equals_oracle():
+    """CV_WARP=float: the float-coordinate reading of cv2.warpPerspective next to the fixed-point one.  The host
+    form (vectorised numpy float32) and the oracle (scalar float32, one pixel at a time) agree byte for byte on interior, out-of-frame
+    and whole-image quadrangles; the two READINGS differ from each other (that is the point of making the choice explicit)."""
+    from chessvision import classical
+
+    rng = np.random.default_rng(21)
+    img = rng.integers(0, 256, (96, 128, 3), dtype=np.uint8)
+    dest = np.array(((0, 0), (48, 0), (48, 48), (0, 48)), np.float32)
+    quads = [np.array([[100, 15], [22, 10], [15, 82], [108, 88]], np.float32),
+             np.array([[125, 3], [5, 1], [-8, 92], [133, 100]], np.float32),              # leaves the frame: BORDER_CONSTANT taps
+             np.array([[127, 0], [0, 0], [0, 95], [127, 95]], np.float32)]                # whole image (the fallback quadrangle's shape)
+    differ = 0
+    for q in quads:
+        m = classical.get_perspective_transform(q, dest)
+        a = cref.warp_perspective_float(img, m, (48, 48))
+        b = classical.warp_perspective(img, m, (48, 48), mode="float")
+        assert np.array_equal(a, b)
+        differ += int((b != classical.warp_perspective(img, m, (48, 48), mode="fixed")).sum())
+    assert differ > 0
+    flat = np.full((40, 40, 3), 77, np.uint8)
+    m = classical.get_perspective_transform(np.array([[30, 5], [6, 4], [5, 33], [32, 35]], np.float32), dest)
+    assert np.unique(classical.warp_perspective(flat, m, (48, 48), mode="float")).tolist() == [77]

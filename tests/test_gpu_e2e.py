@@ -224,3 +224,27 @@ def test_classifier_first_under_a_mixed_precision(tmp_path):
     assert cv.board_extractor.engine.precision == "f16x3"
     with pytest.raises(ValueError):
         ChessVision(precision="f16x3+bogus")
+
+
+def test_per_image_and_batched_api_agree_to_the_summation_order_not_bit_for_bit(cv_model):
+    """`process_image` runs UNet B=1 / ResNet-18 B=64 (split-K launches, graph replay), a `process_images` job runs 64 boards
+    per pass through other tiles -- the same photo goes through different f32 summation orders.  Documented contract
+    (include/chessvision_hip.h): masks equal except where a logit sits within 1e-4 of the threshold, the same
+    quadrangle, probabilities within 1e-4, identical FEN and pawn-rule fixes; NOT bit-identical."""
+    imgs = [synthetic.board_photo(200 + i) for i in range(70)]               # one full 64-board job and a short one
+    batched = cv_model.process_images(imgs, fallback_quad=False)
+    worst = 0.0
+    for i in (0, 1, 31, 63, 64, 69):
+        single = cv_model.process_image(imgs[i])
+        b = batched[i]
+        assert (single.position is None) == (b.position is None)
+        differ = single.board_extraction.binary_mask != b.board_extraction.binary_mask
+        assert np.all(np.abs(single.board_extraction.probabilities[differ]) < 1e-4)          # logits: threshold 0.5 <-> logit 0
+        if single.position is None:
+            continue
+        assert np.array_equal(single.board_extraction.quadrangle, b.board_extraction.quadrangle)
+        assert single.position.fen == b.position.fen and single.position.original_fen == b.position.original_fen
+        assert [(f.square_name, f.corrected_piece) for f in single.position.validation_fixes] == \\
+               [(f.square_name, f.corrected_piece) for f in b.position.validation_fixes]
+        worst = max(worst, float(np.abs(single.position.model_probabilities - b.position.model_probabilities).max()))
+    assert worst <= 1e-4, worst

@@ -64,7 +64,7 @@ def test_unet_vectors(prec, tag, bilinear):
     scale = max(1.0, np.abs(d[f"{tag}_samples"]).max()) if prec == "f16" else 1.0
     assert err <= TOL[prec] * scale, err
     if prec != "f16":
-        assert np.abs(flat.double().sum(1).numpy() - d[f"{tag}_sum"]).max() <= 2.0          # checksum of 65536 logits
+        assert np.abs(flat.double().sum(1).numpy() - d[f"{tag}_sum"]).max() <= 0.25         # checksum of 65536 logits: a mean bias of 4e-6 per logit
         assert np.abs((mask.cpu() > 0).reshape(2, -1).sum(1).numpy() - d[f"{tag}_mask_count"]).max() <= 4
     eng.close()
 

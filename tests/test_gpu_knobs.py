@@ -68,3 +68,47 @@ def test_forward_passes_under_experiment_switches(knobs):
     env.update(knobs)
     out = subprocess.run([sys.executable, "-c", SCRIPT.replace("ROOT", str(ROOT))], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "KNOBS_OK" in out.stdout, (out.stdout[-500:], out.stderr[-3000:])
+
+
+WARP_SCRIPT = r"""
+import sys
+sys.path.insert(0, "ROOT"); sys.path.insert(0, "ROOT/chessvision-3lc_amd")
+import numpy as np, torch
+from chessvision import classical, utils
+from chessvision.hip_backend import HipEngine, board_homographies
+from oracle import classical_ref as cref
+
+assert classical.warp_mode() == "float"
+rng = np.random.default_rng(6)
+imgs = rng.integers(0, 256, (3, 384, 512, 3), dtype=np.uint8)
+quads = [np.array([[400, 60], [90, 40], [60, 330], [430, 350]], np.float32),
+         np.array([[500, 10], [20, 5], [-30, 370], [530, 400]], np.float32),
+         np.array([[255, 0], [0, 0], [0, 255], [255, 255]], np.float32) * np.float32(384 / 256.0)]
+eng = HipEngine(precision="f32", unet_chunk=2, resnet_chunk=128)
+inv = board_homographies(np.stack(quads), (512, 512))
+squares, boards = eng.extract_squares_u8(torch.from_numpy(imgs), inv)
+for k in range(3):
+    host = classical.flip_horizontal(classical.bgr_to_gray(utils.extract_perspective(imgs[k], quads[k], (512, 512))))
+    assert np.array_equal(boards[k].cpu().numpy(), host), k                                # device == host (float reading)
+    fixed = classical.flip_horizontal(classical.bgr_to_gray(classical.warp_perspective(
+        imgs[k], classical.get_perspective_transform(quads[k], np.array(((0, 0), (512, 0), (512, 512), (0, 512)), np.float32)), (512, 512), mode="fixed")))
+    assert not np.array_equal(host, fixed)
+rows = slice(200, 216)                                                                      # the scalar oracle on a band of each board
+for k in range(3):
+    dest = np.array(((0, 0), (512, 0), (512, 512), (0, 512)), np.float64)
+    m = cref.perspective_matrix(quads[k].reshape(4, 2), dest)
+    band = cref.warp_perspective_float(imgs[k], m, (512, 512), rows=range(rows.start, rows.stop))[rows]
+    want = cref.flip_lr(cref.bgr_to_gray(band))
+    assert np.array_equal(boards[k].cpu().numpy()[rows], want), k                           # device == independent oracle
+eng.close()
+print("WARP_FLOAT_OK")
+"""
+
+
+def test_float_reading_of_the_warp_device_equals_host_equals_oracle():
+    """CV_WARP=float in a child process (the library reads it once): the device kernel, the host form and the scalar oracle agree byte
+    for byte on interior, out-of-frame and whole-image-fallback quadrangles, and differ from the fixed-point reading."""
+    env = dict(os.environ)
+    env["CV_WARP"] = "float"
+    out = subprocess.run([sys.executable, "-c", WARP_SCRIPT.replace("ROOT", str(ROOT))], env=env, capture_output=True, text=True, timeout=1800)
+    assert out.returncode == 0 and "WARP_FLOAT_OK" in out.stdout, (out.stdout[-500:], out.stderr[-3000:])
