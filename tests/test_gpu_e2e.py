@@ -244,7 +244,7 @@ def test_per_image_and_batched_api_agree_to_the_summation_order_not_bit_for_bit(
             continue
         assert np.array_equal(single.board_extraction.quadrangle, b.board_extraction.quadrangle)
         assert single.position.fen == b.position.fen and single.position.original_fen == b.position.original_fen
-        assert [(f.square_name, f.corrected_piece) for f in single.position.validation_fixes] == \\
+        assert [(f.square_name, f.corrected_piece) for f in single.position.validation_fixes] == \
                [(f.square_name, f.corrected_piece) for f in b.position.validation_fixes]
         worst = max(worst, float(np.abs(single.position.model_probabilities - b.position.model_probabilities).max()))
     assert worst <= 1e-4, worst
