@@ -221,11 +221,13 @@ def test_concurrent_request_threads_share_one_lazy_instance(tmp_path_factory):
             assert np.array_equal(g.position.model_probabilities, w.position.model_probabilities)
 
 
-def test_classify_position_sees_in_place_edits_of_the_extracted_board(cv_model):
+def test_classify_position_sees_in_place_edits_of_the_extracted_board(tmp_path):
     """`classify_position(result.board_image)` reuses the squares that are still on the device -- but only while the
     array still holds the pixels that were rectified.  A caller that edits the board in place (masks a square, draws on it) gets the
     edited board classified, as the reference does (it classifies the array it is handed, core.py:225-249)."""
-    img = _board_photo(3)
+    pe, pc = synthetic.save_checkpoints(tmp_path, segmenting=True)            # a UNet that finds the synthetic board
+    cv_model = ChessVision(board_extractor_weights=str(pe), classifier_weights=str(pc), lazy_load=True)
+    img = synthetic.board_photo(3)
     ext = cv_model.extract_board(img)
     assert ext.board_image is not None
     untouched = cv_model.classify_position(ext.board_image)                 # device squares reused: same pixels
