@@ -43,15 +43,17 @@ namespace cv {
 #ifndef CV_HALO_TH8_SINGLE
 #define CV_HALO_TH8_SINGLE 0      // experiment (with -DCV_HALO_TH64=8): 8 x 16 patch with ONE halo buffer = 47 KB -> THREE workgroups per CU
 #endif
-constexpr int halo_waves_per_eu(int ct, int th, bool dbh) { return (CV_HALO_TH8_SINGLE && ct == 64 && th == 8 && !dbh) ? 3 : 2; }
+constexpr int halo_waves_per_eu(int ct, int th, bool dbh, int chain = 0) { return chain == 1 ? 1 : (CV_HALO_TH8_SINGLE && ct == 64 && th == 8 && !dbh) ? 3 : 2; }
 // CHAIN (single halo buffer, f16, 64 -> 64 channels, 16 x 16 maps = one patch per image): the "channel blocks" of the K loop are
 // FOUR CONVOLUTIONS in a row (ResNet-18 layer1 = two BasicBlocks).  At every block boundary the epilogue of convolution c -- BN,
 // (+ f32 residual), ReLU -- rounds to f16 and writes the result over the halo buffer IN PLACE (every wave has drained its reads of
 // it by then; the zero border stays), which is then the resident input of convolution c + 1; the weight stream simply continues.
 // The three intermediate tensors never travel to HBM as f16; the f32 trunk twin does (written after convolution 1, read back by
-// the same lanes after convolution 3): round 5, profiles/r05_tuning.md.
-template <typename T, int CT, int TH, int WGC, int NW, int TPS, int NSW, int IMG, bool PERSIST, bool DBH = true, bool FUSE0 = false, bool CHAIN = false>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(halo_waves_per_eu(CT, TH, DBH), halo_waves_per_eu(CT, TH, DBH)))) void conv3x3_halo_kernel(const ConvParams p) {
+// the same lanes after convolution 3): round 5, profiles/r05_tuning.md.  CHAIN = 2: that form, two workgroups per CU.  CHAIN = 1: ONE
+// workgroup per CU with 512 registers per lane -- the f32 residual of the whole tile (64 registers) is fetched at kernel start and stays in
+// registers through both blocks, so the first block's output never leaves the chip and no epilogue waits for a load.
+template <typename T, int CT, int TH, int WGC, int NW, int TPS, int NSW, int IMG, bool PERSIST, bool DBH = true, bool FUSE0 = false, int CHAIN = 0>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(halo_waves_per_eu(CT, TH, DBH, CHAIN), halo_waves_per_eu(CT, TH, DBH, CHAIN)))) void conv3x3_halo_kernel(const ConvParams p) {
     static_assert(!FUSE0 || (!DBH && !PERSIST && IMG == 0 && CT == 64 && NW == 4 && __is_same(T, split_t)), "fused producer: split-f16 64-channel single-halo tile");
     static_assert(!CHAIN || (!DBH && !PERSIST && !FUSE0 && IMG == 0 && CT == 64 && TH == 16 && NW == 4 && __is_same(T, half_t)), "chained convolutions: f16 64-channel single-halo tile over whole 16 x 16 images");
     static_assert(TPS == 1 && (NSW == 3 || NSW == 4), "stage shape");
@@ -430,7 +432,18 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(halo_wa
     // ---- CHAIN: epilogue of convolution c, straight from the accumulator layout -------------------------------------
     // lane (q, l15) holds channels 16 q .. 16 q + 15 of the pixels (patch row wrow0 + g, column l15), g = 0 .. FP-1: 64 contiguous
     // bytes of an f32 plane / 32 of an f16 plane / two 16-byte chunks of the pixel's halo row per g.
-    constexpr int kChainStores = CHAIN ? 4 * FP : 0;            // f32 stores of convolution 1's epilogue (vmcnt bookkeeping)
+    constexpr int kChainStores = CHAIN == 2 ? 4 * FP : 0;       // f32 stores of convolution 1's epilogue (vmcnt bookkeeping)
+    f4 rtrunk[CHAIN == 1 ? FP : 1][4];                          // CHAIN 1: the f32 trunk of this lane's outputs (input twin, then block 0's output)
+    auto chain_load_trunk = [&]() __attribute__((always_inline)) {
+        if constexpr (CHAIN == 1) {
+            const float* const rb = reinterpret_cast<const float*>(p.ch_res0) + q * 16;
+            const unsigned pix0 = (unsigned)((n * p.yHp + wrow0 + 1) * p.yWp + l15 + 1);
+#pragma unroll
+            for (int g = 0; g < FP; ++g)
+#pragma unroll
+                for (int f = 0; f < 4; ++f) rtrunk[g][f] = *reinterpret_cast<const f4*>(rb + (size_t)(pix0 + (unsigned)(g * p.yWp)) * 64 + f * 4);
+        }
+    };
     auto chain_epilogue = [&](int c) __attribute__((always_inline)) {
         if constexpr (CHAIN) {
             const bool has_res = (c & 1) != 0, last = c == 3;   // wave-uniform
@@ -454,7 +467,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(halo_wa
 #pragma unroll
                 for (int f = 0; f < 4; ++f) r[g & 1][f] = *reinterpret_cast<const f4*>(rb + (size_t)(pix0 + (unsigned)(g * p.yWp)) * 64 + f * 4);
             };
-            if (has_res) fetch_res(0);
+            if (CHAIN == 2 && has_res) fetch_res(0);
             const float rm = p.ch_res_mul[c >> 1];
             float* const o32 = reinterpret_cast<float*>(last ? p.y32 : p.ch_y32_mid) + q * 16;
             half_t* const o16 = reinterpret_cast<half_t*>(p.y) + q * 16;
@@ -462,15 +475,22 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(halo_wa
             float bad = 0.f;
 #pragma unroll
             for (int g = 0; g < FP; ++g) {
-                if (has_res && g + 1 < FP) fetch_res(g + 1);
+                if (CHAIN == 2 && has_res && g + 1 < FP) fetch_res(g + 1);
                 float v[16];
 #pragma unroll
                 for (int f = 0; f < 4; ++f)
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         float t = acc[f][g][k] * sc[f * 4 + k] + sh[f * 4 + k];
-                        if (has_res) t = __builtin_fmaf(r[g & 1][f][k], rm, t);
+                        if constexpr (CHAIN == 2) {
+                            if (has_res) t = __builtin_fmaf(r[g & 1][f][k], rm, t);
+                        } else {
+                            if (has_res) t = __builtin_fmaf(rtrunk[g][f][k], rm, t);
+                        }
                         v[f * 4 + k] = __builtin_fmaxf(t, 0.f);
+                        if constexpr (CHAIN == 1) {
+                            if (has_res) rtrunk[g][f][k] = v[f * 4 + k];   // block 0's output (stored units of ITS exponent) is block 1's residual
+                        }
                     }
                 half8 h0, h1;
 #pragma unroll
@@ -479,7 +499,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(halo_wa
                     bad = __builtin_fmaf((float)h0[j], 0.f, bad); bad = __builtin_fmaf((float)h1[j], 0.f, bad);
                 }
                 const size_t pix = (size_t)(pix0 + (unsigned)(g * p.yWp));
-                if (has_res) {
+                if (has_res && (CHAIN == 2 || last)) {
 #pragma unroll
                     for (int f = 0; f < 4; ++f) *reinterpret_cast<f4*>(o32 + pix * 64 + f * 4) = f4{v[f * 4], v[f * 4 + 1], v[f * 4 + 2], v[f * 4 + 3]};
                 }
@@ -549,7 +569,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(halo_wa
         const bool halo_young = !kRoles && !FUSE0 && !CHAIN && more_cb && (DBH ? (J >= 1 && J <= NSW - 1) : J == 8);
         // CHAIN: the sixteen f32 stores of convolution 1's epilogue are younger than the weight stage issued in its tap 8 and older than
         // the one issued in tap 0 of convolution 2: the first two barriers of convolution 2 may leave them in flight as well
-        const bool chain_young = CHAIN && J <= 1 && cb == 2;
+        const bool chain_young = CHAIN == 2 && J <= 1 && cb == 2;
 #if CV_STAMP
         const unsigned long long st_a = __builtin_amdgcn_s_memtime();
 #endif
@@ -647,6 +667,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(halo_wa
     unsigned tile = lid;
     decode(tile);
     issue_prologue();
+    chain_load_trunk();                                  // CHAIN 1: behind the halo / weight DMAs (the compiler waits for it where it is first used)
     if constexpr (FUSE0) {                               // the first weight stages fly while the first halo is produced
         load_patch0();
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -1075,7 +1096,9 @@ hipError_t conv_halo_prepare() {
     CV_FOR_EACH_HALO(X, split_t)
 #undef X
 #if CV_HALO_TH64 == 16 && CV_HALO_NSW64 == 3
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<half_t, 64, 16, 1, 4, 1, 3, 0, false, false, false, true>),
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<half_t, 64, 16, 1, 4, 1, 3, 0, false, false, false, 1>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<half_t, 64, 16, 1, 4, 1, 3, 0, false, false, false, 2>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
 #endif
     return hipSuccess;
@@ -1101,9 +1124,14 @@ bool conv_halo_has_chain() { return CV_HALO_TH64 == 16 && CV_HALO_NSW64 == 3; }
 hipError_t conv_halo_chain_launch(const ConvParams& p, int n_images, hipStream_t stream) {
 #if CV_HALO_TH64 == 16 && CV_HALO_NSW64 == 3
     if (!p.chain || p.nStages != 36 || p.Ho != 16 || p.Wo != 16 || p.yCs != 64 || p.xCs != 64 || p.ksplit > 1 || n_images < 1) return hipErrorInvalidValue;
-    auto kern = conv3x3_halo_kernel<half_t, 64, 16, 1, 4, 1, 3, 0, false, false, false, true>;
     const size_t lds = halo_lds<64, 16, 4, 1, 3, 0>();
-    hipLaunchKernelGGL(kern, dim3((unsigned)n_images), dim3(256), lds, stream, p);
+    if (p.chain == 1) {                                  // one workgroup per CU (its 512 registers per lane see to that)
+        auto kern = conv3x3_halo_kernel<half_t, 64, 16, 1, 4, 1, 3, 0, false, false, false, 1>;
+        hipLaunchKernelGGL(kern, dim3((unsigned)n_images), dim3(256), lds, stream, p);
+    } else {
+        auto kern = conv3x3_halo_kernel<half_t, 64, 16, 1, 4, 1, 3, 0, false, false, false, 2>;
+        hipLaunchKernelGGL(kern, dim3((unsigned)n_images), dim3(256), lds, stream, p);
+    }
     return hipGetLastError();
 #else
     return hipErrorInvalidValue;

@@ -136,7 +136,8 @@ struct ConvParams {
     // f16 copy of the trunk entering the stage.  Convolution c = 0, 2: relu(bn(conv)) stays in LDS as f16.  c = 1: + ch_res0
     // (f32 twin of the input) * ch_res_mul[0], ReLU -> f32 to ch_y32_mid (the first block's output twin) and f16 into LDS.
     // c = 3: + ch_y32_mid * ch_res_mul[1], ReLU -> y32 (f32 twin) and y (f16 copy).  All tensors 18 x 18 x 64 padded planes.
-    int chain;                // 0 = off
+    int chain;                // 0 = off | 2 = the form described above, two workgroups per CU | 1 = one workgroup per CU, 512 registers: the
+                              // f32 trunk stays in registers through both blocks (ch_y32_mid is not touched)
     const float* ch_scale[4]; // per-convolution epilogue constants (range factors folded, as `scale` / `shift`)
     const float* ch_shift[4];
     const char* ch_res0;

@@ -26,6 +26,14 @@ static Status resnet_reserve(Engine& e, int n);
 static Status layer1_chain(Engine& e, int n, hipStream_t s);
 static Status resnet_chunk(Engine& e, const void* x, bool x_u8, int n, float* out, bool softmax, hipStream_t s);
 
+// form of the chained layer1 launch (f16r): 2 (default) = two workgroups per CU, block 0's f32 output written and read back; 1 = one
+// workgroup per CU with 512 registers, the f32 trunk stays in registers -- no round trip, but nothing covers the workgroup's barriers,
+// prologue and epilogues: 1.81 against 1.62 ms per 16384 squares (CV_CHAIN_WG=1; r05_tuning.md step 6)
+static int chain_form() {
+    static const int form = [] { const char* v = std::getenv("CV_CHAIN_WG"); return v && v[0] == '1' ? 1 : 2; }();
+    return form;
+}
+
 static void bn_keys(std::vector<std::string>& out, const std::string& p) {
     for (const char* leaf : {".weight", ".bias", ".running_mean", ".running_var"}) out.push_back(p + leaf);
 }
@@ -274,7 +282,9 @@ static Status resnet_reserve(Engine& e, int n) {
             // no tap for the former, the latter is read from its f32 twin
             const bool chained = R.chain_ok && l == 0;
             if (!chained) R.taps[p + ".act1"] = B.mid.ref(S);
-            R.taps[p] = (chained && bi == 0) ? B.out.ref32(S) : B.out.ref(S);
+            if (chained && bi == 0) {                        // block 0's output: its f32 twin (form 2) or nowhere outside the kernel (form 1)
+                if (chain_form() == 2) R.taps[p] = B.out.ref32(S);
+            } else R.taps[p] = B.out.ref(S);
             if (B.has_down) R.taps[p + ".downsample"] = B.sc.only32 ? B.sc.ref32(S) : B.sc.ref(S);
         }
         R.taps["layer" + std::to_string(l + 1)] = R.blocks[l * 2 + 1].out.ref(S);
@@ -405,7 +415,7 @@ static Status layer1_chain(Engine& e, int n, hipStream_t s) {
     p.Cout = 64; p.rows = 64; p.nStages = 36; p.nCt = 1; p.relu = 1;
     p.flag = e.guard_ptr();
     p.layer_id = B1.conv2.layer_id;
-    p.chain = 4;
+    p.chain = chain_form();
     for (int i = 0; i < 4; ++i) {
         p.ch_scale[i] = reinterpret_cast<const float*>(L[i]->scale.ptr);
         p.ch_shift[i] = reinterpret_cast<const float*>(L[i]->shift.ptr);

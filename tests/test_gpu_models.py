@@ -116,6 +116,8 @@ def test_resnet18_forward_matches_oracle(prec):
     for name in RESNET_TAPS:
         if name == "act1" and prec != "f32":
             continue                    # f16 / f16x3 engines fuse stem + max-pool: the 32x32 stem output never exists
+        if name == "layer1.0" and prec == "f16r":
+            continue                    # f16r runs layer1 as one chained launch: block 0's output stays in registers / LDS
         a = torch.from_numpy(eng.activation("resnet18", name))
         r = got_ref[name][128:200]
         layer_err[name] = [float((a - r).abs().max()), float(r.abs().max())]
