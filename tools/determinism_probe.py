@@ -14,7 +14,7 @@ net = synth.make_resnet(seed=2)
 eng = HipEngine(precision=prec, resnet_chunk=chunk)
 eng.load_resnet18(net.state_dict())
 x = synth.squares_input(seed=4, n=n).cuda()
-NAMES = ("layer3", "layer4.0.downsample", "layer4.0.act1", "layer4.0", "layer4.1.act1", "layer4")
+NAMES = ("maxpool", "layer1", "layer2.0.downsample", "layer2", "layer3", "layer4.0.downsample", "layer4")
 outs, taps = [], []
 for _ in range(4):
     outs.append(eng.resnet18_forward(x).cpu())
