@@ -166,3 +166,36 @@ def test_enlarging_inter_area_host_equals_oracle():
     ramp = np.repeat(np.arange(128, dtype=np.uint8)[None, :, None], 128, axis=0).repeat(3, axis=2)
     up = classical.resize_area(ramp, (256, 256))
     assert np.all(np.diff(up[0, :, 0].astype(int)) >= 0) and up[0, 0, 0] == 0 and up[0, -1, 0] == 127
+
+
+def test_degenerate_contours_and_capacity_errors(hb):
+    """Isolated pixels, one-pixel lines, a two-pixel blob, a full frame, an empty mask: the three implementations agree on every
+    contour list; `cv_find_contours` reports a too-small output buffer as an error instead of writing past it."""
+    import ctypes
+
+    cases = []
+    m = np.zeros((12, 12), np.uint8); m[3, 4] = 1; m[8, 8] = 255; cases.append(m)                 # two isolated pixels
+    m = np.zeros((12, 12), np.uint8); m[5, 2:9] = 1; cases.append(m)                               # horizontal line
+    m = np.zeros((12, 12), np.uint8); m[2:10, 6] = 1; cases.append(m)                              # vertical line
+    m = np.zeros((12, 12), np.uint8); m[np.arange(2, 9), np.arange(3, 10)] = 1; cases.append(m)   # diagonal (8-connected)
+    m = np.zeros((12, 12), np.uint8); m[4, 4] = m[4, 5] = 1; cases.append(m)                       # two pixels
+    cases.append(np.full((9, 13), 255, np.uint8))                                                  # everything set: the border is the frame
+    cases.append(np.zeros((7, 7), np.uint8))                                                       # nothing
+    m = np.full((16, 16), 255, np.uint8); m[1:15, 1:15] = 0; m[4:12, 4:12] = 255; m[6:10, 6:10] = 0; cases.append(m)   # frame > hole > island > hole
+    for k, m in enumerate(cases):
+        for method in (oc.NONE, oc.TC89_KCOS):
+            a, ha = oc.find_contours(m, method)
+            b, hbf = hb.find_contours(m, bool(method))
+            c, hc = classical.find_contours(m, bool(method), True)
+            assert ha == hbf == hc and _same_lists(a, b) and _same_lists(a, c), (k, method)
+        assert _same_quad(oc.find_quadrangle(m), hb.find_quadrangle(m)) and _same_quad(oc.find_quadrangle(m), ChessVision._find_quadrangle(m)), k
+    lib = hb.load_library()
+    m = cases[-1]
+    xy = np.zeros((4, 2), np.int32); counts = np.zeros(8, np.int32); holes = np.zeros(8, np.int32); n = ctypes.c_int64(0)
+    i32p = ctypes.POINTER(ctypes.c_int32)
+    rc = lib.cv_find_contours(m.ctypes.data_as(ctypes.c_void_p), 16, 16, 0, xy.ctypes.data_as(i32p), 4, counts.ctypes.data_as(i32p),
+                              holes.ctypes.data_as(i32p), 8, ctypes.byref(n))
+    assert rc != 0 and b"capacity" in lib.cv_last_error()
+    rc = lib.cv_find_contours(m.ctypes.data_as(ctypes.c_void_p), 16, 16, 7, xy.ctypes.data_as(i32p), 4, counts.ctypes.data_as(i32p),
+                              holes.ctypes.data_as(i32p), 8, ctypes.byref(n))
+    assert rc != 0                                                                                  # unknown approximation method
