@@ -33,7 +33,7 @@ def main():
         ref = net(x)
     out = eng.resnet18_forward(x.cuda()).cpu()
     p_err = float((torch.softmax(ref, 1) - torch.softmax(out, 1)).abs().max())
-    print(f"chain={os.environ.get('CV_RESNET_CHAIN', '1')} form={os.environ.get('CV_CHAIN_WG', '1')} prec={args.prec}: logits err {float((out - ref).abs().max()):.3e} (max {float(ref.abs().max()):.2f}) "
+    print(f"chain={os.environ.get('CV_RESNET_CHAIN', '1')} form={os.environ.get('CV_CHAIN_WG', '2')} prec={args.prec}: logits err {float((out - ref).abs().max()):.3e} (max {float(ref.abs().max()):.2f}) "
           f"softmax err {p_err:.3e} argmax agree {float((ref.argmax(1) == out.argmax(1)).float().mean()):.4f}")
     for name in ("layer1.0", "layer1", "layer2"):
         try:
