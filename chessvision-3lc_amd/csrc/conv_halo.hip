@@ -444,8 +444,111 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(halo_wa
                 for (int f = 0; f < 4; ++f) rtrunk[g][f] = *reinterpret_cast<const f4*>(rb + (size_t)(pix0 + (unsigned)(g * p.yWp)) * 64 + f * 4);
         }
     };
+    // CHAIN 2, convolution 1 (block 0's output): the residual epilogue in the UNIT layout of the kernel's ordinary epilogue -- the
+    // accumulators are staged through LDS (the halo buffer is dead here and is the staging area; the weight ring stays live) and read
+    // back so that a lane holds 8 consecutive channels of a pixel and 8 consecutive lanes one pixel: the f32 residual arrives in one
+    // burst of full lines, the f32 output leaves in full lines, and a unit's f16 values are exactly one 16-byte chunk of the pixel's
+    // halo row, written once every wave has finished with the staging area.  (Straight from the accumulator layout the same traffic was
+    // 64 requests of 16 bytes per wave instruction: r05_tuning.md step 2.)
+#ifndef CV_CHAIN_MIDSTAGE_BUILD
+#define CV_CHAIN_MIDSTAGE_BUILD 0      // 1: also build the staged form of convolution 1's epilogue (CV_CHAIN_MIDSTAGE=1 selects it).  Measured (r05_tuning.md step 8): its mere presence costs the kernel 35 spilled loop invariants and 10 %; enabled it wins half of that back
+#endif
+    auto chain_epilogue_res_mid = [&]() __attribute__((always_inline)) {
+        if constexpr (CHAIN == 2 && CV_CHAIN_MIDSTAGE_BUILD) {
+            constexpr int UN = 8, UPP = 64 / UN, UPL = 16 * UPP / 64, SROW = 272, RG = 2;
+            static_assert(NW * RG * 16 * SROW <= HBYTES && FP % RG == 0, "staging fits in the halo buffer");
+            float sc[16], sh[16];
+#pragma unroll
+            for (int i = 0; i < 16; i += 4) {
+                const f4 a = *reinterpret_cast<const f4*>(p.ch_scale[1] + q * 16 + i);
+                const f4 b = *reinterpret_cast<const f4*>(p.ch_shift[1] + q * 16 + i);
+                sc[i] = a[0]; sc[i + 1] = a[1]; sc[i + 2] = a[2]; sc[i + 3] = a[3];
+                sh[i] = b[0]; sh[i + 1] = b[1]; sh[i + 2] = b[2]; sh[i + 3] = b[3];
+            }
+            const float* const rb = reinterpret_cast<const float*>(p.ch_res0);
+            float* const ob32 = reinterpret_cast<float*>(p.ch_y32_mid);
+            const float rm = p.ch_res_mul[0];
+            // padded-plane pixel of (patch row wrow0 + g, column px) of image n
+            auto pixel = [&](int g, int px) __attribute__((always_inline)) { return (unsigned)((n * p.yHp + wrow0 + g + 1) * p.yWp + px + 1); };
+            // the residual of one row pair at a time (the whole tile's 64 registers spill here): the second pair's burst is issued before
+            // the first pair is worked on
+            f4 rraw[2][RG][UPL][2];
+            auto fetch_pair = [&](int g0, int slot) __attribute__((always_inline)) {
+#pragma unroll
+                for (int r = 0; r < RG; ++r)
+#pragma unroll
+                    for (int i = 0; i < UPL; ++i) {
+                        const int unit = lane + 64 * i, px = unit / UPP, co = (unit % UPP) * UN;
+                        trunk32_fetch(rb + ((size_t)pixel(g0 + r, px) * 64 + co), rraw[slot][r][i]);
+                    }
+            };
+            fetch_pair(0, 0);
+            char* const stg = halo + wave * (RG * 16 * SROW);
+            half8 hold[FP][UPL];
+            float bad = 0.f;
+#pragma unroll
+            for (int g0 = 0; g0 < FP; g0 += RG) {
+                if (g0 + RG < FP) fetch_pair(g0 + RG, ((g0 / RG) + 1) & 1);
+#pragma unroll
+                for (int r = 0; r < RG; ++r)
+#pragma unroll
+                    for (int f = 0; f < FC; ++f) {
+                        f4 t;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) t[k] = acc[f][g0 + r][k] * sc[f * 4 + k] + sh[f * 4 + k];
+                        *reinterpret_cast<f4*>(stg + r * (16 * SROW) + l15 * SROW + (q * 16 + f * 4) * 4) = t;
+                    }
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int i = 0; i < UPL; ++i) {
+                    const int unit = lane + 64 * i, px = unit / UPP, cu = unit % UPP;
+#pragma unroll
+                    for (int r = 0; r < RG; ++r) {
+                        float w[UN];
+#pragma unroll
+                        for (int j = 0; j < UN; j += 4) {
+                            const f4 t = *reinterpret_cast<const f4*>(stg + r * (16 * SROW) + px * SROW + (cu * UN + j) * 4);
+                            w[j] = t[0]; w[j + 1] = t[1]; w[j + 2] = t[2]; w[j + 3] = t[3];
+                        }
+                        trunk32_add_raw(rraw[(g0 / RG) & 1][r][i], w, rm);
+#pragma unroll
+                        for (int j = 0; j < UN; ++j) w[j] = __builtin_fmaxf(w[j], 0.f);
+                        trunk32_store(ob32 + ((size_t)pixel(g0 + r, px) * 64 + cu * UN), w);
+                        half8 h;
+#pragma unroll
+                        for (int j = 0; j < UN; ++j) { h[j] = (half_t)w[j]; bad = __builtin_fmaf((float)h[j], 0.f, bad); }
+                        hold[g0 + r][i] = h;
+                    }
+                }
+                asm volatile("" ::: "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave has read its staged rows back: the buffer becomes the halo again
+#pragma unroll
+            for (int g = 0; g < FP; ++g)
+#pragma unroll
+                for (int i = 0; i < UPL; ++i) {
+                    const int unit = lane + 64 * i, px = unit / UPP, cu = unit % UPP, hx = px + 1;
+                    *reinterpret_cast<half8*>(halo + ((wrow0 + g + 1) * 18 + hx) * 128 + ((cu ^ (hx & 7)) << 4)) = hold[g][i];
+                }
+            // the staging area covered halo rows 0 .. 271, border pixels included: the zero border (= the next convolution's padding) is
+            // restored -- 68 border pixels x 8 chunks of 16 bytes
+            typedef unsigned u4z __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int idx = tid + 256 * k, bp = idx >> 3, ch = idx & 7;
+                if (bp < 68) {
+                    const int j = bp - 36;
+                    const int hy = bp < 18 ? 0 : bp < 36 ? 17 : 1 + (j >> 1);
+                    const int hxz = bp < 18 ? bp : bp < 36 ? bp - 18 : ((j & 1) ? 17 : 0);
+                    *reinterpret_cast<u4z*>(halo + (hy * 18 + hxz) * 128 + ch * 16) = u4z{0u, 0u, 0u, 0u};
+                }
+            }
+            if (bad != bad && p.flag) atomicMin(p.flag, p.ch_layer_id[1]);
+        }
+    };
     auto chain_epilogue = [&](int c) __attribute__((always_inline)) {
         if constexpr (CHAIN) {
+            if (CHAIN == 2 && CV_CHAIN_MIDSTAGE_BUILD && c == 1 && (p.chain & 16)) { chain_epilogue_res_mid(); return; }
             const bool has_res = (c & 1) != 0, last = c == 3;   // wave-uniform
             const float* const scp = p.ch_scale[c] + q * 16;
             const float* const shp = p.ch_shift[c] + q * 16;
@@ -603,7 +706,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(halo_wa
 #endif
 #if CV_ABLATE != 3
         wslot = next_slot(wslot);                         // now the slot of stage s + 1
-        load_a(nxt, std::integral_constant<int, (J + 1) % 3>{}, wslot);
+        // CHAIN 2, tap 8 of convolution 1: its epilogue needs these registers for the residual burst -- the weight fragments are read after it
+        const bool late_a = CHAIN == 2 && CV_CHAIN_MIDSTAGE_BUILD && J == 8 && cb == 1 && (p.chain & 16);
+        if (!late_a) load_a(nxt, std::integral_constant<int, (J + 1) % 3>{}, wslot);
 #endif
 #if CV_STAMP
         const unsigned long long st_c = __builtin_amdgcn_s_memtime();
@@ -639,6 +744,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(halo_wa
 #pragma unroll
                         for (int g = 0; g < FP; ++g) acc[f][g] = f4{0.f, 0.f, 0.f, 0.f};
                     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    if (late_a) load_a(nxt, std::integral_constant<int, (J + 1) % 3>{}, wslot);
                 } else {
                     // everybody's pieces of the next halo have landed (only the weight stage issued after them may still fly)
                     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LW) : "memory");
@@ -703,10 +809,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(halo_wa
         o[4] = st_head; o[5] = st_t0 - st_k0; o[6] = st_tail;
     }
 #endif
-    if constexpr (CHAIN) {                               // convolution 3: + the first block's f32 output, ReLU -> f32 twin and f16 copy
+    if constexpr (CHAIN == 1) {                          // convolution 3 from the trunk registers: + block 0's output, ReLU -> f32 twin and f16 copy
         chain_epilogue(3);
         return;
     }
+    // CHAIN == 2: convolution 3 leaves through the ordinary epilogue below -- the ring and the halo are dead now, so its LDS-staged
+    // full-line stores and its residual burst apply; the host points scale / shift / res / res_mul at convolution 3's constants and at
+    // block 0's f32 output (written by this workgroup's convolution-1 epilogue, complete long ago: 18 stages of counted waits lie between)
     // the epilogue works on the tile just finished; the DMA side moves on to the next one
     const int eCt = ctTile, eTx = tx, eTy = ty, eN = n;
     const unsigned nxt_tile = tile + nwg;
@@ -1125,7 +1234,7 @@ hipError_t conv_halo_chain_launch(const ConvParams& p, int n_images, hipStream_t
 #if CV_HALO_TH64 == 16 && CV_HALO_NSW64 == 3
     if (!p.chain || p.nStages != 36 || p.Ho != 16 || p.Wo != 16 || p.yCs != 64 || p.xCs != 64 || p.ksplit > 1 || n_images < 1) return hipErrorInvalidValue;
     const size_t lds = halo_lds<64, 16, 4, 1, 3, 0>();
-    if (p.chain == 1) {                                  // one workgroup per CU (its 512 registers per lane see to that)
+    if ((p.chain & 3) == 1) {                            // one workgroup per CU (its 512 registers per lane see to that)
         auto kern = conv3x3_halo_kernel<half_t, 64, 16, 1, 4, 1, 3, 0, false, false, false, 1>;
         hipLaunchKernelGGL(kern, dim3((unsigned)n_images), dim3(256), lds, stream, p);
     } else {

@@ -415,7 +415,9 @@ static Status layer1_chain(Engine& e, int n, hipStream_t s) {
     p.Cout = 64; p.rows = 64; p.nStages = 36; p.nCt = 1; p.relu = 1;
     p.flag = e.guard_ptr();
     p.layer_id = B1.conv2.layer_id;
-    p.chain = chain_form();
+    // bit 4: convolution 1's residual epilogue staged through the (dead) halo buffer in the unit layout (CV_CHAIN_MIDSTAGE; two-workgroup form)
+    static const int mid_staged = [] { const char* v = std::getenv("CV_CHAIN_MIDSTAGE"); return v && v[0] == '1' ? 16 : 0; }();
+    p.chain = chain_form() | (chain_form() == 2 ? mid_staged : 0);
     for (int i = 0; i < 4; ++i) {
         p.ch_scale[i] = reinterpret_cast<const float*>(L[i]->scale.ptr);
         p.ch_shift[i] = reinterpret_cast<const float*>(L[i]->shift.ptr);
@@ -425,6 +427,9 @@ static Status layer1_chain(Engine& e, int n, hipStream_t s) {
     p.ch_y32_mid = reinterpret_cast<char*>(y0.base32);
     p.ch_res_mul[0] = std::ldexp(1.f, x.exp - B0.out.exp);
     p.ch_res_mul[1] = std::ldexp(1.f, B0.out.exp - B1.out.exp);
+    // the last convolution's epilogue is the kernel's ordinary one (two-workgroup form): its constants in the ordinary fields
+    p.scale = p.ch_scale[3]; p.shift = p.ch_shift[3];
+    p.res = reinterpret_cast<const char*>(y0.base32); p.res_f32 = 1; p.res_mul = p.ch_res_mul[1]; p.rCs = 64; p.rCoff = 0;
     if (e.profiling) {
         // compulsory bytes: f16 input + its f32 twin, the first block's f32 output written and read back, f32 + f16 output, weights
         const double px = (double)n * 256 * 64;
