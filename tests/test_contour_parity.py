@@ -199,3 +199,24 @@ def test_degenerate_contours_and_capacity_errors(hb):
     rc = lib.cv_find_contours(m.ctypes.data_as(ctypes.c_void_p), 16, 16, 7, xy.ctypes.data_as(i32p), 4, counts.ctypes.data_as(i32p),
                               holes.ctypes.data_as(i32p), 8, ctypes.byref(n))
     assert rc != 0                                                                                  # unknown approximation method
+
+
+def test_random_small_masks_all_three_agree(hb):
+    """600 random masks of 5 x 5 to 40 x 40 at densities 0.1 .. 0.9 (every local border configuration: thin lines, diagonal touches,
+    pixels that belong to an outer border and a hole border at once, nested holes): C++ == oracle on all of them, numpy host form ==
+    oracle on every fifth, contour lists in both approximation modes and quadrangles."""
+    rng = np.random.default_rng(77)
+    n_contours = 0
+    for t in range(600):
+        h, w = int(rng.integers(5, 41)), int(rng.integers(5, 41))
+        mask = ((rng.random((h, w)) < rng.uniform(0.1, 0.9)) * 255).astype(np.uint8)
+        for method in (oc.NONE, oc.TC89_KCOS):
+            a, ha = oc.find_contours(mask, method)
+            b, hb_ = hb.find_contours(mask, bool(method))
+            assert ha == hb_ and _same_lists(a, b), (t, h, w, method)
+            if t % 5 == 0:
+                c, hc = classical.find_contours(mask, bool(method), True)
+                assert ha == hc and _same_lists(a, c), (t, h, w, method, "numpy")
+        n_contours += len(a)
+        assert _same_quad(oc.find_quadrangle(mask), hb.find_quadrangle(mask)), (t, h, w)
+    assert n_contours > 5000
