@@ -1,5 +1,5 @@
 """A/B of the chained ResNet-18 layer1 launch (f16r engine; developer tool): parity of both builds of the schedule against the oracle
-on the same squares, per-layer profile, timing.  usage: python tools/chain_ab.py [--squares 16384]
+on the same squares, per-layer profile, timing.  usage: python tests/dev/chain_ab.py [--squares 16384]
 Run once with CV_RESNET_CHAIN=0 and once without (the knob is read once per process)."""
 from __future__ import annotations
 
@@ -9,7 +9,7 @@ import sys
 import time
 from pathlib import Path
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "chessvision-3lc_amd"))
 

@@ -1,7 +1,7 @@
 """Repeat one ResNet-18 forward and report how many outputs differ between repeats (developer tool)."""
 import os, sys
 from pathlib import Path
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "chessvision-3lc_amd"))
 import torch
 from chessvision.hip_backend import HipEngine

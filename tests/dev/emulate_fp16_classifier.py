@@ -1,6 +1,6 @@
 """(test infrastructure, not collected by pytest) CPU emulation of the classifier's fp16 arithmetic, one rounding source at a time.
 
-    python tools/emulate_fp16_classifier.py [squares=4096] [he|stress] [input seed=42]
+    python tests/dev/emulate_fp16_classifier.py [squares=4096] [he|stress] [input seed=42]
 
 An f16 MFMA with f32 accumulation is emulated exactly (up to summation order) by rounding both operands to f16 and convolving in
 fp32 on the CPU.  The script runs the oracle's ResNet-18 with selectable rounding of (i) convolution inputs, (ii) weights, (iii) the
@@ -16,7 +16,7 @@ import sys
 import time
 from pathlib import Path
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "chessvision-3lc_amd"))
 

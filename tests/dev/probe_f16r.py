@@ -2,7 +2,7 @@
 batch (4096 squares), on the He-normal and on the stressed weights, per-layer error growth, and the forward time at the bench's
 chunk (16384 squares) next to the f16 and f16x3 engines.  Writes JSON lines to stdout.
 
-usage: python tools/probe_f16r.py [--squares 4096] [--time-squares 16384]
+usage: python tests/dev/probe_f16r.py [--squares 4096] [--time-squares 16384]
 """
 from __future__ import annotations
 
@@ -12,7 +12,7 @@ import sys
 import time
 from pathlib import Path
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "chessvision-3lc_amd"))
 

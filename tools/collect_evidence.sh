@@ -31,8 +31,8 @@ rm -rf /tmp/rp_b1
 find /tmp/rp_b1 -name '*kernel_stats.csv' -exec cp {} "$OUT/b1_kernel_stats.csv" \;
 python3 tools/b1_trace_summary.py "$(find /tmp/rp_b1 -name '*kernel_trace.csv' | head -1)" > "$OUT/b1_kernel_trace_summary.txt" 2>&1
 # round 5: the classifier's fp16 mode launch by launch (chained layer1; both forms of the chain, the four-launch schedule for scale)
-python3 tools/chain_ab.py > "$OUT/f16r_layer_profile.txt" 2>&1
-CV_RESNET_CHAIN=0 python3 tools/chain_ab.py > "$OUT/f16r_layer_profile_unchained.txt" 2>&1
-CV_CHAIN_WG=1 python3 tools/chain_ab.py > "$OUT/f16r_layer_profile_chain_1wg.txt" 2>&1
-python3 tools/determinism_probe.py f16r 200 128 > "$OUT/f16r_determinism.txt" 2>&1
+python3 tests/dev/chain_ab.py > "$OUT/f16r_layer_profile.txt" 2>&1
+CV_RESNET_CHAIN=0 python3 tests/dev/chain_ab.py > "$OUT/f16r_layer_profile_unchained.txt" 2>&1
+CV_CHAIN_WG=1 python3 tests/dev/chain_ab.py > "$OUT/f16r_layer_profile_chain_1wg.txt" 2>&1
+python3 tests/dev/determinism_probe.py f16r 200 128 > "$OUT/f16r_determinism.txt" 2>&1
 cat "$OUT/rocprof_reduce.log" | tail -3; cat "$OUT/latency.txt" | tail -5
