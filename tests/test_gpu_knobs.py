@@ -112,3 +112,42 @@ def test_float_reading_of_the_warp_device_equals_host_equals_oracle():
     env["CV_WARP"] = "float"
     out = subprocess.run([sys.executable, "-c", WARP_SCRIPT.replace("ROOT", str(ROOT))], env=env, capture_output=True, text=True, timeout=1800)
     assert out.returncode == 0 and "WARP_FLOAT_OK" in out.stdout, (out.stdout[-500:], out.stderr[-3000:])
+
+
+CHAIN_SCRIPT = r"""
+import hashlib, sys
+sys.path.insert(0, "ROOT"); sys.path.insert(0, "ROOT/chessvision-3lc_amd")
+import torch
+from chessvision.hip_backend import HipEngine
+from oracle import synth
+
+net = synth.make_resnet(2)
+eng = HipEngine(precision="f16r", resnet_chunk=256)
+eng.load_resnet18(net.state_dict())
+x = synth.squares_input(91, 600)                              # two full chunks and a ragged one of 88
+with torch.no_grad():
+    ref = net(x)
+outs = [eng.resnet18_forward(x.cuda()).cpu() for _ in range(3)]
+assert all(torch.equal(outs[0], o) for o in outs[1:]), "not deterministic"
+p_err = float((torch.softmax(ref, 1) - torch.softmax(outs[0], 1)).abs().max())
+assert p_err <= 1e-3 and bool((ref.argmax(1) == outs[0].argmax(1)).all()), p_err
+eng.check_numerics()
+print("SHA", hashlib.sha256(outs[0].numpy().tobytes()).hexdigest(), "PERR", p_err)
+"""
+
+
+def test_f16r_layer1_chain_forms_give_the_bits_of_the_four_launch_schedule():
+    """Round 5: the fp16 classifier runs layer1 (four convolutions) as ONE launch with the image resident in LDS.  Every form of it --
+    two workgroups per CU with the last convolution through the ordinary staged epilogue (default), one workgroup per CU with the
+    f32 trunk in registers (CV_CHAIN_WG=1) -- produces the SAME BITS as the four separate launches (CV_RESNET_CHAIN=0), run to run,
+    on full and ragged chunks; the dedicated shortcut kernel (CV_SHORTCUT_FAST=1: split-f16 products instead of the f32-input MFMA)
+    stays inside the fp16 bar (soft-max within 1e-3 of the oracle, every arg-max equal)."""
+    shas = {}
+    for name, knobs in (("default", {}), ("four_launches", {"CV_RESNET_CHAIN": "0"}), ("one_wg", {"CV_CHAIN_WG": "1"}),
+                        ("fast_shortcut", {"CV_SHORTCUT_FAST": "1"})):
+        env = dict(os.environ)
+        env.update(knobs)
+        out = subprocess.run([sys.executable, "-c", CHAIN_SCRIPT.replace("ROOT", str(ROOT))], env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0 and "SHA" in out.stdout, (name, out.stdout[-500:], out.stderr[-3000:])
+        shas[name] = out.stdout.split("SHA", 1)[1].split()[0]
+    assert shas["default"] == shas["four_launches"] == shas["one_wg"], shas
