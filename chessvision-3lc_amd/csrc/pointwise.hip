@@ -250,17 +250,30 @@ __global__ void maxpool3x3s2_kernel(TensorRef src, TensorRef dst) {
     Grp<T>::store(d, par, m);
 }
 
+// acc + w * (the low | high f16 half of `packed`), the f16 read by the FMA itself (v_fma_mix_f32: no separate conversion).  The compiler
+// does not form this instruction from (float)h * w + acc here; only for kernels without MFMAs (cv_kernels.h: split_pair's note).
+__device__ __forceinline__ float fma_mix_f16(unsigned packed, int high, float w, float acc) {
+    float r;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (high) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(packed), "v"(w), "v"(acc));
+    else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(packed), "v"(w), "v"(acc));
+#else
+    r = acc + w * (float)packed * 0.f + (float)high;      // host pass of the single-source compile: never executed
+#endif
+    return r;
+}
+
 // torch upsample_bilinear2d, align_corners=True: src = dst * (in-1)/(out-1); weights (1-l, l) in f32.
 // Grid = (row segments, output rows, images): the row's source lines and vertical weights are wave-uniform and a thread finds its
 // (column, channel group) with one 32-bit division (r03: the flat one-thread-per-element form decoded its index with three 64-bit
 // divisions -- ~150 instructions around five 32-byte memory operations; a row-per-workgroup loop was slower still: fewer loads in flight).
 template <typename T>
-__global__ __launch_bounds__(256) void upsample_bilinear2x_kernel(TensorRef src, TensorRef dst, float mul, unsigned* flag, unsigned layer_id) {
+__global__ __launch_bounds__(256) void upsample_bilinear2x_kernel(TensorRef src, TensorRef dst, float mul, float sy, float sx, unsigned* flag, unsigned layer_id) {
+    // sy, sx = (in - 1) / (out - 1) as float divisions done ONCE on the host (the same IEEE quotient torch's area_pixel_compute_scale
+    // takes; per lane they were two software divisions, ~20 vector instructions)
     constexpr int GN = Grp<T>::N;
     const int y = blockIdx.y, n = blockIdx.z;
     const unsigned groups = (unsigned)(dst.C / GN);
-    const float sy = dst.H > 1 ? (float)(src.H - 1) / (float)(dst.H - 1) : 0.f;
-    const float sx = dst.W > 1 ? (float)(src.W - 1) / (float)(dst.W - 1) : 0.f;
     const float fy = sy * (float)y;
     const int y0 = (int)fy;
     const int y1 = y0 + (y0 < src.H - 1 ? 1 : 0);
@@ -274,6 +287,60 @@ __global__ __launch_bounds__(256) void upsample_bilinear2x_kernel(TensorRef src,
         const int x0 = (int)fx;
         const int x1 = x0 + (x0 < src.W - 1 ? 1 : 0);
         const float lx1 = fx - (float)x0, lx0 = 1.f - lx1;
+        if constexpr (__is_same(T, split_t)) {
+            // split-f16 (round 5): the kernel is bound by vector issue, not by HBM (~200 instructions per 32 stored bytes: every tap
+            // converted hi and lo to f32 and added them before the blend).  The taps stay f16: each of the eight products per value is one
+            // mixed-precision FMA that reads the f16 half directly (v_fma_mix_f32), the four weights are formed once per lane, and the
+            // numeric guard runs on the packed hi pairs.  Rounding: the weights ly*lx are rounded once instead of the nested form's
+            // partial sums -- a last-bit difference (the parity bars are 1e-5 on the op, 1e-3 end to end).
+            // 32-bit byte offsets from the (wave-uniform) tensor bases: tensors stay below 4 GiB (checked by the engine), and the per-tap
+            // 64-bit address arithmetic was a third of this kernel's vector instructions
+            const char* const sbase = reinterpret_cast<const char*>(src.base);
+            const unsigned spix = (unsigned)src.Cs * 4u, goff = (unsigned)src.Coff * 4u + g * 32u;
+            const unsigned o00 = ((unsigned)row0 + (unsigned)x0) * spix + goff, o10 = ((unsigned)row1 + (unsigned)x0) * spix + goff;
+            const unsigned dxb = (unsigned)(x1 - x0) * spix;
+            const char* const p00 = sbase + o00;
+            const char* const p01 = sbase + (o00 + dxb);
+            const char* const p10 = sbase + o10;
+            const char* const p11 = sbase + (o10 + dxb);
+            const half8 a00 = *reinterpret_cast<const half8*>(p00), b00 = *reinterpret_cast<const half8*>(p00 + 16);
+            const half8 a01 = *reinterpret_cast<const half8*>(p01), b01 = *reinterpret_cast<const half8*>(p01 + 16);
+            const half8 a10 = *reinterpret_cast<const half8*>(p10), b10 = *reinterpret_cast<const half8*>(p10 + 16);
+            const half8 a11 = *reinterpret_cast<const half8*>(p11), b11 = *reinterpret_cast<const half8*>(p11 + 16);
+            const float w00 = ly0 * lx0 * mul, w01 = ly0 * lx1 * mul, w10 = ly1 * lx0 * mul, w11 = ly1 * lx1 * mul;   // mul = 2^k: exact
+            float o[8];
+            typedef unsigned u4t __attribute__((ext_vector_type(4)));
+            const u4t ta[4] = {__builtin_bit_cast(u4t, a00), __builtin_bit_cast(u4t, a01), __builtin_bit_cast(u4t, a10), __builtin_bit_cast(u4t, a11)};
+            const u4t tb[4] = {__builtin_bit_cast(u4t, b00), __builtin_bit_cast(u4t, b01), __builtin_bit_cast(u4t, b10), __builtin_bit_cast(u4t, b11)};
+            const float wt[4] = {w00, w01, w10, w11};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = 0.f;
+            // tap-major: the eight accumulators are independent, so no FMA waits for the one before it (value-major, the compiler padded
+            // every dependent pair of these asm instructions with an s_nop)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = fma_mix_f16(ta[t][j >> 1], j & 1, wt[t], o[j]);   // hi + lo of a tap: the chunk order
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = fma_mix_f16(tb[t][j >> 1], j & 1, wt[t], o[j]);   // inside the group does not matter
+            }
+            const int opar = (dst.Coff / 8 + (int)g) & 1;
+            char* const dp = reinterpret_cast<char*>(dst.base) + (((unsigned)orow + x) * ((unsigned)dst.Cs * 4u) + (unsigned)dst.Coff * 4u + g * 32u);
+            typedef unsigned u4 __attribute__((ext_vector_type(4)));
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            u4 hi, lo;
+            h2 g2 = {(half_t)0.f, (half_t)0.f};
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                unsigned hp, lp;
+                split_pair(o[j], o[j + 1], hp, lp);                   // behind the FMAs that consume nothing else: no MFMA in this kernel
+                g2 = __builtin_elementwise_fma(__builtin_bit_cast(h2, hp), h2{(half_t)0.f, (half_t)0.f}, g2);
+                hi[j / 2] = hp; lo[j / 2] = lp;
+            }
+            bad = __builtin_fmaf((float)g2[0] + (float)g2[1], 0.f, bad);
+            *reinterpret_cast<u4*>(dp + (opar ? 16 : 0)) = hi;
+            *reinterpret_cast<u4*>(dp + (opar ? 0 : 16)) = lo;
+        } else {
         float v00[GN], v01[GN], v10[GN], v11[GN], o[GN];
         int par;
         Grp<T>::load(grp_ptr<T>(src, row0 + x0, g, &par), par, v00);
@@ -284,6 +351,7 @@ __global__ __launch_bounds__(256) void upsample_bilinear2x_kernel(TensorRef src,
         for (int j = 0; j < GN; ++j)
             o[j] = (ly0 * (lx0 * v00[j] + lx1 * v01[j]) + ly1 * (lx0 * v10[j] + lx1 * v11[j])) * mul;   // mul = 2^k: exact
         Grp<T>::store(grp_ptr<T>(dst, orow + x, g, &par), par, o, bad);
+        }
     }
     report_bad(flag, layer_id, bad);
 }
@@ -816,9 +884,11 @@ hipError_t upsample_bilinear2x(int dt, const TensorRef& src, const TensorRef& ds
                                hipStream_t s) {
     const dim3 g_((unsigned)((dst.W * (dst.C / dtype_group(dt)) + 255) / 256), (unsigned)dst.H, (unsigned)dst.N), b_(256);
     const float mul = pow2f(src.exp - dst.exp);
-    if (dt == kF16) hipLaunchKernelGGL(upsample_bilinear2x_kernel<half_t>, g_, b_, 0, s, src, dst, mul, flag, layer_id);
-    else if (dt == kSplit) hipLaunchKernelGGL(upsample_bilinear2x_kernel<split_t>, g_, b_, 0, s, src, dst, mul, flag, layer_id);
-    else hipLaunchKernelGGL(upsample_bilinear2x_kernel<float>, g_, b_, 0, s, src, dst, mul, flag, layer_id);
+    const float sy = dst.H > 1 ? (float)(src.H - 1) / (float)(dst.H - 1) : 0.f;
+    const float sx = dst.W > 1 ? (float)(src.W - 1) / (float)(dst.W - 1) : 0.f;
+    if (dt == kF16) hipLaunchKernelGGL(upsample_bilinear2x_kernel<half_t>, g_, b_, 0, s, src, dst, mul, sy, sx, flag, layer_id);
+    else if (dt == kSplit) hipLaunchKernelGGL(upsample_bilinear2x_kernel<split_t>, g_, b_, 0, s, src, dst, mul, sy, sx, flag, layer_id);
+    else hipLaunchKernelGGL(upsample_bilinear2x_kernel<float>, g_, b_, 0, s, src, dst, mul, sy, sx, flag, layer_id);
     return hipGetLastError();
 }
 hipError_t outc_1x1(int dt, const TensorRef& src, const float* w, const float* bias, float* logits,
