@@ -220,3 +220,26 @@ def test_random_small_masks_all_three_agree(hb):
         n_contours += len(a)
         assert _same_quad(oc.find_quadrangle(mask), hb.find_quadrangle(mask)), (t, h, w)
     assert n_contours > 5000
+
+
+def test_committed_golden_vectors_of_the_label_masks(hb):
+    """tests/golden/contours_tc89.npz (written by the oracle, make_contours.py): per label mask the quadrangle, the contour count, the
+    point counts of the first contour with and without CHAIN_APPROX_TC89_KCOS and a position-weighted checksum of the compressed
+    points.  The product's C++ (all 631) and its numpy host form (every 20th) reproduce them; so does the oracle as built today."""
+    from ragged import G
+
+    z = np.load(G / "contours_tc89.npz")
+    masks = label_masks()
+    assert z["quads"].shape == (631, 4, 2) and z["stats"].shape == (631, 4)
+
+    def stat(contours_tc, contours_full):
+        pts = contours_tc[0].reshape(-1, 2).astype(np.int64)
+        return (len(contours_tc), len(pts), len(contours_full[0]), int((pts[:, 0] * 1009 + pts[:, 1] * 9176 + np.arange(len(pts)) * 31).sum()))
+
+    for i, m in enumerate(masks):
+        assert np.array_equal(hb.find_quadrangle(m).reshape(4, 2), z["quads"][i]), i
+        assert stat(hb.find_contours(m, True)[0], hb.find_contours(m, False)[0]) == tuple(z["stats"][i]), i
+        if i % 20 == 0:
+            assert np.array_equal(ChessVision._find_quadrangle(m).reshape(4, 2), z["quads"][i]), i
+            assert stat(classical.find_contours(m, True), classical.find_contours(m, False)) == tuple(z["stats"][i]), i
+            assert np.array_equal(oc.find_quadrangle(m).reshape(4, 2), z["quads"][i]), i
