@@ -595,7 +595,8 @@ static int impl_cv_process_image(cv_engine_t* ue, cv_engine_t* ce, const uint8_t
     // host block: image | mask | logits | board | probs | inv          device block: image | small | logits | mask | squares | board | probs | inv
     const size_t h_off[6] = {0, up(img_b), up(img_b) + up(mk_b), up(img_b) + up(mk_b) + up(lg_b), up(img_b) + up(mk_b) + up(lg_b) + up(bd_b),
                              up(img_b) + up(mk_b) + up(lg_b) + up(bd_b) + up(pr_b)};
-    const size_t h_need = h_off[5] + up(inv_b);
+    const size_t h_guard = h_off[5] + up(inv_b);              // two guard words (extractor, classifier)
+    const size_t h_need = h_guard + 256;
     size_t d_off[8];
     std::lock_guard<std::mutex> pipe_lock(U.pipe_mu);   // one request at a time per extractor engine: the staging blocks are shared
     {
@@ -627,6 +628,7 @@ static int impl_cv_process_image(cv_engine_t* ue, cv_engine_t* ce, const uint8_t
     float* d_pr = (float*)(db + d_off[6]); double* d_inv = (double*)(db + d_off[7]);
     uint8_t* h_img = (uint8_t*)(hb + h_off[0]); uint8_t* h_mk = (uint8_t*)(hb + h_off[1]); float* h_lg = (float*)(hb + h_off[2]);
     uint8_t* h_bd = (uint8_t*)(hb + h_off[3]); float* h_pr = (float*)(hb + h_off[4]); double* h_inv = (double*)(hb + h_off[5]);
+    unsigned* h_gd = (unsigned*)(hb + h_guard);
 
     std::memcpy(h_img, image, img_b);
     hipError_t e = hipMemcpyAsync(d_img, h_img, img_b, hipMemcpyHostToDevice, st);
@@ -669,13 +671,25 @@ static int impl_cv_process_image(cv_engine_t* ue, cv_engine_t* ce, const uint8_t
         if (e == hipSuccess) e = hipMemcpyAsync(h_pr, d_pr, pr_b, hipMemcpyDeviceToHost, st);
         if (e != hipSuccess) return finish(hip_fail(e, "cv_process_image: download"));
     }
-    {   // the numeric guards synchronise the stream: everything above has landed afterwards
+    {   // the numeric guards ride with the downloads into page-locked memory; ONE synchronisation, then both words are judged
         std::lock_guard<std::mutex> lk(U.mu);
-        s = U.guard_check(st);
+        s = U.guard_read_async(h_gd, st);
+    }
+    h_gd[1] = 0xffffffffu;
+    if (s.ok() && found && &C != &U) {
+        std::lock_guard<std::mutex> lk(C.mu);
+        s = C.guard_read_async(h_gd + 1, st);
+    }
+    if (!s.ok()) return finish(s);
+    e = hipStreamSynchronize(st);                           // everything above has landed afterwards
+    if (e != hipSuccess) return finish(hip_fail(e, "cv_process_image: synchronise"));
+    {
+        std::lock_guard<std::mutex> lk(U.mu);
+        s = U.guard_eval(h_gd[0]);
     }
     if (s.ok() && found && &C != &U) {
         std::lock_guard<std::mutex> lk(C.mu);
-        s = C.guard_check(st);
+        s = C.guard_eval(h_gd[1]);
     }
     if (!s.ok()) return finish(s);
     if (out->logits) std::memcpy(out->logits, h_lg, lg_b);

@@ -429,6 +429,27 @@ Status Engine::guard_init() {
     return Status();
 }
 
+// The same check in two halves for callers that synchronise anyway (cv_process_image): the guard word travels to PAGE-LOCKED memory with
+// the call's other downloads and is looked at after the caller's own synchronisation -- guard_check's copy into pageable memory plus
+// its stream synchronisation cost ~15-20 us per engine on an otherwise finished stream.
+Status Engine::guard_read_async(unsigned* pinned, hipStream_t s) {
+    *pinned = 0xffffffffu;
+    if (!guard.ptr) return Status();
+    CV_HIP(hipMemcpyAsync(pinned, guard.ptr, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    return Status();
+}
+
+Status Engine::guard_eval(unsigned v) {
+    if (v == 0xffffffffu) return Status();
+    CV_HIP(hipMemset(guard.ptr, 0xff, sizeof(unsigned)));
+    const std::string who = v < layer_names.size() ? layer_names[v] : ("layer #" + std::to_string(v));
+    if (v == 0) return fail(5, "non-finite value (NaN / inf) in the input tensor");
+    return fail(5, "non-finite value produced by '" + who + "': an activation left the range the " +
+                       (dt == kF32 ? std::string("f32") : std::string("f16-based")) +
+                       " engine can hold (|x| > 65504 * 2^exp after calibration) or a NaN reached it; results of this "
+                       "call are invalid -- use precision f32 for this checkpoint");
+}
+
 Status Engine::guard_check(hipStream_t s) {
     if (!guard.ptr) return Status();
     unsigned v = 0xffffffffu;

@@ -206,6 +206,8 @@ class Engine {
     unsigned* guard_ptr() const { return reinterpret_cast<unsigned*>(guard.ptr); }
     Status guard_init();
     Status guard_check(hipStream_t s);                  // synchronises; fails with the layer name and re-arms
+    Status guard_read_async(unsigned* pinned, hipStream_t s);   // ... in two halves: enqueue the download into page-locked memory,
+    Status guard_eval(unsigned v);                      // ... and judge the word after the caller's own synchronisation
 
     // range calibration (see Activation): while set, every producer measures its output tensor after the launch
     bool calibrating = false;
