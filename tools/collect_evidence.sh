@@ -10,6 +10,7 @@ PRECS="f16x3 f32" bash tools/pmc_collect.sh "$OUT" > "$OUT/pmc.log" 2>&1
 bash tools/rocprof_bench.sh "$OUT" > "$OUT/rocprof_reduce.log" 2>&1
 bash tools/pmc_sq.sh "$OUT" f16x3 unet > "$OUT/pmc_sq_unet.log" 2>&1
 bash tools/pmc_sq.sh "$OUT" f16x3 resnet18 > "$OUT/pmc_sq_resnet18.log" 2>&1
+bash tools/pmc_sq.sh "$OUT" f16r resnet18 > "$OUT/pmc_sq_f16r_resnet18.log" 2>&1
 bash tools/pmc_sq2.sh "$OUT" f16x3 unet > "$OUT/pmc_sq2_unet.log" 2>&1
 for d in f16x3 f32 f16; do
   python3 tools/layer_profile.py --prec $d > "$OUT/layer_profile_$d.txt" 2>&1
