@@ -325,6 +325,8 @@ struct Knobs {
     int halo_th8 = env_int("CV_HALO_TH8", 1), halo_th8_max_tiles = env_int("CV_HALO_TH8_MAX_TILES", 384);
     int splitk_halo = env_int("CV_SPLITK_HALO", 1);     // 3x3 layers on maps >= 16 x 16 split inside the halo kernel (by channel blocks)
     int splitk_halo_stage_ns = env_int("CV_SPLITK_HALO_STAGE_NS", 500);
+    // two independent layers in one launch (Engine::PendingConv): only while their workgroups together leave the chip unfilled
+    int pair = env_int("CV_PAIR", 1), pair_max_blocks = env_int("CV_PAIR_MAX_BLOCKS", 512);
 };
 static const Knobs& knobs() {
     static const Knobs k;
@@ -677,6 +679,12 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
                                  std::to_string(conv_cfg_pt(cfg)) + ",ring" + std::to_string(ns) + (L.shuffle ? ",shuffle" : "") +
                                  (p.ksplit > 1 ? ",splitK" + std::to_string(p.ksplit) : std::string()) + ">";
     }
+    if (defer && knobs().pair && !halo && !profiling && !calibrating && !stamp_dev && !head && !fuse0 && p.kbase && !(pool_out && !fuse_pool) &&
+        !(defer_first && p.ksplit > 1) &&
+        blocks_for(L.rows, p.M, conv_cfg_ct(cfg), conv_cfg_pt(cfg)) * (p.ksplit > 1 ? p.ksplit : 1) <= knobs().pair_max_blocks) {
+        defer->held = true; defer->cfg = cfg; defer->ns = ns; defer->dt = dt; defer->p = p; defer->name = L.name;
+        return Status();                                              // issued by flush_pending
+    }
     // launches with fewer 16 x 16 patches than the chip holds workgroups (2 per CU) take the 8 x 16 patch: twice the workgroups
     const int th = (halo && halo_th8_for(L, p, ct, Ho, fuse0 != nullptr)) ? 8 : 16;
     hipError_t e = halo ? conv_halo_launch(ct, dt, p, x.N, s, th) : conv_igemm_launch(cfg, ns, dt, p, s);
@@ -712,6 +720,27 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
         e = maxpool2x2(dt, y, *pool_out, s);
         if (profiling) prof_end(s);
         if (e != hipSuccess) return hip_fail(e, "maxpool2x2");
+    }
+    return Status();
+}
+
+Status Engine::flush_pending(PendingConv& a, PendingConv& b, hipStream_t s) {
+    hipError_t e = hipSuccess;
+    const bool dt_ok = a.dt == b.dt || (a.dt == kF32 && b.dt == kF16);     // the fp16 classifier's shortcuts run in f32
+    if (a.held && b.held && a.cfg == b.cfg && a.ns == b.ns && dt_ok && !(a.p.ksplit > 1 && b.p.ksplit > 1)) {
+        e = conv_igemm_pair_launch(a.cfg, a.ns, a.dt, b.dt, a.p, b.p, s);
+        if (e == hipSuccess && a.p.ksplit > 1) e = conv_splitk_reduce_launch(a.dt, a.p, s);
+        if (e == hipSuccess && b.p.ksplit > 1) e = conv_splitk_reduce_launch(b.dt, b.p, s);
+        a.held = b.held = false;
+        if (e != hipSuccess) return hip_fail(e, ("conv pair launch " + a.name + " + " + b.name).c_str());
+        return Status();
+    }
+    for (PendingConv* q : {&a, &b}) {
+        if (!q->held) continue;
+        q->held = false;
+        e = conv_igemm_launch(q->cfg, q->ns, q->dt, q->p, s);
+        if (e == hipSuccess && q->p.ksplit > 1) e = conv_splitk_reduce_launch(q->dt, q->p, s);
+        if (e != hipSuccess) return hip_fail(e, ("conv launch " + q->name).c_str());
     }
     return Status();
 }

@@ -151,3 +151,43 @@ def test_f16r_layer1_chain_forms_give_the_bits_of_the_four_launch_schedule():
         assert out.returncode == 0 and "SHA" in out.stdout, (name, out.stdout[-500:], out.stderr[-3000:])
         shas[name] = out.stdout.split("SHA", 1)[1].split()[0]
     assert shas["default"] == shas["four_launches"] == shas["one_wg"], shas
+
+
+PAIR_SCRIPT = r"""
+import hashlib, sys
+sys.path.insert(0, "ROOT"); sys.path.insert(0, "ROOT/chessvision-3lc_amd")
+import torch
+from chessvision.hip_backend import HipEngine
+from oracle import synth
+net = synth.make_resnet(2)
+h = hashlib.sha256()
+worst = 0.0
+for prec in ("f16x3", "f32", "f16", "f16r"):
+    eng = HipEngine(precision=prec)
+    eng.load_resnet18(net.state_dict())
+    for n in (64, 1, 128, 640):
+        sq = synth.squares_input(70 + n, n)
+        for _ in range(3):                                    # eager, capture, replay
+            got = eng.resnet18_forward(sq.cuda()).cpu()
+        h.update(got.numpy().tobytes())
+        if prec in ("f16x3", "f32"):
+            with torch.no_grad():
+                worst = max(worst, float((got - net(sq)).abs().max()))
+    eng.check_numerics()
+assert worst <= 1e-3, worst
+print("SHA", h.hexdigest())
+"""
+
+
+def test_two_layers_in_one_launch_give_the_bits_of_two_launches():
+    """Round 5: at single-board sizes a ResNet-18 stage's shortcut convolution and its first 3x3 convolution go out as ONE launch
+    (conv_igemm_pair_kernel, Engine::PendingConv).  Each half is the launch it replaces: the logits are bit-identical to CV_PAIR=0 at
+    1, 64, 128 and 640 squares, every precision (the fp16 classifier pairs its f32 shortcut with an f16 convolution), eager and replayed."""
+    shas = {}
+    for name, knobs in (("paired", {}), ("two_launches", {"CV_PAIR": "0"}), ("paired_always", {"CV_PAIR_MAX_BLOCKS": "1000000"})):
+        env = dict(os.environ)
+        env.update(knobs)
+        out = subprocess.run([sys.executable, "-c", PAIR_SCRIPT.replace("ROOT", str(ROOT))], env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0 and "SHA" in out.stdout, (name, out.stdout[-500:], out.stderr[-3000:])
+        shas[name] = out.stdout.split("SHA", 1)[1].split()[0]
+    assert shas["paired"] == shas["two_launches"] == shas["paired_always"], shas
