@@ -10,6 +10,9 @@
 // (numpy) and as the independent oracle oracle/c_ref/contours_ref.c (raster-scan relabelling); tests/test_contour_cpp.py,
 // tests/test_contour_parity.py.
 #include <algorithm>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -31,9 +34,8 @@ const int kDy[8] = {0, -1, -1, -1, 0, 1, 1, 1};
 const int kDx[8] = {-1, -1, 0, 1, 1, 1, 0, -1};
 
 inline int nbr_index(int dy, int dx) {
-    for (int i = 0; i < 8; ++i)
-        if (kDy[i] == dy && kDx[i] == dx) return i;
-    return 0;
+    static const int8_t kIndex[3][3] = {{1, 2, 3}, {0, 0, 4}, {7, 6, 5}};    // [dy + 1][dx + 1]; the centre never occurs
+    return kIndex[dy + 1][dx + 1];
 }
 
 struct Image {
@@ -85,6 +87,14 @@ struct RowBits {
             const uint8_t* row = mask + (size_t)y * w;
             uint64_t* out = bits.data() + (size_t)y * words;
             int x = 0;
+#if defined(__SSE2__)
+            // 16 pixels per step: byte != 0 -> one bit each (pcmpeqb against zero, pmovmskb, inverted)
+            for (; x + 16 <= w; x += 16) {
+                const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i*>(row + x));
+                const uint64_t z = (uint64_t)(uint16_t)~_mm_movemask_epi8(_mm_cmpeq_epi8(v, _mm_setzero_si128()));
+                out[x >> 6] |= z << (x & 63);
+            }
+#endif
             for (; x + 8 <= w; x += 8) {
                 uint64_t v;
                 __builtin_memcpy(&v, row + x, 8);
@@ -279,7 +289,11 @@ std::vector<Border> find_contours(const uint8_t* mask, int h, int w, size_t* tot
     rb.build(mask, h, w);
     RunIndex fg;
     const std::vector<Comp> outer = component_starts(rb, h, false, true, false, &fg);
-    const std::vector<Comp> holes = component_starts(rb, h, true, false, true);
+    // a hole needs a row with foreground on both sides of it: while no row has two foreground runs every background run reaches the
+    // frame and the second labelling (clean board masks: a third of this function's time) has nothing to find
+    bool may_have_holes = false;
+    for (int y = 0; y < h && !may_have_holes; ++y) may_have_holes = fg.row_begin[y + 1] - fg.row_begin[y] > 1;
+    const std::vector<Comp> holes = may_have_holes ? component_starts(rb, h, true, false, true) : std::vector<Comp>();
     *total = outer.size() + holes.size();
     const bool prune = prune_small && *total > 1;
     const double need = 0.35 * (double)h * w;

@@ -24,6 +24,7 @@ hipError_t resize_area_u8_tab(const uint8_t* src, int n, int h, int w, int c, ui
                               const int* xsi, const float* xa, const int* yofs, const int* ysi, const float* ya, hipStream_t s);
 hipError_t extract_squares_u8(const uint8_t* images, int n, int h, int w, const double* inv, uint8_t* squares,
                               uint8_t* boards, hipStream_t s);
+hipError_t extract_squares_u8_one(const uint8_t* image, int h, int w, const double* inv_host, uint8_t* squares, uint8_t* board, hipStream_t s);
 void board_homographies(const float* quads, int n, int out_w, int out_h, double* forward, double* inverse);
 }  // namespace cv
 
@@ -625,21 +626,25 @@ static int impl_cv_process_image(cv_engine_t* ue, cv_engine_t* ce, const uint8_t
     char* db = (char*)U.pipe_dev.ptr;
     uint8_t* d_img = (uint8_t*)(db + d_off[0]); uint8_t* d_small = (uint8_t*)(db + d_off[1]); float* d_lg = (float*)(db + d_off[2]);
     uint8_t* d_mk = (uint8_t*)(db + d_off[3]); uint8_t* d_sq = (uint8_t*)(db + d_off[4]); uint8_t* d_bd = (uint8_t*)(db + d_off[5]);
-    float* d_pr = (float*)(db + d_off[6]); double* d_inv = (double*)(db + d_off[7]);
+    float* d_pr = (float*)(db + d_off[6]);
     uint8_t* h_img = (uint8_t*)(hb + h_off[0]); uint8_t* h_mk = (uint8_t*)(hb + h_off[1]); float* h_lg = (float*)(hb + h_off[2]);
     uint8_t* h_bd = (uint8_t*)(hb + h_off[3]); float* h_pr = (float*)(hb + h_off[4]); double* h_inv = (double*)(hb + h_off[5]);
     unsigned* h_gd = (unsigned*)(hb + h_guard);
 
+    // The mask (64 KB) and the probabilities (3.3 KB) are written by their kernels straight into the page-locked block, which the device
+    // sees under its host address: over PCIe inside the kernel instead of a copy operation behind it (-18 us per call for the mask, same-box
+    // A/B in profiles/r05_tuning.md section 14).  CV_PI_HOSTMASK=0 / CV_PI_HOSTOUT=0 restore the device buffers + copies.
+    static const bool host_mask = [] { const char* v = std::getenv("CV_PI_HOSTMASK"); return !(v && v[0] == '0'); }();
     std::memcpy(h_img, image, img_b);
     hipError_t e = hipMemcpyAsync(d_img, h_img, img_b, hipMemcpyHostToDevice, st);
     if (e != hipSuccess) return finish(hip_fail(e, "cv_process_image: upload"));
     {
         std::lock_guard<std::mutex> lk(U.mu);
         s = resize_on_stream(U, d_img, 1, h, w_, 3, d_small, 256, 256, st);
-        if (s.ok()) s = unet_forward(U, d_small, true, 1, d_lg, d_mk, threshold, st);
+        if (s.ok()) s = unet_forward(U, d_small, true, 1, d_lg, host_mask ? h_mk : d_mk, threshold, st);
     }
     if (!s.ok()) return finish(s);
-    e = hipMemcpyAsync(h_mk, d_mk, mk_b, hipMemcpyDeviceToHost, st);
+    e = host_mask ? hipSuccess : hipMemcpyAsync(h_mk, d_mk, mk_b, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess && !U.pipe_event) e = hipEventCreateWithFlags(&U.pipe_event, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventRecord(U.pipe_event, st);
     if (e == hipSuccess) e = hipMemcpyAsync(h_lg, d_lg, lg_b, hipMemcpyDeviceToHost, st);     // travels while the host finds the quadrangle
@@ -647,6 +652,7 @@ static int impl_cv_process_image(cv_engine_t* ue, cv_engine_t* ce, const uint8_t
     if (e != hipSuccess) return finish(hip_fail(e, "cv_process_image: mask"));
     if (out->mask) std::memcpy(out->mask, h_mk, mk_b);
     int32_t quad[8];
+    bool side_busy = false, side_joined = false;             // a download is in flight on U.pipe_side: every exit below waits for it
     bool found = find_quadrangle(h_mk, 256, 256, quad);
     if (!found && fallback_quad) {
         const int32_t whole[8] = {255, 0, 0, 0, 0, 255, 255, 255};            // TR, TL, BL, BR of the mask
@@ -659,17 +665,34 @@ static int impl_cv_process_image(cv_engine_t* ue, cv_engine_t* ce, const uint8_t
         const double factor = (double)h / 256.0;
         for (int i = 0; i < 8; ++i) { corners[i] = (float)((double)quad[i] * factor); out->quadrangle[i] = corners[i]; }
         board_homographies(corners, 1, 512, 512, nullptr, h_inv);
-        e = hipMemcpyAsync(d_inv, h_inv, inv_b, hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) e = extract_squares_u8(d_img, 1, h, w_, d_inv, d_sq, d_bd, st);
+        e = extract_squares_u8_one(d_img, h, w_, h_inv, d_sq, d_bd, st);   // the matrix travels in the kernel arguments
+        // the rectified board (256 KB) goes home on a side stream while the classifier runs: behind the classifier on `st` it was 16 us
+        // at the end of every call
+        static const bool side_on = [] { const char* v = std::getenv("CV_PI_SIDE"); return !(v && v[0] == '0'); }();
+        static const bool host_out = [] { const char* v = std::getenv("CV_PI_HOSTOUT"); return !(v && v[0] == '0'); }();
+        if (side_on) {
+            if (e == hipSuccess && !U.pipe_side) e = hipStreamCreateWithFlags(&U.pipe_side, hipStreamNonBlocking);
+            if (e == hipSuccess && !U.pipe_event2) e = hipEventCreateWithFlags(&U.pipe_event2, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventRecord(U.pipe_event2, st);
+            if (e == hipSuccess) e = hipStreamWaitEvent(U.pipe_side, U.pipe_event2, 0);
+            if (e == hipSuccess) e = hipMemcpyAsync(h_bd, d_bd, bd_b, hipMemcpyDeviceToHost, U.pipe_side);
+            side_busy = e == hipSuccess;
+            if (e == hipSuccess && !U.pipe_event3) e = hipEventCreateWithFlags(&U.pipe_event3, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventRecord(U.pipe_event3, U.pipe_side);
+        }
         if (e != hipSuccess) return finish(hip_fail(e, "cv_process_image: warp"));
         {
             std::lock_guard<std::mutex> lk(C.mu);
-            s = resnet_forward(C, d_sq, true, 64, d_pr, true, st);
+            // the 64 x 13 probabilities are written by the head kernel straight into the page-locked block (device-visible under
+            // its host address): 3.3 KB over PCIe inside the kernel instead of one more copy operation at the end of the stream
+            s = resnet_forward(C, d_sq, true, 64, host_out ? h_pr : d_pr, true, st);
         }
-        if (!s.ok()) return finish(s);
-        e = hipMemcpyAsync(h_bd, d_bd, bd_b, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(h_pr, d_pr, pr_b, hipMemcpyDeviceToHost, st);
-        if (e != hipSuccess) return finish(hip_fail(e, "cv_process_image: download"));
+        if (!s.ok()) { if (side_busy) (void)hipStreamSynchronize(U.pipe_side); return finish(s); }
+        e = host_out ? hipSuccess : hipMemcpyAsync(h_pr, d_pr, pr_b, hipMemcpyDeviceToHost, st);
+        // the side stream joins `st` on the DEVICE (the download finished long before the classifier): one host synchronisation per call
+        if (e == hipSuccess && side_busy) { e = hipStreamWaitEvent(st, U.pipe_event3, 0); side_joined = e == hipSuccess; }
+        if (e == hipSuccess && !side_busy) e = hipMemcpyAsync(h_bd, d_bd, bd_b, hipMemcpyDeviceToHost, st);
+        if (e != hipSuccess) { if (side_busy) (void)hipStreamSynchronize(U.pipe_side); return finish(hip_fail(e, "cv_process_image: download")); }
     }
     {   // the numeric guards ride with the downloads into page-locked memory; ONE synchronisation, then both words are judged
         std::lock_guard<std::mutex> lk(U.mu);
@@ -680,8 +703,9 @@ static int impl_cv_process_image(cv_engine_t* ue, cv_engine_t* ce, const uint8_t
         std::lock_guard<std::mutex> lk(C.mu);
         s = C.guard_read_async(h_gd + 1, st);
     }
-    if (!s.ok()) return finish(s);
+    if (!s.ok()) { if (side_busy) (void)hipStreamSynchronize(U.pipe_side); return finish(s); }
     e = hipStreamSynchronize(st);                           // everything above has landed afterwards
+    if (side_busy && !side_joined) { const hipError_t e2 = hipStreamSynchronize(U.pipe_side); if (e == hipSuccess) e = e2; }
     if (e != hipSuccess) return finish(hip_fail(e, "cv_process_image: synchronise"));
     {
         std::lock_guard<std::mutex> lk(U.mu);

@@ -406,6 +406,9 @@ Engine::~Engine() {
     if (capture_stream) (void)hipStreamDestroy(capture_stream);
     if (pipe_host) (void)hipHostFree(pipe_host);
     if (pipe_event) (void)hipEventDestroy(pipe_event);
+    if (pipe_event2) (void)hipEventDestroy(pipe_event2);
+    if (pipe_event3) (void)hipEventDestroy(pipe_event3);
+    if (pipe_side) (void)hipStreamDestroy(pipe_side);
 }
 
 void Engine::graph_clear() {

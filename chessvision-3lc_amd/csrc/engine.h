@@ -195,6 +195,9 @@ class Engine {
     DeviceBuffer pipe_dev;
     std::mutex pipe_mu;                                 // one cv_process_image at a time per extractor engine (the staging is shared)
     hipEvent_t pipe_event = nullptr;
+    hipEvent_t pipe_event2 = nullptr;               // cv_process_image: "the rectified board exists" -> its download on pipe_side beside the classifier
+    hipStream_t pipe_side = nullptr;
+    hipEvent_t pipe_event3 = nullptr;               // cv_process_image: "the board is home" (side stream) -> joined into the caller's stream on the device
     DeviceBuffer area_tabs;                             // INTER_AREA tables of the last fractional resize geometry (cv_resize_area_u8)
     long long area_key = -1;
     size_t area_off[6] = {0, 0, 0, 0, 0, 0};

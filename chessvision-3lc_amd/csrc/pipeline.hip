@@ -170,17 +170,25 @@ __global__ void resize_area_u8_kernel(const uint8_t* __restrict__ src, int n, in
 // Workgroup = 64 x 16 pixels of the FLIPPED board (what the classifier sees) = a quarter of one square's rows; wave w owns rows
 // 4w .. 4w+3, lane l the pixels 4*(l%16) .. +3 of row l/16.  Writes the classifier's (64 squares, 64, 64) u8 layout directly,
 // and optionally the flipped gray board itself.
+// `one`: a single board's matrix travelling as a kernel ARGUMENT (cv_process_image: the 72-byte host-to-device copy in front of this
+// launch cost ~10 us of stream time); inv == nullptr selects it.
+struct WarpMatrix { double m[9]; };
 __global__ __launch_bounds__(256) void extract_squares_u8_kernel(const uint8_t* __restrict__ images, int n, int h, int w,
                                                                  const double* __restrict__ inv, uint8_t* __restrict__ squares,
-                                                                 uint8_t* __restrict__ boards) {
+                                                                 uint8_t* __restrict__ boards, const WarpMatrix one) {
 #pragma clang fp contract(off)
     constexpr int B = 512;
     const int img = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int bx0 = blockIdx.x * 64 + (lane & 15) * 4;                  // first of this lane's 4 pixels (flipped board)
     const int by = blockIdx.y * 16 + wave * 4 + (lane >> 4);
-    const double* m = inv + (size_t)img * 9;
-    const double m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3], m4 = m[4], m5 = m[5], m6 = m[6], m7 = m[7], m8 = m[8];
+    double m0, m1, m2, m3, m4, m5, m6, m7, m8;
+    if (inv) {
+        const double* m = inv + (size_t)img * 9;
+        m0 = m[0]; m1 = m[1]; m2 = m[2]; m3 = m[3]; m4 = m[4]; m5 = m[5]; m6 = m[6]; m7 = m[7]; m8 = m[8];
+    } else {
+        m0 = one.m[0]; m1 = one.m[1]; m2 = one.m[2]; m3 = one.m[3]; m4 = one.m[4]; m5 = one.m[5]; m6 = one.m[6]; m7 = one.m[7]; m8 = one.m[8];
+    }
     // cv2.flip(board, 1) undone: flipped pixel bx is warp-space column xs = 511 - bx.  The lane's four columns xs = xs3 .. xs3+3
     // (xs3 = 508 - bx0, a multiple of 4) lie in ONE 64-column block of OpenCV's walk (WarpPerspectiveInvoker: BLOCK_SZ = 32, bh0 =
     // min(16, h), bw0 = min(32 * 32 / bh0, w) = 64 for the 512 x 512 board; the 128 x 32 blocks are warpAffine's), whose start column
@@ -255,15 +263,14 @@ __global__ __launch_bounds__(256) void extract_squares_u8_kernel(const uint8_t* 
 // order the host form and the oracle use: the three agree byte for byte.
 __global__ __launch_bounds__(256) void extract_squares_u8_float_kernel(const uint8_t* __restrict__ images, int n, int h, int w,
                                                                        const double* __restrict__ inv, uint8_t* __restrict__ squares,
-                                                                       uint8_t* __restrict__ boards) {
+                                                                       uint8_t* __restrict__ boards, const WarpMatrix one) {
 #pragma clang fp contract(off)
     constexpr int B = 512;
     const int img = blockIdx.z;
     const int bx = blockIdx.x * 64 + (threadIdx.x & 63), by = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const double* md = inv + (size_t)img * 9;
     float m[9];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) m[i] = (float)md[i];
+    for (int i = 0; i < 9; ++i) m[i] = (float)(inv ? inv[(size_t)img * 9 + i] : one.m[i]);
     const float fx = (float)(B - 1 - bx), fy = (float)by;               // cv2.flip(board, 1) undone
     const float den = (fx * m[6] + fy * m[7]) + m[8];
     const float sx = ((fx * m[0] + fy * m[1]) + m[2]) / den;
@@ -345,19 +352,32 @@ hipError_t resize_area_u8(const uint8_t* src, int n, int h, int w, int c, uint8_
 }
 hipError_t extract_squares_u8(const uint8_t* images, int n, int h, int w, const double* inv, uint8_t* squares,
                               uint8_t* boards, hipStream_t s) {
+    WarpMatrix none;
+    for (int i = 0; i < 9; ++i) none.m[i] = 0.0;
     // grid.z = boards: jobs of the pipeline carry <= a few hundred boards (65535 is the limit)
     for (int off = 0; off < n; off += 32768) {
         const int cnt = n - off < 32768 ? n - off : 32768;
         if (warp_float_mode()) {
             hipLaunchKernelGGL(extract_squares_u8_float_kernel, dim3(8, 128, (unsigned)cnt), dim3(256), 0, s,
                                images + (size_t)off * h * w * 3, cnt, h, w, inv + (size_t)off * 9, squares + (size_t)off * 64 * 4096,
-                               boards ? boards + (size_t)off * 512 * 512 : nullptr);
+                               boards ? boards + (size_t)off * 512 * 512 : nullptr, none);
             continue;
         }
         hipLaunchKernelGGL(extract_squares_u8_kernel, dim3(8, 32, (unsigned)cnt), dim3(256), 0, s,
                            images + (size_t)off * h * w * 3, cnt, h, w, inv + (size_t)off * 9, squares + (size_t)off * 64 * 4096,
-                           boards ? boards + (size_t)off * 512 * 512 : nullptr);
+                           boards ? boards + (size_t)off * 512 * 512 : nullptr, none);
     }
+    return hipGetLastError();
+}
+
+// ONE board whose matrix (host memory, 9 doubles) rides in the kernel arguments: no device copy of it exists
+hipError_t extract_squares_u8_one(const uint8_t* image, int h, int w, const double* inv_host, uint8_t* squares, uint8_t* board, hipStream_t s) {
+    WarpMatrix one;
+    for (int i = 0; i < 9; ++i) one.m[i] = inv_host[i];
+    if (warp_float_mode())
+        hipLaunchKernelGGL(extract_squares_u8_float_kernel, dim3(8, 128, 1), dim3(256), 0, s, image, 1, h, w, (const double*)nullptr, squares, board, one);
+    else
+        hipLaunchKernelGGL(extract_squares_u8_kernel, dim3(8, 32, 1), dim3(256), 0, s, image, 1, h, w, (const double*)nullptr, squares, board, one);
     return hipGetLastError();
 }
 

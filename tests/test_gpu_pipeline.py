@@ -238,3 +238,25 @@ def test_classify_position_sees_in_place_edits_of_the_extracted_board(tmp_path):
     assert np.array_equal(edited.model_probabilities, fresh.model_probabilities)
     assert np.array_equal(edited.squares, fresh.squares)
     assert not np.array_equal(edited.model_probabilities, untouched.model_probabilities)
+
+
+def test_repeated_process_image_calls_never_return_stale_staging(tmp_path):
+    """Round 5: ``cv_process_image`` lets the UNet head write the mask and the classifier head write the probabilities straight into the
+    engine's page-locked block, sends the rectified board home on a side stream beside the classifier and passes the warp matrix as a
+    kernel argument.  300 calls alternating three photos (two with a board, one without): every result equals the first result of its
+    photo bit for bit -- nothing of the previous call's staging is ever seen."""
+    pe, pc = synthetic.save_checkpoints(tmp_path, segmenting=True)
+    cv = ChessVision(board_extractor_weights=str(pe), classifier_weights=str(pc))
+    photos = [synthetic.board_photo(11, 512), np.random.default_rng(5).integers(0, 30, (512, 512, 3), dtype=np.uint8), synthetic.board_photo(12, 512)]
+    first = [cv.process_image(p) for p in photos]
+    assert first[0].position is not None and first[2].position is not None and first[1].position is None
+    assert first[0].position.fen != first[2].position.fen or not np.array_equal(first[0].board_extraction.board_image, first[2].board_extraction.board_image)
+    for it in range(300):
+        k = (it * 7 + it // 5) % 3
+        r, f = cv.process_image(photos[k]), first[k]
+        assert np.array_equal(r.board_extraction.binary_mask, f.board_extraction.binary_mask), it
+        assert np.array_equal(r.board_extraction.probabilities, f.board_extraction.probabilities), it
+        assert (r.position is None) == (f.position is None), it
+        if f.position is not None:
+            assert np.array_equal(r.board_extraction.board_image, f.board_extraction.board_image), it
+            assert np.array_equal(r.position.model_probabilities, f.position.model_probabilities) and r.position.fen == f.position.fen, it
