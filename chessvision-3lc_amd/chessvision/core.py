@@ -221,7 +221,7 @@ class ChessVision:
                                rule_name="no_pawns_on_ends") for sq, old, new in r["fixes"]]
         extraction = BoardExtractionResult(board_image=r["board"], binary_mask=r["mask"], quadrangle=r["quadrangle"], probabilities=r["logits"])
         position = PositionResult(fen=r["fen"], original_fen=r["original_fen"], model_probabilities=r["probabilities"],
-                                  squares=self.extract_squares(r["board"]), square_names=names, validation_fixes=fixes)
+                                  squares=r["squares"], square_names=names, validation_fixes=fixes)
         elapsed = time.time() - started
         logger.info(f"Processing completed in {elapsed:.2f} seconds")
         return ChessVisionResult(board_extraction=extraction, position=position, processing_time=elapsed)

@@ -22,7 +22,7 @@ import torch
 
 _LIB_NAME = "libchessvision_hip.so"
 PREC_F32, PREC_F16, PREC_F16X3, PREC_F16R = 0, 1, 2, 3
-ABI_VERSION = 4
+ABI_VERSION = 5
 _PRECISIONS = {"f32": PREC_F32, "fp32": PREC_F32, "float32": PREC_F32, "f16": PREC_F16, "fp16": PREC_F16,
                "float16": PREC_F16, "f16x3": PREC_F16X3, "split": PREC_F16X3, "f16r": PREC_F16R}
 _PREC_NAMES = {PREC_F32: "f32", PREC_F16: "f16", PREC_F16X3: "f16x3", PREC_F16R: "f16r"}
@@ -36,7 +36,7 @@ class _ImageResult(ctypes.Structure):             # mirrors cv_image_result_t (i
     _fields_ = [("logits", ctypes.POINTER(ctypes.c_float)), ("mask", ctypes.POINTER(ctypes.c_uint8)), ("quadrangle", ctypes.c_float * 8),
                 ("found", ctypes.c_int32), ("board", ctypes.POINTER(ctypes.c_uint8)), ("probabilities", ctypes.POINTER(ctypes.c_float)),
                 ("labels", ctypes.POINTER(ctypes.c_int8)), ("fen", ctypes.c_char * 72), ("original_fen", ctypes.c_char * 72),
-                ("fixes", ctypes.c_int32 * 64), ("n_fixes", ctypes.c_int32)]
+                ("fixes", ctypes.c_int32 * 64), ("n_fixes", ctypes.c_int32), ("squares", ctypes.POINTER(ctypes.c_uint8))]
 
 
 class _Param(ctypes.Structure):
@@ -243,7 +243,7 @@ def process_image_native(unet_engine: "HipEngine", classifier_engine: "HipEngine
                          flip: bool = False, fallback_quad: bool = False) -> dict:
     """One host image through ``cv_process_image`` (the native form of ``ChessVision.process_image``, reference core.py:152-195):
     returns {"logits" (256,256) f32, "mask" (256,256) u8, "found", and when found "quadrangle" (4,1,2) f32, "board" (512,512) u8,
-    "probabilities" (64,13) f32, "fen", "original_fen", "fixes" [(square index, original class, corrected class)]}."""
+    "probabilities" (64,13) f32, "squares" (64,64,64,1) u8, "fen", "original_fen", "fixes" [(square index, original class, corrected class)]}."""
     lib = load_library()
     img = np.ascontiguousarray(image, dtype=np.uint8)
     if img.ndim != 3 or img.shape[2] != 3:
@@ -258,12 +258,14 @@ def process_image_native(unet_engine: "HipEngine", classifier_engine: "HipEngine
     res.board = board.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
     res.probabilities = probs.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
     res.labels = None
+    squares = np.empty((64, 64, 64, 1), np.uint8)           # PositionResult.squares, cut on the native side (-10 us against the numpy reshape)
+    res.squares = squares.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
     _check(lib.cv_process_image(unet_engine._h, classifier_engine._h, img.ctypes.data_as(_vp), img.shape[0], img.shape[1],
                                 float(threshold), int(bool(flip)), int(bool(fallback_quad)), ctypes.byref(res),
                                 _stream_ptr(unet_engine.device)))
     out = {"logits": logits, "mask": mask, "found": bool(res.found)}
     if res.found:
-        out.update(quadrangle=np.array(list(res.quadrangle), dtype=np.float32).reshape(4, 1, 2), board=board, probabilities=probs,
+        out.update(quadrangle=np.array(list(res.quadrangle), dtype=np.float32).reshape(4, 1, 2), board=board, probabilities=probs, squares=squares,
                    fen=res.fen.decode(), original_fen=res.original_fen.decode(),
                    fixes=[(int(res.fixes[4 * i + 1]), int(res.fixes[4 * i + 2]), int(res.fixes[4 * i + 3])) for i in range(res.n_fixes)])
     return out

@@ -719,6 +719,11 @@ static int impl_cv_process_image(cv_engine_t* ue, cv_engine_t* ce, const uint8_t
     if (out->logits) std::memcpy(out->logits, h_lg, lg_b);
     if (!found) return CV_OK;
     if (out->board) std::memcpy(out->board, h_bd, bd_b);
+    if (out->squares)                                        // extract_squares (core.py:419-439) on the host copy: 4096 rows of 64 bytes
+        for (int r = 0; r < 8; ++r)
+            for (int c = 0; c < 8; ++c)
+                for (int y = 0; y < 64; ++y)
+                    std::memcpy(out->squares + ((size_t)(r * 8 + c) * 64 + y) * 64, h_bd + (size_t)(r * 64 + y) * 512 + c * 64, 64);
     if (out->probabilities) std::memcpy(out->probabilities, h_pr, pr_b);
     int8_t labels[64];
     decode_positions(h_pr, 1, flip, out->fen, out->original_fen, labels, out->fixes, &out->n_fixes);

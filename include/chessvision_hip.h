@@ -41,9 +41,10 @@
 extern "C" {
 #endif
 
-#define CV_ABI_VERSION 4      /* 2: CV_PREC_F16R, CV_ERR_NUMERIC + cv_engine_numeric_status, cv_engine_set_chunk before cv_load_* only
+#define CV_ABI_VERSION 5      /* 2: CV_PREC_F16R, CV_ERR_NUMERIC + cv_engine_numeric_status, cv_engine_set_chunk before cv_load_* only
                                  3: cv_board_homographies, cv_engine_export/import_calibration, cv_process_image (additions only)
-                                 4: cv_find_contours (addition); cv_find_quadrangle follows CHAIN_APPROX_TC89_KCOS */
+                                 4: cv_find_contours (addition); cv_find_quadrangle follows CHAIN_APPROX_TC89_KCOS
+                                 5: cv_image_result_t gains `squares` (appended; zero the struct before use, as before) */
 
 enum cv_status {
     CV_OK = 0,
@@ -287,6 +288,8 @@ typedef struct cv_image_result {
     char     original_fen[72];
     int32_t  fixes[16 * 4];   /* {0, square index, original class, corrected class} */
     int32_t  n_fixes;
+    uint8_t* squares;         /* 64 x 64 x 64 uint8 or NULL: PositionResult.squares, the board cut into its squares a8..h1 (the
+                                 reference's extract_squares, utils.py:115-132: tile (r, c) = board[64 r .. 64 r + 63][64 c .. 64 c + 63]) */
 } cv_image_result_t;
 int cv_process_image(cv_engine_t* unet_engine, cv_engine_t* classifier_engine, const uint8_t* image, int h, int w,
                      float threshold, int flip, int fallback_quad, cv_image_result_t* out, void* stream);

@@ -35,7 +35,7 @@ def test_host_entry_points_from_plain_c(tmp_path):
     out = subprocess.run([str(exe), "host"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     lines = dict(ln.split(" ", 1) for ln in out.stdout.strip().splitlines())
-    assert lines["abi"] == "4"
+    assert lines["abi"] == "5"
     assert float(lines["homography_err2"]) < 1e-16                        # cv_board_homographies from C: corners -> board corners, inv * fwd = I
     quad = [int(v) for v in lines["quad"].split()]
     assert quad[0] == 1                                                   # found; vertices = TR, TL, BL, BR of the drawn shape
