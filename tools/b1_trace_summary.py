@@ -6,7 +6,9 @@ import sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
 rows = [r for r in rows if "copyBuffer" not in r["Kernel_Name"] and "fillBuffer" not in r["Kernel_Name"]]
 # one iteration = from a fused first-layer launch (FUSE0 instantiation: ", true>" as the last template flag of the halo kernel) to the next
-starts = [i for i, r in enumerate(rows) if "conv3x3_halo_kernel" in r["Kernel_Name"] and r["Kernel_Name"].rstrip().endswith("true>(cv::ConvParams)")]
+import re
+fuse0 = re.compile(r"true(, \d+)?>\(cv::ConvParams\)$")       # round 5: the template gained a trailing CHAIN parameter
+starts = [i for i, r in enumerate(rows) if "conv3x3_halo_kernel" in r["Kernel_Name"] and fuse0.search(r["Kernel_Name"].rstrip())]
 if len(starts) < 3:
     print("no complete iteration found"); sys.exit(0)
 it = rows[starts[-2]:starts[-1]]

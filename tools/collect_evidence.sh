@@ -31,6 +31,11 @@ rm -rf /tmp/rp_b1
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_b1 -o b1 -- python3 "$(cd "$OLDPWD" && pwd)/tools/b1_trace.py" f16x3 50 > /tmp/rp_b1.log 2>&1)
 find /tmp/rp_b1 -name '*kernel_stats.csv' -exec cp {} "$OUT/b1_kernel_stats.csv" \;
 python3 tools/b1_trace_summary.py "$(find /tmp/rp_b1 -name '*kernel_trace.csv' | head -1)" > "$OUT/b1_kernel_trace_summary.txt" 2>&1
+# round 5: one process_image call as a host / copy / kernel timeline
+rm -rf /tmp/rp_pi
+(cd /tmp && rocprofv3 --kernel-trace --hip-trace --memory-copy-trace --output-format csv -d /tmp/rp_pi -o pi -- python3 "$(cd "$OLDPWD" && pwd)/tools/process_image_latency.py" --iters 60 > /tmp/rp_pi.log 2>&1)
+python3 tools/process_image_timeline.py /tmp/rp_pi 30 > "$OUT/process_image_timeline.txt" 2>&1
+python3 tests/dev/python_overhead.py > "$OUT/python_overhead.txt" 2>&1
 # round 5: the classifier's fp16 mode launch by launch (chained layer1; both forms of the chain, the four-launch schedule for scale)
 python3 tests/dev/chain_ab.py > "$OUT/f16r_layer_profile.txt" 2>&1
 CV_RESNET_CHAIN=0 python3 tests/dev/chain_ab.py > "$OUT/f16r_layer_profile_unchained.txt" 2>&1
