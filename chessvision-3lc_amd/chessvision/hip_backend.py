@@ -32,11 +32,11 @@ class HipBackendError(RuntimeError):
     """Raised for every non-zero status of the C ABI (message = ``cv_last_error()``)."""
 
 
-class _ImageResult(ctypes.Structure):             # mirrors cv_image_result_t (include/chessvision_hip.h)
-    _fields_ = [("logits", ctypes.POINTER(ctypes.c_float)), ("mask", ctypes.POINTER(ctypes.c_uint8)), ("quadrangle", ctypes.c_float * 8),
-                ("found", ctypes.c_int32), ("board", ctypes.POINTER(ctypes.c_uint8)), ("probabilities", ctypes.POINTER(ctypes.c_float)),
-                ("labels", ctypes.POINTER(ctypes.c_int8)), ("fen", ctypes.c_char * 72), ("original_fen", ctypes.c_char * 72),
-                ("fixes", ctypes.c_int32 * 64), ("n_fixes", ctypes.c_int32), ("squares", ctypes.POINTER(ctypes.c_uint8))]
+class _ImageResult(ctypes.Structure):             # mirrors cv_image_result_t (include/chessvision_hip.h); the pointer fields as plain
+    _fields_ = [("logits", ctypes.c_void_p), ("mask", ctypes.c_void_p), ("quadrangle", ctypes.c_float * 8),     # addresses: assigning
+                ("found", ctypes.c_int32), ("board", ctypes.c_void_p), ("probabilities", ctypes.c_void_p),      # ndarray.ctypes.data costs
+                ("labels", ctypes.c_void_p), ("fen", ctypes.c_char * 72), ("original_fen", ctypes.c_char * 72),   # a fifth of data_as()
+                ("fixes", ctypes.c_int32 * 64), ("n_fixes", ctypes.c_int32), ("squares", ctypes.c_void_p)]
 
 
 class _Param(ctypes.Structure):
@@ -252,20 +252,16 @@ def process_image_native(unet_engine: "HipEngine", classifier_engine: "HipEngine
     mask = np.empty((256, 256), np.uint8)
     board = np.empty((512, 512), np.uint8)
     probs = np.empty((64, 13), np.float32)
-    res = _ImageResult()
-    res.logits = logits.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
-    res.mask = mask.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
-    res.board = board.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
-    res.probabilities = probs.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
-    res.labels = None
     squares = np.empty((64, 64, 64, 1), np.uint8)           # PositionResult.squares, cut on the native side (-10 us against the numpy reshape)
-    res.squares = squares.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
-    _check(lib.cv_process_image(unet_engine._h, classifier_engine._h, img.ctypes.data_as(_vp), img.shape[0], img.shape[1],
+    res = _ImageResult()
+    res.logits, res.mask, res.board = logits.ctypes.data, mask.ctypes.data, board.ctypes.data
+    res.probabilities, res.squares, res.labels = probs.ctypes.data, squares.ctypes.data, None
+    _check(lib.cv_process_image(unet_engine._h, classifier_engine._h, img.ctypes.data, img.shape[0], img.shape[1],
                                 float(threshold), int(bool(flip)), int(bool(fallback_quad)), ctypes.byref(res),
                                 _stream_ptr(unet_engine.device)))
     out = {"logits": logits, "mask": mask, "found": bool(res.found)}
     if res.found:
-        out.update(quadrangle=np.array(list(res.quadrangle), dtype=np.float32).reshape(4, 1, 2), board=board, probabilities=probs, squares=squares,
+        out.update(quadrangle=np.frombuffer(res.quadrangle, dtype=np.float32).reshape(4, 1, 2).copy(), board=board, probabilities=probs, squares=squares,
                    fen=res.fen.decode(), original_fen=res.original_fen.decode(),
                    fixes=[(int(res.fixes[4 * i + 1]), int(res.fixes[4 * i + 2]), int(res.fixes[4 * i + 3])) for i in range(res.n_fixes)])
     return out

@@ -686,6 +686,7 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
         !(defer_first && p.ksplit > 1) &&
         blocks_for(L.rows, p.M, conv_cfg_ct(cfg), conv_cfg_pt(cfg)) * (p.ksplit > 1 ? p.ksplit : 1) <= knobs().pair_max_blocks) {
         defer->held = true; defer->cfg = cfg; defer->ns = ns; defer->dt = dt; defer->p = p; defer->name = L.name;
+        defer->blocks = blocks_for(L.rows, p.M, conv_cfg_ct(cfg), conv_cfg_pt(cfg)) * (p.ksplit > 1 ? p.ksplit : 1);
         return Status();                                              // issued by flush_pending
     }
     // launches with fewer 16 x 16 patches than the chip holds workgroups (2 per CU) take the 8 x 16 patch: twice the workgroups
@@ -730,7 +731,8 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
 Status Engine::flush_pending(PendingConv& a, PendingConv& b, hipStream_t s) {
     hipError_t e = hipSuccess;
     const bool dt_ok = a.dt == b.dt || (a.dt == kF32 && b.dt == kF16);     // the fp16 classifier's shortcuts run in f32
-    if (a.held && b.held && a.cfg == b.cfg && a.ns == b.ns && dt_ok && !(a.p.ksplit > 1 && b.p.ksplit > 1)) {
+    if (a.held && b.held && a.cfg == b.cfg && a.ns == b.ns && dt_ok && !(a.p.ksplit > 1 && b.p.ksplit > 1) &&
+        a.blocks + b.blocks <= knobs().pair_max_blocks) {
         e = conv_igemm_pair_launch(a.cfg, a.ns, a.dt, b.dt, a.p, b.p, s);
         if (e == hipSuccess && a.p.ksplit > 1) e = conv_splitk_reduce_launch(a.dt, a.p, s);
         if (e == hipSuccess && b.p.ksplit > 1) e = conv_splitk_reduce_launch(b.dt, b.p, s);

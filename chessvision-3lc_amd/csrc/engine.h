@@ -264,10 +264,11 @@ class Engine {
                     hipStream_t s, const Head* head = nullptr, const TensorRef* pool_out = nullptr, const Fuse0* fuse0 = nullptr);
     // Two INDEPENDENT layers in one launch (conv_igemm_pair_kernel; round 5, single boards).  A caller that is about to run two
     // layers with no dependency between them points `defer` at a PendingConv before each run_conv: a launch that qualifies (generic
-    // kernel, table-free offsets, small grid, no profiling / calibration / stand-alone pool behind it; the FIRST of the two also
+    // kernel, table-free offsets, no profiling / calibration / stand-alone pool behind it; the FIRST of the two also
     // unsplit, so that the split-K scratch has one user) is then prepared but not issued, and flush_pending issues the pair as one
-    // launch when both were held with the same tile configuration -- otherwise whatever was held, one after the other.
-    struct PendingConv { bool held = false; int cfg = 0, ns = 0, dt = 0; ConvParams p; std::string name; };
+    // launch when both were held with the same tile configuration and their grids TOGETHER stay under CV_PAIR_MAX_BLOCKS (512: the
+    // pair is for launches that leave the chip unfilled) -- otherwise whatever was held, one after the other.
+    struct PendingConv { bool held = false; int cfg = 0, ns = 0, dt = 0; long long blocks = 0; ConvParams p; std::string name; };
     PendingConv* defer = nullptr;
     bool defer_first = false;
     Status flush_pending(PendingConv& a, PendingConv& b, hipStream_t s);

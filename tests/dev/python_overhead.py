@@ -17,10 +17,9 @@ with tempfile.TemporaryDirectory() as d:
     logits = np.empty((256, 256), np.float32); mask = np.empty((256, 256), np.uint8); board = np.empty((512, 512), np.uint8)
     probs = np.empty((64, 13), np.float32); squares = np.empty((64, 64, 64, 1), np.uint8)
     res = hb._ImageResult()
-    res.logits = logits.ctypes.data_as(ctypes.POINTER(ctypes.c_float)); res.mask = mask.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
-    res.board = board.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)); res.probabilities = probs.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
-    res.squares = squares.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
-    ip = img.ctypes.data_as(ctypes.c_void_p); sp = hb._stream_ptr(eng.device)
+    res.logits, res.mask, res.board = logits.ctypes.data, mask.ctypes.data, board.ctypes.data
+    res.probabilities, res.squares = probs.ctypes.data, squares.ctypes.data
+    ip = img.ctypes.data; sp = hb._stream_ptr(eng.device)
     def med(f, n=300):
         ts = []
         for _ in range(n):
