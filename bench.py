@@ -449,7 +449,7 @@ def process_image_latency(cv, iters=100):
     return {"process_image_ms_median": round(float(np.median(a)), 3), "process_image_ms_p10": round(float(np.percentile(a, 10)), 3),
             "process_image_ms_p90": round(float(np.percentile(a, 90)), 3), "iters": iters, "boards_found": found,
             "image": "512x512x3 uint8 on the host", "note": "UNet B=1 + ResNet-18 B=64 (split-K launches, hipGraph replay), C++ contours, "
-                                                              "device resize / warp; every call synchronises twice (mask, probabilities)"}
+                                                              "device resize / warp; the host waits twice per call (an event behind the UNet, one stream synchronisation at the end)"}
 
 
 def measure(eng, x, sq, steps, warmup, device, cvd, streams=None):

@@ -274,8 +274,10 @@ int cv_decode_positions(const float* probs, int n_boards, int flip, char* fen, c
  *   yields none (not a reference behaviour: random-init weights in tests and benchmarks).
  *   out: HOST, caller-owned; every pointer may be NULL except the struct itself.  found = 0: no quadrangle, board / probabilities /
  *   FEN fields are left untouched.
- * Synchronises `stream` (twice: mask, results).  Staging buffers (page-locked host memory and device memory for the image and
- * the results) belong to unet_engine and are reused across calls. */
+ * The host waits twice (an event behind the UNet, `stream` itself at the end); the mask and the probabilities are written by their
+ * kernels straight into the engine's page-locked block, the board travels on an engine-owned side stream that is joined into `stream`
+ * before the final wait.  Staging buffers (page-locked host memory and device memory for the image and the results) belong to
+ * unet_engine and are reused across calls: one call at a time per extractor engine (serialised internally). */
 typedef struct cv_image_result {
     float*   logits;          /* 256 x 256 float32: BoardExtractionResult.probabilities (raw logits, core.py:287,306) */
     uint8_t* mask;            /* 256 x 256 uint8 0 / 255 */
