@@ -680,7 +680,7 @@ static int impl_cv_process_image(cv_engine_t* ue, cv_engine_t* ce, const uint8_t
             if (e == hipSuccess && !U.pipe_event3) e = hipEventCreateWithFlags(&U.pipe_event3, hipEventDisableTiming);
             if (e == hipSuccess) e = hipEventRecord(U.pipe_event3, U.pipe_side);
         }
-        if (e != hipSuccess) return finish(hip_fail(e, "cv_process_image: warp"));
+        if (e != hipSuccess) { if (side_busy) (void)hipStreamSynchronize(U.pipe_side); return finish(hip_fail(e, "cv_process_image: warp")); }
         {
             std::lock_guard<std::mutex> lk(C.mu);
             // the 64 x 13 probabilities are written by the head kernel straight into the page-locked block (device-visible under
