@@ -263,6 +263,17 @@ __device__ __forceinline__ float fma_mix_f16(unsigned packed, int high, float w,
     return r;
 }
 
+// source pair and upper weight of one output index: torch's area_pixel_compute_source_index / compute_source_index_and_lambda with
+// align_corners -- the product scale * index is ROUNDED before the integer part is taken off (no fused multiply-subtract: with
+// contraction left to the compiler the two up-sample kernels below differed in the last bit of their weights)
+__device__ __forceinline__ void bilinear_axis(float scale, int index, int in_size, int& i0, int& i1, float& l1) {
+#pragma clang fp contract(off)
+    const float f = scale * (float)index;
+    i0 = (int)f;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l1 = f - (float)i0;
+}
+
 // torch upsample_bilinear2d, align_corners=True: src = dst * (in-1)/(out-1); weights (1-l, l) in f32.
 // Grid = (row segments, output rows, images): the row's source lines and vertical weights are wave-uniform and a thread finds its
 // (column, channel group) with one 32-bit division (r03: the flat one-thread-per-element form decoded its index with three 64-bit
@@ -274,19 +285,19 @@ __global__ __launch_bounds__(256) void upsample_bilinear2x_kernel(TensorRef src,
     constexpr int GN = Grp<T>::N;
     const int y = blockIdx.y, n = blockIdx.z;
     const unsigned groups = (unsigned)(dst.C / GN);
-    const float fy = sy * (float)y;
-    const int y0 = (int)fy;
-    const int y1 = y0 + (y0 < src.H - 1 ? 1 : 0);
-    const float ly1 = fy - (float)y0, ly0 = 1.f - ly1;
+    int y0, y1;
+    float ly1;
+    bilinear_axis(sy, y, src.H, y0, y1, ly1);
+    const float ly0 = 1.f - ly1;
     const size_t row0 = pix_index(src, n, y0, 0), row1 = pix_index(src, n, y1, 0), orow = pix_index(dst, n, y, 0);
     float bad = 0.f;
     const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < (unsigned)dst.W * groups) {
         const unsigned x = idx / groups, g = idx - x * groups;
-        const float fx = sx * (float)x;
-        const int x0 = (int)fx;
-        const int x1 = x0 + (x0 < src.W - 1 ? 1 : 0);
-        const float lx1 = fx - (float)x0, lx0 = 1.f - lx1;
+        int x0, x1;
+        float lx1;
+        bilinear_axis(sx, (int)x, src.W, x0, x1, lx1);
+        const float lx0 = 1.f - lx1;
         if constexpr (__is_same(T, split_t)) {
             // split-f16 (round 5): the kernel is bound by vector issue, not by HBM (~200 instructions per 32 stored bytes: every tap
             // converted hi and lo to f32 and added them before the blend).  The taps stay f16: each of the eight products per value is one
@@ -351,6 +362,111 @@ __global__ __launch_bounds__(256) void upsample_bilinear2x_kernel(TensorRef src,
         for (int j = 0; j < GN; ++j)
             o[j] = (ly0 * (lx0 * v00[j] + lx1 * v01[j]) + ly1 * (lx0 * v10[j] + lx1 * v11[j])) * mul;   // mul = 2^k: exact
         Grp<T>::store(grp_ptr<T>(dst, orow + x, g, &par), par, o, bad);
+        }
+    }
+    report_bad(flag, layer_id, bad);
+}
+
+// split-f16, 2 x 2 OUTPUT pixels per lane (round 5).  With align_corners=True and an exact factor of two the output rows 2k - 1 and 2k
+// blend the SAME two source rows (k - 1, k) -- likewise the columns -- so a lane that owns the block {2k - 1, 2k} x {2j - 1, 2j} loads
+// four source pixels (8 x 16 bytes) for four outputs instead of 32 x 16 bytes: the one-output-per-lane kernel above moved its bytes
+// at 0.44 of the HBM rate on tap loads through L1, not on arithmetic.  Each output keeps the exact operation order of that kernel
+// (weights ly * lx * mul rounded once, taps accumulated 00, 01, 10, 11), so both kernels produce the same bits; a block whose rows or
+// columns do NOT share their source pair (never for a factor of two; checked, not assumed: the indices come from the same float
+// products torch forms) falls back to that order with its own loads.  Grid = (segments of (W_in + 1) x groups, H_in + 1, images).
+__device__ __forceinline__ void upsample_split_emit(const TensorRef& dst, size_t opix, unsigned g, const unsigned (&t)[4][8], float w00, float w01,
+                                                    float w10, float w11, float& bad) {
+    const float wt[4] = {w00, w01, w10, w11};
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = fma_mix_f16(t[k][j >> 1], j & 1, wt[k], o[j]);          // first 16-byte half of the group
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = fma_mix_f16(t[k][4 + (j >> 1)], j & 1, wt[k], o[j]);    // second half
+    }
+    const int opar = (dst.Coff / 8 + (int)g) & 1;
+    char* const dp = reinterpret_cast<char*>(dst.base) + ((unsigned)opix * ((unsigned)dst.Cs * 4u) + (unsigned)dst.Coff * 4u + g * 32u);
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    u4 hi, lo;
+    h2 g2 = {(half_t)0.f, (half_t)0.f};
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        unsigned hp, lp;
+        split_pair(o[j], o[j + 1], hp, lp);
+        g2 = __builtin_elementwise_fma(__builtin_bit_cast(h2, hp), h2{(half_t)0.f, (half_t)0.f}, g2);
+        hi[j / 2] = hp; lo[j / 2] = lp;
+    }
+    bad = __builtin_fmaf((float)g2[0] + (float)g2[1], 0.f, bad);
+    *reinterpret_cast<u4*>(dp + (opar ? 16 : 0)) = hi;
+    *reinterpret_cast<u4*>(dp + (opar ? 0 : 16)) = lo;
+}
+
+__global__ __launch_bounds__(256) void upsample_bilinear2x_split2x2_kernel(TensorRef src, TensorRef dst, float mul, float sy, float sx,
+                                                                           unsigned* flag, unsigned layer_id) {
+    const int k = blockIdx.y, n = blockIdx.z;
+    const unsigned groups = (unsigned)(dst.C / 8);
+    float bad = 0.f;
+    // the block's two output rows (wave-uniform): source pair and weights of each, from torch's float products
+    int ry[2] = {2 * k - 1, 2 * k}, y0[2], y1[2];
+    float ly1[2];
+    bool rv[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        rv[r] = ry[r] >= 0 && ry[r] < dst.H;
+        bilinear_axis(sy, rv[r] ? ry[r] : 0, src.H, y0[r], y1[r], ly1[r]);
+    }
+    const int rbase = rv[0] ? 0 : 1;                          // the row whose source pair the lane loads
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (unsigned)(src.W + 1) * groups) {
+        const unsigned j = idx / groups, g = idx - j * groups;
+        int cx[2] = {2 * (int)j - 1, 2 * (int)j}, x0[2], x1[2];
+        float lx1[2];
+        bool cv_[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            cv_[c] = cx[c] >= 0 && cx[c] < dst.W;
+            bilinear_axis(sx, cv_[c] ? cx[c] : 0, src.W, x0[c], x1[c], lx1[c]);
+        }
+        const int cbase = cv_[0] ? 0 : 1;
+        const char* const sbase = reinterpret_cast<const char*>(src.base);
+        const unsigned spix = (unsigned)src.Cs * 4u, goff = (unsigned)src.Coff * 4u + g * 32u;
+        auto load4 = [&](int yy0, int yy1, int xx0, int xx1, unsigned (&t)[4][8]) {
+            const unsigned r0 = (unsigned)pix_index(src, n, yy0, 0), r1 = (unsigned)pix_index(src, n, yy1, 0);
+            const unsigned off[4] = {(r0 + (unsigned)xx0) * spix + goff, (r0 + (unsigned)xx1) * spix + goff, (r1 + (unsigned)xx0) * spix + goff,
+                                     (r1 + (unsigned)xx1) * spix + goff};
+            typedef unsigned u4t __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const u4t a = *reinterpret_cast<const u4t*>(sbase + off[q]), b = *reinterpret_cast<const u4t*>(sbase + off[q] + 16);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { t[q][i] = a[i]; t[q][4 + i] = b[i]; }
+            }
+        };
+        unsigned t[4][8];
+        load4(y0[rbase], y1[rbase], x0[cbase], x1[cbase], t);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            if (!rv[r]) continue;
+            const bool rows_shared = y0[r] == y0[rbase] && y1[r] == y1[rbase];
+            const float ly0 = 1.f - ly1[r];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                if (!cv_[c]) continue;
+                const float lx0 = 1.f - lx1[c];
+                const float w00 = ly0 * lx0 * mul, w01 = ly0 * lx1[c] * mul, w10 = ly1[r] * lx0 * mul, w11 = ly1[r] * lx1[c] * mul;   // mul = 2^k: exact
+                const size_t opix = pix_index(dst, n, ry[r], cx[c]);
+                if (rows_shared && x0[c] == x0[cbase] && x1[c] == x1[cbase]) {
+                    upsample_split_emit(dst, opix, g, t, w00, w01, w10, w11, bad);
+                } else {                                      // not reached for a factor of two; kept so that the kernel is exact for any geometry
+                    unsigned u[4][8];
+                    load4(y0[r], y1[r], x0[c], x1[c], u);
+                    upsample_split_emit(dst, opix, g, u, w00, w01, w10, w11, bad);
+                }
+            }
         }
     }
     report_bad(flag, layer_id, bad);
@@ -887,7 +1003,13 @@ hipError_t upsample_bilinear2x(int dt, const TensorRef& src, const TensorRef& ds
     const float sy = dst.H > 1 ? (float)(src.H - 1) / (float)(dst.H - 1) : 0.f;
     const float sx = dst.W > 1 ? (float)(src.W - 1) / (float)(dst.W - 1) : 0.f;
     if (dt == kF16) hipLaunchKernelGGL(upsample_bilinear2x_kernel<half_t>, g_, b_, 0, s, src, dst, mul, sy, sx, flag, layer_id);
-    else if (dt == kSplit) hipLaunchKernelGGL(upsample_bilinear2x_kernel<split_t>, g_, b_, 0, s, src, dst, mul, sy, sx, flag, layer_id);
+    else if (dt == kSplit) {
+        static const bool block2x2 = [] { const char* v = std::getenv("CV_UPSAMPLE_2X2"); return !(v && v[0] == '0'); }();
+        if (block2x2 && dst.H == 2 * src.H && dst.W == 2 * src.W) {
+            const dim3 g2((unsigned)(((src.W + 1) * (dst.C / 8) + 255) / 256), (unsigned)(src.H + 1), (unsigned)dst.N);
+            hipLaunchKernelGGL(upsample_bilinear2x_split2x2_kernel, g2, b_, 0, s, src, dst, mul, sy, sx, flag, layer_id);
+        } else hipLaunchKernelGGL(upsample_bilinear2x_kernel<split_t>, g_, b_, 0, s, src, dst, mul, sy, sx, flag, layer_id);
+    }
     else hipLaunchKernelGGL(upsample_bilinear2x_kernel<float>, g_, b_, 0, s, src, dst, mul, sy, sx, flag, layer_id);
     return hipGetLastError();
 }
