@@ -1172,6 +1172,93 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (live && bad != bad && flag) atomicMin(flag, layer_id);
 }
 
+// Second form (round 5, late): the weights of the workgroup's 128-channel group live in LDS (KS x 16 KB, staged once), eight PERSISTENT
+// waves walk the pixel groups and read their weight fragments from LDS -- in the first form every wave streamed those 32-128 KB from L2
+// for 16 pixels of work (2.1 GB of L2 traffic per launch against 0.2-0.8 GB of HBM bytes: that, not the stride-2 read, was what the
+// launch waited for).  The next pixel group's floats are fetched while the current one is multiplied (CIN <= 128: 16-32 registers).
+// Same arithmetic, same operation order per output as the first form: same bits.
+template <int CIN, int NW, bool PREFETCH>
+__global__ __launch_bounds__(64 * NW) void shortcut1x1s2_lds_kernel(
+    const float* __restrict__ x, int n, int H, int W, const half8* __restrict__ wpk, const float* __restrict__ scale,
+    const float* __restrict__ shift, float* __restrict__ y, unsigned* flag, unsigned layer_id) {
+    constexpr int COUT = 2 * CIN, KS = CIN / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem_sc[];
+    half8* const wl = reinterpret_cast<half8*>(smem_sc);
+    const int cg = blockIdx.y;
+    for (int i = threadIdx.x; i < KS * 16 * 64; i += 64 * NW) wl[i] = wpk[(size_t)cg * KS * 16 * 64 + i];
+    __syncthreads();
+    const int Ho = H / 2, Wo = W / 2, M = n * Ho * Wo, ngroups = (M + 15) / 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, l15 = lane & 15;
+    const int c0 = cg * 128 + q * 32;
+    auto src_of = [&](int pg) {
+        int m = pg * 16 + l15;
+        m = m < M ? m : M - 1;
+        const int ox = m % Wo, oy = (m / Wo) % Ho, img = m / (Wo * Ho);
+        return x + ((size_t)(img * (H + 2) + 2 * oy + 1) * (W + 2) + 2 * ox + 1) * CIN + q * 8;
+    };
+    auto fetch = [&](const float* xp, f4 (&xv)[KS][2]) {
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            xv[k][0] = *reinterpret_cast<const f4*>(xp + k * 32);
+            xv[k][1] = *reinterpret_cast<const f4*>(xp + k * 32 + 4);
+        }
+    };
+    float bad = 0.f;
+    const int stride = gridDim.x * NW;
+    int pg = blockIdx.x * NW + wave;
+    f4 xn[KS][2];
+    if (pg < ngroups) fetch(src_of(pg), xn);
+    for (; pg < ngroups; pg += stride) {
+        f4 xv[KS][2];
+#pragma unroll
+        for (int k = 0; k < KS; ++k) { xv[k][0] = xn[k][0]; xv[k][1] = xn[k][1]; }
+        if (PREFETCH) { if (pg + stride < ngroups) fetch(src_of(pg + stride), xn); }
+        f4 acc[8];
+#pragma unroll
+        for (int f = 0; f < 8; ++f) acc[f] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            half8 bh, bl;                                    // plain C conversion: see the first form
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = j < 4 ? xv[k][0][j] : xv[k][1][j - 4];
+                bh[j] = (half_t)v;
+                bl[j] = (half_t)(v - (float)bh[j]);
+            }
+            // weight fragments four channel fragments at a time (32 registers live; left alone the compiler hoists every LDS read of
+            // every k-step to the top of the iteration and spills 200-400 registers)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                half8 wa[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) wa[i] = wl[(k * 16 + h * 8 + i) * 64 + lane];
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    acc[h * 4 + f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[2 * f], bh, acc[h * 4 + f], 0, 0, 0);
+                    acc[h * 4 + f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[2 * f + 1], bh, acc[h * 4 + f], 0, 0, 0);
+                    acc[h * 4 + f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[2 * f], bl, acc[h * 4 + f], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        const int m = pg * 16 + l15;
+        const bool live = m < M;
+        const int mm = live ? m : M - 1;
+        const int ox = mm % Wo, oy = (mm / Wo) % Ho, img = mm / (Wo * Ho);
+        float* const yp = y + ((size_t)(img * (Ho + 2) + oy + 1) * (Wo + 2) + ox + 1) * COUT + c0;
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            const f4 sc = *reinterpret_cast<const f4*>(scale + c0 + f * 4), sh = *reinterpret_cast<const f4*>(shift + c0 + f * 4);
+            f4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { o[r] = acc[f][r] * sc[r] + sh[r]; bad = __builtin_fmaf(o[r], 0.f, bad); }
+            if (live) *reinterpret_cast<f4*>(yp + f * 4) = o;
+        }
+        if (!PREFETCH) { if (pg + stride < ngroups) fetch(src_of(pg + stride), xn); }
+    }
+    if (bad != bad && flag) atomicMin(flag, layer_id);
+}
+
 hipError_t shortcut1x1s2(const TensorRef& x32, const void* wpk, const float* scale, const float* shift, const TensorRef& y32,
                          unsigned* flag, unsigned layer_id, hipStream_t s) {
     if (!x32.f32_only || !y32.f32_only || x32.Coff || y32.Coff || x32.Cs != x32.C || y32.Cs != y32.C || y32.C != 2 * x32.C ||
@@ -1183,6 +1270,33 @@ hipError_t shortcut1x1s2(const TensorRef& x32, const void* wpk, const float* sca
     const float* xb = reinterpret_cast<const float*>(x32.base);
     float* yb = reinterpret_cast<float*>(y32.base);
     const half8* w = reinterpret_cast<const half8*>(wpk);
+    static const bool lds_form = [] { const char* v = std::getenv("CV_SHORTCUT_LDS"); return !(v && v[0] == '0'); }();
+    if (lds_form) {
+        static const int per_cu = [] { const char* v = std::getenv("CV_SHORTCUT_WGS"); return v && *v ? std::atoi(v) : 1; }();
+        static const int nw_knob = [] { const char* v = std::getenv("CV_SHORTCUT_NW"); return v && *v ? std::atoi(v) : 8; }();
+        static const int pf_knob = [] { const char* v = std::getenv("CV_SHORTCUT_PF"); return v && *v ? std::atoi(v) : 1; }();
+        const int nw = (nw_knob == 4 && cin == 64) ? 4 : 8;
+        const int cgs = 2 * cin / 128, groups = (M + 15) / 16;
+        int wgx = (256 * per_cu + cgs - 1) / cgs;                       // persistent: about per_cu workgroups per CU over all channel groups
+        if (wgx > (groups + nw - 1) / nw) wgx = (groups + nw - 1) / nw;
+        if (wgx < 1) wgx = 1;
+        const dim3 g2((unsigned)wgx, (unsigned)cgs), b2((unsigned)(64 * nw));
+        const size_t lds = (size_t)(cin / 32) * 16 * 1024;
+#define CV_SC_LAUNCH(CIN_, NW_, PF_)                                                                                                      \
+        do {                                                                                                                              \
+            static bool set_ = false;                                                                                                     \
+            if (!set_) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(shortcut1x1s2_lds_kernel<CIN_, NW_, PF_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set_ = true; } \
+            hipLaunchKernelGGL((shortcut1x1s2_lds_kernel<CIN_, NW_, PF_>), g2, b2, lds, s, xb, x32.N, x32.H, x32.W, w, scale, shift, yb, flag, layer_id); \
+        } while (0)
+        if (cin == 64 && nw == 4) CV_SC_LAUNCH(64, 4, true);
+        else if (cin == 64) CV_SC_LAUNCH(64, 8, true);
+        else if (cin == 128) CV_SC_LAUNCH(128, 8, true);
+        else if (cin == 256 && pf_knob) CV_SC_LAUNCH(256, 8, true);
+        else if (cin == 256) CV_SC_LAUNCH(256, 8, false);
+        else return hipErrorInvalidValue;
+#undef CV_SC_LAUNCH
+        return hipGetLastError();
+    }
     if (cin == 64) hipLaunchKernelGGL(shortcut1x1s2_kernel<64>, grid, block, 0, s, xb, x32.N, x32.H, x32.W, w, scale, shift, yb, flag, layer_id);
     else if (cin == 128) hipLaunchKernelGGL(shortcut1x1s2_kernel<128>, grid, block, 0, s, xb, x32.N, x32.H, x32.W, w, scale, shift, yb, flag, layer_id);
     else if (cin == 256) hipLaunchKernelGGL(shortcut1x1s2_kernel<256>, grid, block, 0, s, xb, x32.N, x32.H, x32.W, w, scale, shift, yb, flag, layer_id);

@@ -121,10 +121,12 @@ import torch
 from chessvision.hip_backend import HipEngine
 from oracle import synth
 
+import os
 net = synth.make_resnet(2)
-eng = HipEngine(precision="f16r", resnet_chunk=256)
+chunk, count = int(os.environ.get("CHAIN_CHUNK", "256")), int(os.environ.get("CHAIN_N", "600"))
+eng = HipEngine(precision="f16r", resnet_chunk=chunk)
 eng.load_resnet18(net.state_dict())
-x = synth.squares_input(91, 600)                              # two full chunks and a ragged one of 88
+x = synth.squares_input(91, count)                            # default: two full chunks and a ragged one of 88
 with torch.no_grad():
     ref = net(x)
 outs = [eng.resnet18_forward(x.cuda()).cpu() for _ in range(3)]
@@ -140,17 +142,21 @@ def test_f16r_layer1_chain_forms_give_the_bits_of_the_four_launch_schedule():
     """Round 5: the fp16 classifier runs layer1 (four convolutions) as ONE launch with the image resident in LDS.  Every form of it --
     two workgroups per CU with the last convolution through the ordinary staged epilogue (default), one workgroup per CU with the
     f32 trunk in registers (CV_CHAIN_WG=1) -- produces the SAME BITS as the four separate launches (CV_RESNET_CHAIN=0), run to run,
-    on full and ragged chunks; the dedicated shortcut kernel (CV_SHORTCUT_FAST=1: split-f16 products instead of the f32-input MFMA)
+    on full and ragged chunks; the dedicated shortcut kernel (default for >= 1024 squares: split-f16 products instead of the f32-input MFMA; both of its forms give the same bits)
     stays inside the fp16 bar (soft-max within 1e-3 of the oracle, every arg-max equal)."""
     shas = {}
-    for name, knobs in (("default", {}), ("four_launches", {"CV_RESNET_CHAIN": "0"}), ("one_wg", {"CV_CHAIN_WG": "1"}),
-                        ("fast_shortcut", {"CV_SHORTCUT_FAST": "1"})):
+    for name, knobs in (("default", {"CV_SHORTCUT_FAST": "0"}), ("four_launches", {"CV_RESNET_CHAIN": "0", "CV_SHORTCUT_FAST": "0"}),
+                        ("one_wg", {"CV_CHAIN_WG": "1", "CV_SHORTCUT_FAST": "0"}),
+                        # the dedicated shortcut kernel serves launches of >= 1024 squares: one full chunk of 2048 and a ragged one of 1100
+                        ("fast_shortcut", {"CHAIN_CHUNK": "2048", "CHAIN_N": "3148"}),
+                        ("fast_shortcut_first_form", {"CV_SHORTCUT_LDS": "0", "CHAIN_CHUNK": "2048", "CHAIN_N": "3148"})):
         env = dict(os.environ)
         env.update(knobs)
         out = subprocess.run([sys.executable, "-c", CHAIN_SCRIPT.replace("ROOT", str(ROOT))], env=env, capture_output=True, text=True, timeout=900)
         assert out.returncode == 0 and "SHA" in out.stdout, (name, out.stdout[-500:], out.stderr[-3000:])
         shas[name] = out.stdout.split("SHA", 1)[1].split()[0]
     assert shas["default"] == shas["four_launches"] == shas["one_wg"], shas
+    assert shas["fast_shortcut"] == shas["fast_shortcut_first_form"], shas     # both forms of the dedicated shortcut kernel: same operation order
 
 
 PAIR_SCRIPT = r"""
