@@ -1177,7 +1177,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // for 16 pixels of work (2.1 GB of L2 traffic per launch against 0.2-0.8 GB of HBM bytes: that, not the stride-2 read, was what the
 // launch waited for).  The next pixel group's floats are fetched while the current one is multiplied (CIN <= 128: 16-32 registers).
 // Same arithmetic, same operation order per output as the first form: same bits.
-template <int CIN, int NW, bool PREFETCH>
+template <int CIN, int NW, bool PREFETCH, bool STAGE>
 __global__ __launch_bounds__(64 * NW) void shortcut1x1s2_lds_kernel(
     const float* __restrict__ x, int n, int H, int W, const half8* __restrict__ wpk, const float* __restrict__ scale,
     const float* __restrict__ shift, float* __restrict__ y, unsigned* flag, unsigned layer_id) {
@@ -1250,7 +1250,41 @@ __global__ __launch_bounds__(64 * NW) void shortcut1x1s2_lds_kernel(
         const bool live = m < M;
         const int mm = live ? m : M - 1;
         const int ox = mm % Wo, oy = (mm / Wo) % Ho, img = mm / (Wo * Ho);
-        float* const yp = y + ((size_t)(img * (Ho + 2) + oy + 1) * (Wo + 2) + ox + 1) * COUT + c0;
+        const size_t opix = (size_t)(img * (Ho + 2) + oy + 1) * (Wo + 2) + ox + 1;
+        if constexpr (STAGE) {
+            // the accumulators leave each lane with 32 channels of ONE pixel: eight store instructions of 64 scattered 16-byte pieces.  Park
+            // the wave's 16 x 128 tile in its own LDS corner (rows padded to 528 B) and read it back two whole pixel rows per instruction:
+            // every store instruction then writes 1 KB in full lines.  Wave-private: DS operations of a wave execute in order.
+            // SR pixel rows per pass (16 = the whole tile; Cin = 256 keeps 128 KB of weights in LDS and stages 4 rows at a time).
+            constexpr int SROW = 528, SR = CIN <= 128 ? 16 : 4;
+            char* const stg = smem_sc + (size_t)KS * 16 * 1024 + 1024 + (size_t)wave * (SR * SROW + 64);
+            unsigned* const pixw = reinterpret_cast<unsigned*>(stg + SR * SROW);
+            f4 o[8];
+#pragma unroll
+            for (int f = 0; f < 8; ++f) {
+                const f4 sc = *reinterpret_cast<const f4*>(sl + q * 32 + f * 4), sh = *reinterpret_cast<const f4*>(sl + 128 + q * 32 + f * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { o[f][r] = acc[f][r] * sc[r] + sh[r]; bad = __builtin_fmaf(o[f][r], 0.f, bad); }
+            }
+#pragma unroll
+            for (int ps = 0; ps < 16 / SR; ++ps) {
+                if (SR == 16 || (l15 / SR) == ps) {
+#pragma unroll
+                    for (int f = 0; f < 8; ++f) *reinterpret_cast<f4*>(stg + (l15 % SR) * SROW + (q * 32 + f * 4) * 4) = o[f];
+                    if (q == 0) pixw[l15 % SR] = live ? (unsigned)opix : 0xffffffffu;
+                }
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int j = 0; j < SR / 2; ++j) {
+                    const int px = 2 * j + (lane >> 5), part = lane & 31;
+                    const f4 v = *reinterpret_cast<const f4*>(stg + px * SROW + part * 16);
+                    const unsigned op = pixw[px];
+                    if (op != 0xffffffffu) *reinterpret_cast<f4*>(y + (size_t)op * COUT + cg * 128 + part * 4) = v;
+                }
+                asm volatile("" ::: "memory");
+            }
+        } else {
+        float* const yp = y + opix * COUT + c0;
 #pragma unroll
         for (int f = 0; f < 8; ++f) {
             const f4 sc = *reinterpret_cast<const f4*>(sl + q * 32 + f * 4), sh = *reinterpret_cast<const f4*>(sl + 128 + q * 32 + f * 4);
@@ -1258,6 +1292,7 @@ __global__ __launch_bounds__(64 * NW) void shortcut1x1s2_lds_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r) { o[r] = acc[f][r] * sc[r] + sh[r]; bad = __builtin_fmaf(o[r], 0.f, bad); }
             if (live) *reinterpret_cast<f4*>(yp + f * 4) = o;
+        }
         }
         if (!PREFETCH) { if (pg + stride < ngroups) fetch(src_of(pg + stride), xn); }
     }
@@ -1286,18 +1321,20 @@ hipError_t shortcut1x1s2(const TensorRef& x32, const void* wpk, const float* sca
         if (wgx > (groups + nw - 1) / nw) wgx = (groups + nw - 1) / nw;
         if (wgx < 1) wgx = 1;
         const dim3 g2((unsigned)wgx, (unsigned)cgs), b2((unsigned)(64 * nw));
-        const size_t lds = (size_t)(cin / 32) * 16 * 1024 + 1024;         // weights + the group's scale / shift
-#define CV_SC_LAUNCH(CIN_, NW_, PF_)                                                                                                      \
+        static const int stage_knob = [] { const char* v = std::getenv("CV_SHORTCUT_STAGE"); return v && *v ? std::atoi(v) : 1; }();
+        const bool stage = stage_knob != 0;
+        const size_t lds = (size_t)(cin / 32) * 16 * 1024 + 1024 + (stage ? (size_t)nw * ((cin <= 128 ? 16 : 4) * 528 + 64) : 0);   // weights + scale / shift (+ staging)
+#define CV_SC_LAUNCH(CIN_, NW_, PF_, ST_)                                                                                                 \
         do {                                                                                                                              \
             static bool set_ = false;                                                                                                     \
-            if (!set_) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(shortcut1x1s2_lds_kernel<CIN_, NW_, PF_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set_ = true; } \
-            hipLaunchKernelGGL((shortcut1x1s2_lds_kernel<CIN_, NW_, PF_>), g2, b2, lds, s, xb, x32.N, x32.H, x32.W, w, scale, shift, yb, flag, layer_id); \
+            if (!set_) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(shortcut1x1s2_lds_kernel<CIN_, NW_, PF_, ST_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set_ = true; } \
+            hipLaunchKernelGGL((shortcut1x1s2_lds_kernel<CIN_, NW_, PF_, ST_>), g2, b2, lds, s, xb, x32.N, x32.H, x32.W, w, scale, shift, yb, flag, layer_id); \
         } while (0)
-        if (cin == 64 && nw == 4) CV_SC_LAUNCH(64, 4, true);
-        else if (cin == 64) CV_SC_LAUNCH(64, 8, true);
-        else if (cin == 128) CV_SC_LAUNCH(128, 8, true);
-        else if (cin == 256 && pf_knob) CV_SC_LAUNCH(256, 8, true);
-        else if (cin == 256) CV_SC_LAUNCH(256, 8, false);
+        if (cin == 64 && nw == 4) { if (stage) CV_SC_LAUNCH(64, 4, true, true); else CV_SC_LAUNCH(64, 4, true, false); }
+        else if (cin == 64) { if (stage) CV_SC_LAUNCH(64, 8, true, true); else CV_SC_LAUNCH(64, 8, true, false); }
+        else if (cin == 128) { if (stage) CV_SC_LAUNCH(128, 8, true, true); else CV_SC_LAUNCH(128, 8, true, false); }
+        else if (cin == 256 && pf_knob) { if (stage) CV_SC_LAUNCH(256, 8, true, true); else CV_SC_LAUNCH(256, 8, true, false); }
+        else if (cin == 256) { if (stage) CV_SC_LAUNCH(256, 8, false, true); else CV_SC_LAUNCH(256, 8, false, false); }
         else return hipErrorInvalidValue;
 #undef CV_SC_LAUNCH
         return hipGetLastError();
