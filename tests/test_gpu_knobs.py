@@ -142,21 +142,21 @@ def test_f16r_layer1_chain_forms_give_the_bits_of_the_four_launch_schedule():
     """Round 5: the fp16 classifier runs layer1 (four convolutions) as ONE launch with the image resident in LDS.  Every form of it --
     two workgroups per CU with the last convolution through the ordinary staged epilogue (default), one workgroup per CU with the
     f32 trunk in registers (CV_CHAIN_WG=1) -- produces the SAME BITS as the four separate launches (CV_RESNET_CHAIN=0), run to run,
-    on full and ragged chunks; the dedicated shortcut kernel (default for >= 1024 squares: split-f16 products instead of the f32-input MFMA; both of its forms give the same bits)
+    on full and ragged chunks; the dedicated shortcut kernel (default: split-f16 products instead of the f32-input MFMA; all of its forms give the same bits)
     stays inside the fp16 bar (soft-max within 1e-3 of the oracle, every arg-max equal)."""
     shas = {}
     for name, knobs in (("default", {"CV_SHORTCUT_FAST": "0"}), ("four_launches", {"CV_RESNET_CHAIN": "0", "CV_SHORTCUT_FAST": "0"}),
                         ("one_wg", {"CV_CHAIN_WG": "1", "CV_SHORTCUT_FAST": "0"}),
-                        # the dedicated shortcut kernel serves launches of >= 1024 squares: one full chunk of 2048 and a ragged one of 1100
-                        ("fast_shortcut", {"CHAIN_CHUNK": "2048", "CHAIN_N": "3148"}),
-                        ("fast_shortcut_first_form", {"CV_SHORTCUT_LDS": "0", "CHAIN_CHUNK": "2048", "CHAIN_N": "3148"})):
+                        ("fast_shortcut", {}), ("fast_shortcut_first_form", {"CV_SHORTCUT_LDS": "0"}),
+                        ("fast_shortcut_unstaged", {"CV_SHORTCUT_STAGE": "0"})):
         env = dict(os.environ)
         env.update(knobs)
         out = subprocess.run([sys.executable, "-c", CHAIN_SCRIPT.replace("ROOT", str(ROOT))], env=env, capture_output=True, text=True, timeout=900)
         assert out.returncode == 0 and "SHA" in out.stdout, (name, out.stdout[-500:], out.stderr[-3000:])
         shas[name] = out.stdout.split("SHA", 1)[1].split()[0]
     assert shas["default"] == shas["four_launches"] == shas["one_wg"], shas
-    assert shas["fast_shortcut"] == shas["fast_shortcut_first_form"], shas     # both forms of the dedicated shortcut kernel: same operation order
+    assert shas["fast_shortcut"] == shas["fast_shortcut_first_form"] == shas["fast_shortcut_unstaged"], shas   # every form of the dedicated
+                                                                                  # shortcut kernel: same operation order per output
 
 
 PAIR_SCRIPT = r"""
@@ -192,6 +192,7 @@ def test_two_layers_in_one_launch_give_the_bits_of_two_launches():
     shas = {}
     for name, knobs in (("paired", {}), ("two_launches", {"CV_PAIR": "0"}), ("paired_always", {"CV_PAIR_MAX_BLOCKS": "1000000"})):
         env = dict(os.environ)
+        env["CV_SHORTCUT_FAST"] = "0"                        # the fp16 classifier's generic shortcut launches: the f32-beside-f16 pair
         env.update(knobs)
         out = subprocess.run([sys.executable, "-c", PAIR_SCRIPT.replace("ROOT", str(ROOT))], env=env, capture_output=True, text=True, timeout=900)
         assert out.returncode == 0 and "SHA" in out.stdout, (name, out.stdout[-500:], out.stderr[-3000:])
