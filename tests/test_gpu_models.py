@@ -401,3 +401,22 @@ def test_rejected_calibration_import_leaves_the_engine_untouched():
     assert np.array_equal(eng.export_calibration("resnet18"), cal)
     assert torch.equal(eng.resnet18_forward(x).cpu(), before)
     eng.close()
+
+
+@pytest.mark.gpu
+def test_fp16_classifier_at_ragged_tiny_batches():
+    """Round 5: the fp16 classifier's persistent kernels (chained layer1: one workgroup per square; shortcut kernel: groups of 16 output
+    pixels per wave, partial last group) at 1 .. 65 squares: soft-max within configs[2]'s 1e-3 of the oracle, every arg-max equal."""
+    from chessvision.hip_backend import HipEngine
+
+    net = synth.make_resnet(2)
+    eng = HipEngine(precision="f16r")
+    eng.load_resnet18(net.state_dict())
+    for n in (1, 2, 3, 5, 17, 63, 65):
+        x = synth.squares_input(70 + n, n)
+        with torch.no_grad():
+            ref = net(x)
+        got = eng.resnet18_forward(x.cuda()).cpu()
+        assert float((torch.softmax(ref, 1) - torch.softmax(got, 1)).abs().max()) <= 1e-3, n
+        assert bool((ref.argmax(1) == got.argmax(1)).all()), n
+    eng.check_numerics()
