@@ -127,10 +127,10 @@ static int image_mode(const char* unet_blob, const char* resnet_blob, const char
     CHECK(cv_load_unet(eng, tu, nu));
     CHECK(cv_load_resnet18(eng, tr, nr));
     static float probs[64 * 13], logits[256 * 256];
-    static uint8_t mask[256 * 256], board[512 * 512];
+    static uint8_t mask[256 * 256], board[512 * 512], crops[64 * 64 * 64];
     cv_image_result_t res;
     memset(&res, 0, sizeof(res));
-    res.logits = logits; res.mask = mask; res.board = board; res.probabilities = probs;
+    res.logits = logits; res.mask = mask; res.board = board; res.probabilities = probs; res.squares = crops;   /* squares: ABI 5 */
     for (int rep = 0; rep < 3; ++rep)                                         /* eager, graph capture, graph replay */
         CHECK(cv_process_image(eng, eng, image, hw[0], hw[1], 0.5f, 0, 1, &res, NULL));
     printf("pi_found %d\npi_fen %s\npi_orig %s\npi_quad", (int)res.found, res.fen, res.original_fen);
@@ -138,7 +138,9 @@ static int image_mode(const char* unet_blob, const char* resnet_blob, const char
     unsigned long long msum = 0, bsum = 0;
     for (int i = 0; i < 256 * 256; ++i) msum += mask[i];
     for (int i = 0; i < 512 * 512; ++i) bsum += (unsigned long long)board[i] * (unsigned)(i % 251 + 1);
-    printf("\npi_mask_sum %llu\npi_board_checksum %llu\npi_probs", msum, bsum);
+    unsigned long long csum = 0;
+    for (int i = 0; i < 64 * 64 * 64; ++i) csum += (unsigned long long)crops[i] * (unsigned)(i % 253 + 1);
+    printf("\npi_mask_sum %llu\npi_board_checksum %llu\npi_squares_checksum %llu\npi_probs", msum, bsum, csum);
     for (int i = 0; i < 64 * 13; ++i) printf(" %.9g", probs[i]);
     printf("\n");
     int rc = cv_process_image(eng, eng, NULL, 512, 512, 0.5f, 0, 0, &res, NULL);

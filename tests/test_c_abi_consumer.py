@@ -125,6 +125,8 @@ def test_process_image_from_plain_c_equals_the_python_class(tmp_path):
     assert int(lines["pi_mask_sum"]) == int(want.board_extraction.binary_mask.astype(np.uint64).sum())
     board = want.board_extraction.board_image.reshape(-1).astype(np.uint64)
     assert int(lines["pi_board_checksum"]) == int((board * (np.arange(board.size, dtype=np.uint64) % 251 + 1)).sum())
+    crops = ChessVision.extract_squares(want.board_extraction.board_image).reshape(-1).astype(np.uint64)      # the reference's tiling (utils.py:115-132)
+    assert int(lines["pi_squares_checksum"]) == int((crops * (np.arange(crops.size, dtype=np.uint64) % 253 + 1)).sum())
     probs = np.array(lines["pi_probs"].split(), dtype=np.float64).astype(np.float32).reshape(64, 13)
     assert np.array_equal(probs, want.position.model_probabilities)
     assert lines["pi_null_image"].startswith("rc=1 msg=")
