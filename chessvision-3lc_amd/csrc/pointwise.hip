@@ -584,6 +584,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // so the global-load latency and the conversion pass hide behind the MFMA phase and one barrier per square is left (r03:
     // 42 % of the wave cycles were waits with a single set)
     __shared__ __attribute__((aligned(16))) half_t plane[2][NPL][ROWS * LD];
+    __shared__ __attribute__((aligned(16))) char stage[4][16 * 272];      // one pooled row per wave on its way out (see the stores below)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, l15 = lane & 15;
 
@@ -694,18 +695,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             conv_row_max(2 * py + 1, low);
 #pragma unroll
             for (int i = 0; i < 16; ++i) { best[i] = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(carry[i], mid[i]), low[i]), 0.f); carry[i] = low[i]; }
+            // A pooled row of the square = 16 pixels x 64 channels = ONE contiguous run in memory (2-4 KB; the launcher checks that the
+            // tensor holds exactly the stem's 64 channels).  The MFMA leaves a lane with 16 channels of one pixel, i.e. 64 scattered
+            // 16-byte pieces per store instruction; through the wave's LDS corner the run leaves as 1 KB per instruction in full lines
+            // (r05_tuning.md section 15).  Wave-private staging: DS operations of a wave execute in order.  The split-f16 instantiation keeps
+            // its direct stores: there the staging costs 10-12 spilled registers and the kernel is bound by its matrix work anyway.
             const size_t opix = pix_index(dst, sq, py, l15);
+            if constexpr (!__is_same(T, half_t)) {
 #pragma unroll
-            for (int i = 0; i < 16; i += Grp<T>::N) {
-                int par;
-                char* d = grp_ptr<T>(dst, opix, (q * 16 + i) / Grp<T>::N, &par);
-                Grp<T>::store(d, par, best + i, bad);
-            }
-            if constexpr (__is_same(T, half_t) && SPLIT) {
-                if (dst.base32) {
-                    float* d32 = reinterpret_cast<float*>(dst.base32) + opix * dst.Cs + dst.Coff + q * 16;
+                for (int i = 0; i < 16; i += Grp<T>::N) {
+                    int par;
+                    char* d = grp_ptr<T>(dst, opix, (q * 16 + i) / Grp<T>::N, &par);
+                    Grp<T>::store(d, par, best + i, bad);
+                }
+            } else {
+                constexpr int ESZ = Grp<T>::BYTES / Grp<T>::N, PB = 64 * ESZ, SRA = PB + 16;
+                typedef unsigned u4 __attribute__((ext_vector_type(4)));
+                char* const stg = &stage[wave][0];
 #pragma unroll
-                    for (int i = 0; i < 16; i += 4) *reinterpret_cast<f4*>(d32 + i) = f4{best[i], best[i + 1], best[i + 2], best[i + 3]};
+                for (int i = 0; i < 16; i += Grp<T>::N)
+                    Grp<T>::store(stg + l15 * SRA + (q * 16 + i) * ESZ, ((q * 16 + i) / Grp<T>::N) & 1, best + i, bad);
+                asm volatile("" ::: "memory");
+                char* const grow = reinterpret_cast<char*>(dst.base) + pix_index(dst, sq, py, 0) * (size_t)PB;
+#pragma unroll
+                for (int t = 0; t < 16 * PB / 1024; ++t) {
+                    const int o = t * 1024 + lane * 16;
+                    *reinterpret_cast<u4*>(grow + o) = *reinterpret_cast<const u4*>(stg + (o / PB) * SRA + (o % PB));
+                }
+                asm volatile("" ::: "memory");
+                if constexpr (__is_same(T, half_t) && SPLIT) {
+                    if (dst.base32) {
+#pragma unroll
+                        for (int i = 0; i < 16; i += 4)
+                            *reinterpret_cast<f4*>(stg + l15 * 272 + (q * 16 + i) * 4) = f4{best[i], best[i + 1], best[i + 2], best[i + 3]};
+                        asm volatile("" ::: "memory");
+                        char* const grow32 = reinterpret_cast<char*>(dst.base32) + pix_index(dst, sq, py, 0) * (size_t)256;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const int o = t * 1024 + lane * 16;
+                            *reinterpret_cast<u4*>(grow32 + o) = *reinterpret_cast<const u4*>(stg + (o / 256) * 272 + (o % 256));
+                        }
+                        asm volatile("" ::: "memory");
+                    }
                 }
             }
         }
@@ -1036,7 +1067,7 @@ hipError_t stem7x7(int dt, const void* x, bool x_is_u8, int n, const float* w, c
 hipError_t stem_pool_mfma(int dt, const void* x, bool x_is_u8, int n, const void* wpk, const float* scale,
                           const float* shift, int in_exp, const TensorRef& dst, unsigned* flag, unsigned layer_id,
                           hipStream_t s) {
-    if (dt == kF32 || dst.C != 64 || dst.H != 16 || dst.W != 16 || dst.Coff != 0) return hipErrorInvalidValue;
+    if (dt == kF32 || dst.C != 64 || dst.Cs != 64 || dst.H != 16 || dst.W != 16 || dst.Coff != 0) return hipErrorInvalidValue;   // rows of the tensor are contiguous runs
     const dim3 g((unsigned)(n < 2048 ? n : 2048)), b(256);
     const half8* w = reinterpret_cast<const half8*>(wpk);
     const float im = pow2f(-in_exp);
