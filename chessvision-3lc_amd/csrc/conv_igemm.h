@@ -21,6 +21,9 @@ enum ConvCfg {            // <channel tile> x <pixel tile> of one 256-thread wor
 
 hipError_t conv_igemm_prepare();                                   // raise dynamic-LDS limits (once per device)
 hipError_t conv_igemm_launch(int cfg, int ns, int dt, const ConvParams& p, hipStream_t stream);   // ns = LDS ring depth 2|3
+// position-major launch (ConvParams::ptab / pcount / posN / nPtPer set; table-free offsets; unsplit): rows = [output position][image]
+bool conv_cfg_has_pos(int cfg);
+hipError_t conv_igemm_pos_launch(int cfg, int ns, int dt, const ConvParams& p, hipStream_t stream);
 // two independent layers of one tile configuration in ONE launch (conv_igemm_pair_kernel; both with ConvParams::kbase)
 hipError_t conv_igemm_pair_launch(int cfg, int ns, int dt_a, int dt_b, const ConvParams& a, const ConvParams& b, hipStream_t stream);   // dt_a == dt_b, or f32 beside f16
 hipError_t conv_splitk_reduce_launch(int dt, const ConvParams& p, hipStream_t stream);   // second pass of a split-K launch (ConvParams::ksplit > 1)

@@ -32,7 +32,9 @@ namespace cv {
 // SEP: every stage's 8 K chunks are one contiguous 128-byte line of a pixel (all layers with Cin a multiple of the
 // line), so the gather offset is kbase[stage] + 16 * chunk: the per-stage base comes through the scalar cache and no
 // LDS is spent on the offset table (lets two 80 KB workgroups share a CU).
-template <typename T, int CT, int PT, int WGC, int NS, int NW, bool SEP>
+// POS: GEMM rows ordered [output position][image]; the K loop walks only the stages whose tap reads a real pixel at the tile's
+// position (ConvParams::ptab; the 3x3 layers on ResNet-18's 2x2 / 4x4 / 8x8 maps at throughput batch sizes).
+template <typename T, int CT, int PT, int WGC, int NS, int NW, bool SEP, bool POS = false>
 __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvParams p) {
     const unsigned nwg = gridDim.x, bid = blockIdx.x;
 #include "conv_igemm_body.h"
@@ -49,6 +51,7 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm_pair_kernel(const ConvPara
     // two copies of the body, each on its own kernel argument (choosing `p` at run time -- a reference to pa or pb -- makes the compiler
     // park a copy of the 448-byte parameter block in scratch) and each in its own arithmetic: TA != TB is the fp16 classifier, whose
     // shortcut convolutions run on the f32-input MFMA (resnet.cpp)
+    constexpr bool POS = false;
     if (blockIdx.x < a_pad) {
         if (blockIdx.x >= a_n) return;
         typedef TA T;
@@ -181,6 +184,18 @@ static hipError_t launch_one(const ConvParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// position-major launch (ConvParams::ptab): grid = 8 XCDs x output positions x the XCD's share of the (image tile, channel tile) columns
+template <typename T, int CT, int PT, int WGC, int NS, int NW>
+static hipError_t launch_pos(const ConvParams& p, hipStream_t stream) {
+    const size_t lds = (size_t)NS * (CT + PT) * 128;
+    if (lds > 160 * 1024 || !p.kbase || !p.ptab || !p.pcount || !p.porder || p.ksplit > 1 || p.head_w || p.posN <= 0) return hipErrorInvalidValue;
+    if (p.nPtPer != (p.posN + PT - 1) / PT || p.M != p.posN * p.Ho * p.Wo) return hipErrorInvalidValue;
+    auto kern = conv_igemm_kernel<T, CT, PT, WGC, NS, NW, true, true>;
+    const unsigned col_groups = ((unsigned)(p.nPtPer * p.nCt) + 7u) >> 3;          // columns (image tile, channel tile) per XCD
+    hipLaunchKernelGGL(kern, dim3(8u * col_groups * (unsigned)(p.Ho * p.Wo)), dim3(64 * NW), lds, stream, p);
+    return hipGetLastError();
+}
+
 // two layers in one launch (conv_igemm_pair_kernel): same tile configuration, both with table-free gather offsets (SEP)
 template <typename TA, typename TB, int CT, int PT, int WGC, int NS, int NW>
 static hipError_t launch_pair(const ConvParams& a, const ConvParams& b, hipStream_t stream) {
@@ -223,6 +238,12 @@ static hipError_t prepare_one() {
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
+template <typename T, int CT, int PT, int WGC, int NS, int NW>
+static hipError_t prepare_pos() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, CT, PT, WGC, NS, NW, true, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
 // (the 4-wave 128x256 tile and the ring-3 64x256 tile of round 1 lost every sweep and are no longer instantiated)
 #define CV_FOR_EACH_CFG(X, T)              \
     X(T, 64, 128, 1, 3, 4, kCfg64x128)     \
@@ -230,6 +251,11 @@ static hipError_t prepare_one() {
     X(T, 64, 256, 1, 2, 4, kCfg64x256)     \
     X(T, 64, 128, 1, 2, 4, kCfg64x128)     \
     X(T, 128, 128, 2, 2, 4, kCfg128x128)   \
+    X(T, 128, 256, 2, 3, 8, kCfg128x256w8) \
+    X(T, 256, 256, 4, 2, 8, kCfg256x256w8)
+
+// the tiles that take position-major launches: the two 8-wave tiles (what the deep ResNet-18 stages run at throughput sizes)
+#define CV_FOR_EACH_POS_CFG(X, T)          \
     X(T, 128, 256, 2, 3, 8, kCfg128x256w8) \
     X(T, 256, 256, 4, 2, 8, kCfg256x256w8)
 
@@ -241,7 +267,23 @@ hipError_t conv_igemm_prepare() {
     CV_FOR_EACH_CFG(X, float)
     CV_FOR_EACH_CFG(X, split_t)
 #undef X
+#define X(T, CT, PT, WGC, NS, NW, ID) \
+    if ((e = prepare_pos<T, CT, PT, WGC, NS, NW>()) != hipSuccess) return e;
+    CV_FOR_EACH_POS_CFG(X, half_t)
+    CV_FOR_EACH_POS_CFG(X, float)
+    CV_FOR_EACH_POS_CFG(X, split_t)
+#undef X
     return hipSuccess;
+}
+
+bool conv_cfg_has_pos(int cfg) { return cfg == kCfg128x256w8 || cfg == kCfg256x256w8; }
+
+hipError_t conv_igemm_pos_launch(int cfg, int ns, int dt, const ConvParams& p, hipStream_t stream) {
+#define X(T, CT, PT, WGC, NS, NW, ID) \
+    if (cfg == ID && ns == NS) return launch_pos<T, CT, PT, WGC, NS, NW>(p, stream);
+    if (dt == kF16) { CV_FOR_EACH_POS_CFG(X, half_t) } else if (dt == kSplit) { CV_FOR_EACH_POS_CFG(X, split_t) } else { CV_FOR_EACH_POS_CFG(X, float) }
+#undef X
+    return hipErrorInvalidValue;
 }
 
 hipError_t conv_igemm_launch(int cfg, int ns, int dt, const ConvParams& p, hipStream_t stream) {

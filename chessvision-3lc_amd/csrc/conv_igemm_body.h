@@ -1,6 +1,7 @@
 // conv_igemm_body.h -- the body of conv_igemm_kernel / conv_igemm_pair_kernel (conv_igemm.hip), included TEXTUALLY inside both.
-// Expects in scope: the template parameters T, CT, PT, WGC, NS, NW, SEP; `p` (the layer's ConvParams); `nwg` / `bid` (unsigned: the
-// number of workgroups that run this layer and this workgroup's index among them).  A function taking ConvParams by reference or by
+// Expects in scope: the template parameters T, CT, PT, WGC, NS, NW, SEP and the constant POS (position-major rows, ConvParams::ptab);
+// `p` (the layer's ConvParams); `nwg` / `bid` (unsigned: the number of workgroups that run this layer and this workgroup's index
+// among them).  A function taking ConvParams by reference or by
 // value instead changes the register allocation of the production kernels (152 -> 156, 228 -> 232, 254 -> 255 VGPRs, measured on the
 // ISA): the textual form keeps conv_igemm_kernel byte-identical to what it was before the pair kernel existed.
     constexpr int WGP = NW / WGC;
@@ -27,7 +28,7 @@
     // split-K launches: the pixel tiles of one (channel tile, K split) are neighbours -- they stream the SAME weight slab (the large
     // operand of the deep layers these launches serve) and, after the XCD remap above, through the same L2
     int ctTile, ptTile, sBase = 0, nS = p.nStages;
-    if (p.ksplit > 1) {
+    if (!POS && p.ksplit > 1) {
         const int nPt = (p.M + PT - 1) / PT;
         ptTile = lid % nPt;
         const int t = lid / nPt;
@@ -40,6 +41,26 @@
         ptTile = lid / p.nCt;
     }
     const int HoWo = p.Ho * p.Wo;
+    // POS: workgroups differ in K length (a corner position of a 4x4 map walks 4 taps, an interior one 9) and a CU holds ONE of these
+    // tiles at a time, a launch being 2-4 rounds deep -- so the walk is longest-first inside every XCD: with the columns (image tile,
+    // channel tile) dealt round-robin over the XCDs, XCD x (workgroups x, x + 8, ...: dispatched in that order) runs all columns of its
+    // heaviest position class first, the corners last, and the tail of the launch is a short tile instead of a long one (measured
+    // before this order: layer3 0.87 of the unsplit time with 0.69 of the stages; f32, which is MFMA-bound: 0.98).  Workgroups that run
+    // side by side on an XCD are then the same-class positions of the same images: they share input lines (L2) and the weight stages
+    // of their position, and they stay in step because their K loops are equally long.
+    int pos = 0, tImg = 0;
+    if constexpr (POS) {
+        static_assert(SEP, "position-major launches use the table-free gather offsets");
+        const unsigned nCol = (unsigned)(p.nPtPer * p.nCt), nColX = (nCol + 7) >> 3;    // columns per XCD (grid = 8 * nColX * HoWo)
+        const unsigned j = bid >> 3, cl = j % nColX, col = (bid & 7) + 8 * cl;
+        if (col >= nCol) return;                                                          // padding of the last column group
+        ctTile = col / p.nPtPer;
+        tImg = col - ctTile * p.nPtPer;
+        pos = __builtin_amdgcn_readfirstlane(p.porder[j / nColX]);
+        ptTile = tImg;
+        nS = p.pcount[pos];
+    }
+    const int posY = POS ? pos / p.Wo : 0, posX = POS ? pos - posY * p.Wo : 0;
 
     if constexpr (!SEP)
         for (int i = tid; i < nS * 8; i += 64 * NW) koffs[i] = p.koff[sBase * 8 + i];
@@ -49,11 +70,17 @@
 #pragma unroll
     for (int i = 0; i < LX; ++i) {
         int pix = ptTile * PT + (i * NW + wave) * 8 + (lane >> 3);
-        pix = pix < p.M ? pix : p.M - 1;
-        const int n = pix / HoWo;
-        const int rem = pix - n * HoWo;
-        const int oy = rem / p.Wo;
-        const int ox = rem - oy * p.Wo;
+        int n, oy, ox;
+        if constexpr (POS) {
+            n = pix < p.posN ? pix : p.posN - 1;
+            oy = posY; ox = posX;
+        } else {
+            pix = pix < p.M ? pix : p.M - 1;
+            n = pix / HoWo;
+            const int rem = pix - n * HoWo;
+            oy = rem / p.Wo;
+            ox = rem - oy * p.Wo;
+        }
         xoff[i] = (unsigned)((n * p.xHp + oy * p.stride) * p.xWp + ox * p.stride) * (unsigned)p.xCs *
                   (unsigned)sizeof(T);
     }
@@ -64,11 +91,20 @@
     auto issue = [&](int s, int buf) {
         char* sW = smem + buf * STAGE;
         char* sX = sW + CT * 128;
-        const char* gw = wsrc + (size_t)s * (CT * 128);
+        int ws = s, ko;
+        if constexpr (POS) {
+            // {weight stage, gather base} of this position's s-th live stage: one 8-byte load through the scalar cache
+            typedef int i2_t __attribute__((ext_vector_type(2)));
+            typedef const __attribute__((address_space(4))) i2_t* c2ptr_t;
+            const i2_t e = reinterpret_cast<c2ptr_t>(reinterpret_cast<uintptr_t>(p.ptab))[pos * p.nStages + s];
+            ws = e[0];
+            ko = e[1] + myChunk * 16;
+        }
+        const char* gw = wsrc + (size_t)ws * (CT * 128);
 #pragma unroll
         for (int i = 0; i < LW; ++i) glds16(gw + i * (NW * 1024), sW + (i * NW + wave) * 1024);
-        int ko;
-        if constexpr (SEP) {
+        if constexpr (POS) {
+        } else if constexpr (SEP) {
             // constant address space => s_load through the scalar cache (a VGPR load here would make the compiler
             // drain vmcnt, i.e. the whole DMA ring, every stage)
             typedef const __attribute__((address_space(4))) int* cptr_t;
@@ -249,7 +285,7 @@
     // ---- epilogue: BN affine (+ residual) (+ ReLU), convert, 16-B NHWC stores -------------------------
     constexpr int NV = 4 * FC;                          // consecutive channels held by this lane
     const int row0 = ctTile * CT + wci * WCT + q * NV;  // first GEMM row (== channel, by host permutation)
-    if (p.ksplit > 1) {
+    if (!POS && p.ksplit > 1) {                         // (position-major launches are never split, nor do they feed the fused head)
         // split-K: raw accumulators -> partial[split][pixel][channel]; a lane's 16 channels are 64 contiguous bytes, the four
         // lane groups of a pixel cover 256.  conv_splitk_reduce_kernel finishes the layer.
         float* const part = p.partial + (size_t)(sBase / p.kper) * p.M * p.prow + row0;
@@ -281,7 +317,7 @@
     T* const ybase = reinterpret_cast<T*>(p.y);
     const T* const rbase = reinterpret_cast<const T*>(p.res);
 
-    if (p.head_w) {
+    if (!POS && p.head_w) {
         // fused OutConv (UNet outc): 4 lanes (q = 0..3) hold a pixel's 64 channels; nothing is stored but the logit
         float hw[NV];
 #pragma unroll
@@ -329,14 +365,21 @@
 #pragma unroll
     for (int g = 0; g < FP; ++g) {
         const int pix = ptTile * PT + wpi * WPT + g * 16 + l15;
-        const int cp = pix < p.M ? pix : p.M - 1;
-        const int n = cp / HoWo;
-        const int rem = cp - n * HoWo;
-        const int oy = rem / p.Wo;
-        const int ox = rem - oy * p.Wo;
+        int n, oy, ox, plive;
+        if constexpr (POS) {
+            plive = pix < p.posN ? 1 : 0;
+            n = plive ? pix : p.posN - 1;
+            oy = posY; ox = posX;
+        } else {
+            plive = pix < p.M ? 1 : 0;
+            const int cp = plive ? pix : p.M - 1;
+            n = cp / HoWo;
+            const int rem = cp - n * HoWo;
+            oy = rem / p.Wo;
+            ox = rem - oy * p.Wo;
+        }
         const unsigned obase = p.shuffle ? (unsigned)((n * p.yHp + 2 * oy + 1) * p.yWp + 2 * ox + 1)
                                          : (unsigned)((n * p.yHp + oy + 1) * p.yWp + ox + 1);
-        const int plive = pix < p.M ? 1 : 0;
 #pragma unroll
         for (int f = 0; f < FC; ++f) {
             f4 t;

@@ -144,6 +144,16 @@ struct ConvParams {
     char* ch_y32_mid;
     float ch_res_mul[2];
     unsigned ch_layer_id[4];  // numeric-guard ids of the four convolutions
+    // POSITION-MAJOR launch (conv_igemm_kernel<..., POS = true>; round 6: 3x3 layers on the 2x2 / 4x4 / 8x8 maps of ResNet-18 at
+    // throughput batch sizes).  GEMM rows are ordered [output position][image] instead of [image][position], so all rows of a pixel
+    // tile share ONE output position (oy, ox) and therefore one set of taps that read a real pixel: the K loop walks only those
+    // stages (`ptab`), the taps that would gather the zero border -- 5 of 9 at every position of a 2x2 map -- are never fetched nor
+    // multiplied.  A skipped stage would have added exact zeros, so every output keeps its K order and its bits.  Null ptab = off.
+    const int* ptab;          // [Ho*Wo][nStages][2]: {weight stage index, gather base (kbase of that stage)} of the live stages, K order
+    const int* pcount;        // [Ho*Wo] live stages of each position
+    const int* porder;        // [Ho*Wo] positions by falling stage count: the walk starts the long K loops first (see conv_igemm_body.h)
+    int posN;                 // images in the launch = rows per position
+    int nPtPer;               // pixel tiles per position = ceil(posN / PT)
 };
 
 }  // namespace cv

@@ -299,11 +299,61 @@ Status ConvLayer::get_koff(const TensorRef& x, const int** chunks, const int** b
             base[s] = tab[(size_t)s * 8];
             for (int c = 0; c < 8; ++c) kt->separable = kt->separable && tab[(size_t)s * 8 + c] == base[s] + 16 * c;
         }
-        if (kt->separable) CV_TRY(kt->bases.upload(base.data(), base.size() * sizeof(int)));
+        if (kt->separable) { CV_TRY(kt->bases.upload(base.data(), base.size() * sizeof(int))); kt->h_bases = base; }
         it = koff.emplace(key, std::move(kt)).first;
     }
     *chunks = reinterpret_cast<const int*>(it->second->chunks.ptr);
     *bases = it->second->separable ? reinterpret_cast<const int*>(it->second->bases.ptr) : nullptr;
+    return Status();
+}
+
+// Position-major launches: for every output position (oy, ox) the list of K stages whose tap (ky, kx) lands on a real input pixel --
+// iy = oy * stride + ky - 1 in [0, H), ix likewise -- in K order, each as {stage index (selects the weight slab), gather base of that
+// stage}.  Stages of taps that would read the zero border contribute exact zeros and are left out.  3x3 / pad-1 layers whose stages hold
+// one tap each (Cin a multiple of the 128-byte line, i.e. table-free offsets) only.
+Status ConvLayer::get_pos(const TensorRef& x, int Ho, int Wo, const int** tab, const int** count, const int** order, double* live) {
+    const PosKey key{x.H + 2, x.W + 2, x.Cs, x.Coff};
+    auto it = pos.find(key);
+    if (it == pos.end()) {
+        if (capture_flag()) return fail(1, name + ": position table created during graph capture");
+        const int* chunks = nullptr;
+        const int* bases = nullptr;
+        CV_TRY(get_koff(x, &chunks, &bases));
+        const auto kt = koff.find(KoffKey{x.W + 2, x.Cs, x.Coff});
+        if (k != 3 || shuffle || !bases || kt == koff.end() || (int)kt->second->h_bases.size() != nStages || nStages % 9 != 0)
+            return fail(1, name + ": layer cannot run position-major");
+        std::vector<int> t((size_t)Ho * Wo * nStages * 2, 0), cnt((size_t)Ho * Wo, 0);
+        long long total = 0;
+        for (int oy = 0; oy < Ho; ++oy)
+            for (int ox = 0; ox < Wo; ++ox) {
+                const int ps = oy * Wo + ox;
+                int n = 0;
+                for (int s = 0; s < nStages; ++s) {
+                    int tap, ci;
+                    k_decode(kgroup, 9, chunk_k0(dt, s * 8), &tap, &ci);      // a stage = one tap of one channel block
+                    const int iy = oy * stride + tap / 3 - 1, ix = ox * stride + tap % 3 - 1;
+                    if (iy < 0 || iy >= x.H || ix < 0 || ix >= x.W) continue;
+                    t[((size_t)ps * nStages + n) * 2] = s;
+                    t[((size_t)ps * nStages + n) * 2 + 1] = kt->second->h_bases[(size_t)s];
+                    ++n;
+                }
+                cnt[(size_t)ps] = n;
+                total += n;
+            }
+        auto pt = std::make_unique<PosTab>();
+        CV_TRY(pt->tab.upload(t.data(), t.size() * sizeof(int)));
+        CV_TRY(pt->count.upload(cnt.data(), cnt.size() * sizeof(int)));
+        std::vector<int> ord((size_t)Ho * Wo);                      // positions by falling stage count (ties: raster order)
+        for (size_t i = 0; i < ord.size(); ++i) ord[i] = (int)i;
+        std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return cnt[(size_t)a] > cnt[(size_t)b]; });
+        CV_TRY(pt->order.upload(ord.data(), ord.size() * sizeof(int)));
+        pt->live = (double)total / ((double)Ho * Wo * nStages);
+        it = pos.emplace(key, std::move(pt)).first;
+    }
+    *tab = reinterpret_cast<const int*>(it->second->tab.ptr);
+    *count = reinterpret_cast<const int*>(it->second->count.ptr);
+    *order = reinterpret_cast<const int*>(it->second->order.ptr);
+    *live = it->second->live;
     return Status();
 }
 
@@ -327,6 +377,9 @@ struct Knobs {
     int splitk_halo_stage_ns = env_int("CV_SPLITK_HALO_STAGE_NS", 500);
     // two independent layers in one launch (Engine::PendingConv): only while their workgroups together leave the chip unfilled
     int pair = env_int("CV_PAIR", 1), pair_max_blocks = env_int("CV_PAIR_MAX_BLOCKS", 512);
+    // position-major rows + live-tap stage lists (ConvParams::ptab): 0 = off; at least pos_min_tiles pixel tiles of images per position;
+    // maps up to pos_max_hw on a side
+    int pos = env_int("CV_POS", 1), pos_min_tiles = env_int("CV_POS_MIN_TILES", 1), pos_max_hw = env_int("CV_POS_MAX_HW", 8);
 };
 static const Knobs& knobs() {
     static const Knobs k;
@@ -637,6 +690,20 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
         } else split_kind = 0;
     }
     if (halo && split_kind == 2) p.nCt = (L.rows + ct - 1) / ct;      // the halo kernel's channel tiles
+    // Position-major rows (round 6): the generic kernel's 3x3 launches on small maps -- ResNet-18 layer3 / layer4 and the stride-2 conv1
+    // of layer2-4 -- multiply the zero border at every border position: 5 of 9 taps everywhere on a 2x2 map, 31 % of the stages on 4x4.
+    // With at least a pixel tile of images per position the rows are ordered [position][image] and each tile walks its live taps only.
+    bool pos_major = false;
+    if (knobs().pos && !halo && L.k == 3 && !L.shuffle && p.kbase && p.ksplit <= 1 && !head && !fuse0 && conv_cfg_has_pos(cfg) &&
+        x.N >= conv_cfg_pt(cfg) * knobs().pos_min_tiles && std::min(Ho, Wo) <= knobs().pos_max_hw && L.nStages % 9 == 0) {
+        const int* ptab = nullptr;
+        const int* pcount = nullptr;
+        const int* porder = nullptr;
+        double live = 1.0;
+        CV_TRY(L.get_pos(x, Ho, Wo, &ptab, &pcount, &porder, &live));
+        p.ptab = ptab; p.pcount = pcount; p.porder = porder; p.posN = x.N; p.nPtPer = (x.N + conv_cfg_pt(cfg) - 1) / conv_cfg_pt(cfg);
+        pos_major = true;
+    }
     if (fuse0) {
         if (!halo || !conv_halo_can_fuse_first_layer(ct, dt)) { Status ns; ns.code = kNotFused; return ns; }   // caller runs the layers apart
         p.f0_x = fuse0->x; p.f0_u8 = fuse0->u8 ? 1 : 0; p.f0_w = fuse0->w; p.f0_scale = fuse0->scale; p.f0_shift = fuse0->shift;
@@ -680,9 +747,9 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
         else
             prof.back().kernel = std::string("conv_igemm_kernel<") + tn + "," + std::to_string(conv_cfg_ct(cfg)) + "x" +
                                  std::to_string(conv_cfg_pt(cfg)) + ",ring" + std::to_string(ns) + (L.shuffle ? ",shuffle" : "") +
-                                 (p.ksplit > 1 ? ",splitK" + std::to_string(p.ksplit) : std::string()) + ">";
+                                 (p.ksplit > 1 ? ",splitK" + std::to_string(p.ksplit) : std::string()) + (pos_major ? ",POS" : "") + ">";
     }
-    if (defer && knobs().pair && !halo && !profiling && !calibrating && !stamp_dev && !head && !fuse0 && p.kbase && !(pool_out && !fuse_pool) &&
+    if (defer && knobs().pair && !halo && !pos_major && !profiling && !calibrating && !stamp_dev && !head && !fuse0 && p.kbase && !(pool_out && !fuse_pool) &&
         !(defer_first && p.ksplit > 1) &&
         blocks_for(L.rows, p.M, conv_cfg_ct(cfg), conv_cfg_pt(cfg)) * (p.ksplit > 1 ? p.ksplit : 1) <= knobs().pair_max_blocks) {
         defer->held = true; defer->cfg = cfg; defer->ns = ns; defer->dt = dt; defer->p = p; defer->name = L.name;
@@ -691,7 +758,7 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
     }
     // launches with fewer 16 x 16 patches than the chip holds workgroups (2 per CU) take the 8 x 16 patch: twice the workgroups
     const int th = (halo && halo_th8_for(L, p, ct, Ho, fuse0 != nullptr)) ? 8 : 16;
-    hipError_t e = halo ? conv_halo_launch(ct, dt, p, x.N, s, th) : conv_igemm_launch(cfg, ns, dt, p, s);
+    hipError_t e = halo ? conv_halo_launch(ct, dt, p, x.N, s, th) : pos_major ? conv_igemm_pos_launch(cfg, ns, dt, p, s) : conv_igemm_launch(cfg, ns, dt, p, s);
     if (e == hipSuccess && p.ksplit > 1) e = conv_splitk_reduce_launch(dt, p, s);
     if (profiling) prof_end(s);
     if (stamp_dev) {

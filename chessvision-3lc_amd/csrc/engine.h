@@ -144,8 +144,14 @@ struct ConvLayer {
     // koff tables are geometry dependent: keyed by (xWp, xCs, xCoff)
     struct KoffKey { int xWp, xCs, xCoff; bool operator<(const KoffKey& o) const {
         if (xWp != o.xWp) return xWp < o.xWp; if (xCs != o.xCs) return xCs < o.xCs; return xCoff < o.xCoff; } };
-    struct KoffTab { DeviceBuffer chunks, bases; bool separable = false; };
+    struct KoffTab { DeviceBuffer chunks, bases; bool separable = false; std::vector<int> h_bases; };
     std::map<KoffKey, std::unique_ptr<KoffTab>> koff;
+    // position-major launches (ConvParams::ptab): per output position the K stages whose tap reads a real pixel; geometry dependent
+    struct PosKey { int xHp, xWp, xCs, xCoff; bool operator<(const PosKey& o) const {
+        if (xHp != o.xHp) return xHp < o.xHp; if (xWp != o.xWp) return xWp < o.xWp; if (xCs != o.xCs) return xCs < o.xCs; return xCoff < o.xCoff; } };
+    struct PosTab { DeviceBuffer tab, count, order; double live = 1.0; };     // live = mean fraction of the stages a position walks
+    std::map<PosKey, std::unique_ptr<PosTab>> pos;
+    Status get_pos(const TensorRef& x, int Ho, int Wo, const int** tab, const int** count, const int** order, double* live);
 
     // w_oihw: (cout, cin, k, k); scale/shift: (cout)
     Status build_conv(const std::string& name_, int dt_, const float* w_oihw, int cout_, int cin_, int k_,

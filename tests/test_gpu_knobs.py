@@ -233,3 +233,64 @@ def test_upsample_2x2_block_kernel_gives_the_bits_of_the_one_output_kernel():
         assert out.returncode == 0 and "SHA" in out.stdout, (name, out.stdout[-500:], out.stderr[-3000:])
         shas[name] = out.stdout.split("SHA", 1)[1].split()[0]
     assert shas["block"] == shas["single"], shas
+
+
+POS_SCRIPT = r"""
+import hashlib, os, sys
+sys.path.insert(0, "ROOT"); sys.path.insert(0, "ROOT/chessvision-3lc_amd")
+import torch
+from chessvision.hip_backend import HipEngine
+from oracle import synth
+net = synth.make_resnet(2)
+chunk = int(os.environ.get("POS_CHUNK", "1024"))
+counts = [int(v) for v in os.environ.get("POS_N", "256,300,700").split(",")]
+precs = os.environ.get("POS_PRECS", "f16x3,f32,f16,f16r").split(",")
+want_pos = os.environ.get("CV_POS", "1") != "0"
+h = hashlib.sha256()
+tagged = set()
+for prec in precs:
+    eng = HipEngine(precision=prec, resnet_chunk=chunk)
+    eng.load_resnet18(net.state_dict())
+    for n in counts:
+        sq = synth.squares_input(300 + n, n)
+        got = eng.resnet18_forward(sq.cuda()).cpu()
+        again = eng.resnet18_forward(sq.cuda()).cpu()
+        assert torch.equal(got, again), "not deterministic"
+        h.update((got + 0.0).numpy().tobytes())               # + 0.0: a skipped all-zero stage may flip the sign of an exact zero
+        for tap in ("layer2.0.act1", "layer3.0.act1", "layer3", "layer4.0.act1", "layer4"):
+            h.update((torch.from_numpy(eng.activation("resnet18", tap)) + 0.0).numpy().tobytes())
+        if n <= 1024 and prec in ("f16x3", "f32"):
+            with torch.no_grad():
+                err = float((got - net(sq)).abs().max())
+            assert err <= 1e-3, (prec, n, err)
+    entries = eng.profile("resnet18", synth.squares_input(5, counts[-1]))[3]
+    tagged |= {e["name"] for e in entries if ",POS" in e["kernel"]}
+    eng.check_numerics()
+    eng.close()
+assert bool(tagged) == want_pos, tagged
+print("POSLAYERS", ",".join(sorted(tagged)) or "-")
+print("SHA", h.hexdigest())
+"""
+
+
+@pytest.mark.parametrize("shape", ["forced_small", "production_chunk"])
+def test_position_major_rows_skip_the_zero_border_and_keep_every_bit(shape):
+    """Round 6: the generic kernel's 3x3 launches on the 2x2 / 4x4 / 8x8 maps of ResNet-18 order their rows [output position][image] and
+    walk only the K stages whose tap reads a real pixel (ConvParams::ptab): 5 of 9 taps of every position of a 2x2 map gather the zero
+    border.  A skipped stage would have added exact zeros, so logits and the layer2-4 activations are BIT-IDENTICAL to CV_POS=0 -- in all
+    four precisions, on full and ragged image tiles (256 / 300 / 700 squares with the 256-pixel tiles forced), and at the production
+    chunk of 16384 squares where the 256 x 256 tile takes layer3 / layer4 by itself."""
+    base = {"POS_CHUNK": "1024", "POS_N": "256,300,700", "CV_CONV_PT": "256", "CV_SPLITK": "0"} if shape == "forced_small" else \
+           {"POS_CHUNK": "16384", "POS_N": "16384", "POS_PRECS": "f16x3,f16r"}
+    shas, layers = {}, {}
+    for name, knobs in (("pos", {}), ("image_major", {"CV_POS": "0"})):
+        env = dict(os.environ)
+        env.update(base)
+        env.update(knobs)
+        out = subprocess.run([sys.executable, "-c", POS_SCRIPT.replace("ROOT", str(ROOT))], env=env, capture_output=True, text=True, timeout=1800)
+        assert out.returncode == 0 and "SHA" in out.stdout, (name, out.stdout[-500:], out.stderr[-3000:])
+        shas[name] = out.stdout.split("SHA", 1)[1].split()[0]
+        layers[name] = out.stdout.split("POSLAYERS", 1)[1].split()[0]
+    assert shas["pos"] == shas["image_major"], shas
+    for must in ("layer3.1.conv1", "layer4.0.conv1", "layer4.1.conv2"):
+        assert must in layers["pos"], layers
