@@ -77,6 +77,8 @@ class ChessVision:
         self._native_lock = threading.Lock()            # the single-image path shares its staging buffers between request threads
         self._stage: dict = {}
         self._last_board = None                         # (board array of the last native extraction, its squares on the device)
+        self._f32_twin: ChessVision | None = None       # exact-f32 instance of the same checkpoints, created on the first numeric-guard trip
+        self._guard_logged: set = set()
         if not lazy_load:
             logger.info("Eager loading models...")
             self._initialize_board_extractor()
@@ -157,7 +159,7 @@ class ChessVision:
         logger.info("Starting image processing pipeline...")
         started = time.time()
         if image.shape[2] == 3 and self._native(self.board_extractor) and self._native(self.classifier):
-            return self._process_image_native(image, threshold, flip, started)
+            return self._recover(lambda cv: cv._process_image_native(image, threshold, flip, started))
         board_result = self.extract_board(image, threshold)
         position_result = None
         if board_result.board_image is None:
@@ -172,6 +174,34 @@ class ChessVision:
 
     predict = process_image                                  # name used by BASELINE.json's north_star
 
+    # ---- numeric-guard recovery (the reference never fails on an image: core.py:152-195 has no failure mode here) -----------------
+    def _recover(self, run):
+        """``run(self)``; when an f16-based engine trips its numeric guard (``NumericRangeError``: an activation of THIS checkpoint on
+        THIS image left the range f16 storage holds after calibration) the request is repeated on an exact-f32 instance of the same
+        checkpoints -- native kernels on the f32-input MFMA, created on first use, never the oracle -- and that result is returned.
+        The tripping layer is logged once per layer.  Only the serve-path methods recover; direct engine calls
+        (``HipEngine.unet_forward`` ...) keep raising, and an instance that already runs in f32 has nothing to fall back to."""
+        from .hip_backend import NumericRangeError
+
+        try:
+            return run(self)
+        except NumericRangeError as exc:
+            if set(self._precision.split("+")) <= {"f32", "fp32", "float32"}:
+                raise
+            if exc.layer not in self._guard_logged:
+                self._guard_logged.add(exc.layer)
+                logger.warning(f"numeric guard tripped at '{exc.layer}' ({self._precision}); re-running the request on the exact f32 engine. {exc}")
+            return run(self._get_f32_twin())
+
+    def _get_f32_twin(self) -> "ChessVision":
+        with self._init_lock:
+            if self._f32_twin is None:
+                self._f32_twin = ChessVision(board_extractor_weights=self._board_extractor_weights,
+                                             board_extractor_model_id=self._board_extractor_model_id,
+                                             classifier_weights=self._classifier_weights,
+                                             classifier_model_id=self._classifier_model_id, lazy_load=True, precision="f32")
+        return self._f32_twin
+
     def _native(self, model) -> bool:
         from .hip_backend import _HipModel
         return isinstance(model, _HipModel)
@@ -181,7 +211,7 @@ class ChessVision:
         docstring); any other model object gets the reference's literal tensor path and the numpy stages."""
         model = self.board_extractor
         if self._native(model) and image.ndim == 3 and image.shape[2] == 3 and image.dtype == np.uint8:
-            return self._extract_board_native(model.engine, image, threshold)
+            return self._recover(lambda cv: cv._extract_board_native(cv.board_extractor.engine, image, threshold))
         comp_image = classical.resize_area(image, constants.INPUT_SIZE)
         batch = torch.Tensor(np.array([comp_image])) / 255           # (1,256,256,3) float32, channels as given
         batch = batch.permute(0, 3, 1, 2).to(self.device)
@@ -193,7 +223,7 @@ class ChessVision:
         """Reference core.py:225-249 + 309-355."""
         model = self.classifier
         if self._native(model) and board_image.dtype == np.uint8 and board_image.shape == (constants.BOARD_SIZE[1], constants.BOARD_SIZE[0]):
-            return self._classify_position_native(model.engine, board_image, flip)
+            return self._recover(lambda cv: cv._classify_position_native(cv.classifier.engine, board_image, flip))
         squares = self.extract_squares(board_image)
         square_names = constants.SQUARE_NAMES_FLIPPED if flip else constants.SQUARE_NAMES_NORMAL
         batch = torch.Tensor(squares).permute(0, 3, 1, 2).to(self.device)
@@ -309,6 +339,15 @@ class ChessVision:
                        fallback_quad: bool = False, pipeline_chunk: int = 64, return_crops: bool = True,
                        timings: dict | None = None, first_job: int | None = None,
                        last_job: int | None = None) -> list[ChessVisionResult]:
+        """Batched pipeline: see ``_process_images_native`` (this wrapper adds the numeric-guard recovery: a call whose f16-based
+        engine reports a non-finite value is repeated as a whole on the exact-f32 instance, ``_recover``)."""
+        return self._recover(lambda cv: cv._process_images_native(images, threshold, flip, fallback_quad, pipeline_chunk, return_crops,
+                                                                  timings, first_job, last_job))
+
+    def _process_images_native(self, images: Sequence[NDArray[np.uint8]], threshold: float = 0.5, flip: bool = False,
+                               fallback_quad: bool = False, pipeline_chunk: int = 64, return_crops: bool = True,
+                               timings: dict | None = None, first_job: int | None = None,
+                               last_job: int | None = None) -> list[ChessVisionResult]:
         """Batched pipeline (new; the reference processes one image per call, core.py:152-195).
 
         Images stay on the device between the two CNNs: INTER_AREA resize -> UNet (u8 in, logits + thresholded mask out);

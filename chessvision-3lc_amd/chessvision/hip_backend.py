@@ -28,8 +28,21 @@ _PRECISIONS = {"f32": PREC_F32, "fp32": PREC_F32, "float32": PREC_F32, "f16": PR
 _PREC_NAMES = {PREC_F32: "f32", PREC_F16: "f16", PREC_F16X3: "f16x3", PREC_F16R: "f16r"}
 
 
+CV_ERR_NUMERIC = 5                               # include/chessvision_hip.h
+
+
 class HipBackendError(RuntimeError):
     """Raised for every non-zero status of the C ABI (message = ``cv_last_error()``)."""
+
+
+class NumericRangeError(HipBackendError):
+    """CV_ERR_NUMERIC: a layer of an f16-based engine stored a non-finite value (an activation left the range the engine can hold, or
+    a NaN reached it); the results of the call are invalid.  ``layer`` names the first such layer.  ``ChessVision.process_image`` /
+    ``process_images`` / ``extract_board`` / ``classify_position`` catch it and repeat the request on an exact-f32 engine."""
+
+    def __init__(self, message: str):
+        super().__init__(message)
+        self.layer = message.split("produced by '", 1)[1].split("'", 1)[0] if "produced by '" in message else "input tensor"
 
 
 class _ImageResult(ctypes.Structure):             # mirrors cv_image_result_t (include/chessvision_hip.h); the pointer fields as plain
@@ -134,7 +147,8 @@ def load_library():
 def _check(status: int) -> None:
     if status != 0:
         msg = load_library().cv_last_error()
-        raise HipBackendError(f"[cv status {status}] {msg.decode(errors='replace') if msg else 'unknown error'}")
+        text = f"[cv status {status}] {msg.decode(errors='replace') if msg else 'unknown error'}"
+        raise NumericRangeError(text) if status == CV_ERR_NUMERIC else HipBackendError(text)
 
 
 def _stream_ptr(device: torch.device) -> int:

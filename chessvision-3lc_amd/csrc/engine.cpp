@@ -154,6 +154,13 @@ static Status finish_layer(ConvLayer& L, std::vector<float>& Wk, int K, const st
         L.h_shift[r] = shift[r];
         if (!std::isfinite(L.h_scale[r])) return fail(1, L.name + ": weight magnitude x BatchNorm scale leaves the f32 range");
     }
+    L.h_shift_base = L.h_shift;
+    if (L.want_round_err && L.dt == kF16) {             // (w - w_hat) of the normalised rows, for the rounding-bias correction
+        L.Kerr = K;
+        L.h_round_err.resize((size_t)L.rows * K);
+        for (size_t i = 0; i < L.h_round_err.size(); ++i) L.h_round_err[i] = Wk[i] - (float)(_Float16)Wk[i];
+        L.tap_sum.clear(); L.tap_count = 0;
+    }
     std::vector<char> packed;
     pack_rows(L.dt, packed, CT, L.nCt, L.nStages, L.rows, K, Wk);
     CV_TRY(L.w.upload(packed.data(), packed.size()));
@@ -191,6 +198,22 @@ Status ConvLayer::set_input_split(int split, int delta, hipStream_t s) {
         }
     in_split = split; in_delta = delta;
     return finish_layer(*this, Wk, Kdim, b_scale, b_shift);
+}
+
+// shift[r] += scale[r] * sum_k (w - w_hat)[r][k] * mean(x_stored[k]) * 2^in_exp -- see ConvLayer::want_round_err
+Status ConvLayer::fold_rounding_bias() {
+    if (h_round_err.empty() || tap_sum.empty() || tap_count <= 0 || (int)tap_sum.size() != Kerr || h_shift_base.size() != h_shift.size())
+        return Status();
+    for (int r = 0; r < rows; ++r) {
+        const float* e = h_round_err.data() + (size_t)r * Kerr;
+        double acc = 0.0;
+        for (int k = 0; k < Kerr; ++k) acc += (double)e[k] * tap_sum[(size_t)k];
+        const double corr = std::ldexp(acc / tap_count * (double)h_scale[r], tap_in_exp);
+        if (!std::isfinite(corr)) return fail(1, name + ": rounding-bias correction is not finite");
+        h_shift[r] = (float)((double)h_shift_base[r] + corr);
+    }
+    in_exp = out_exp = 1 << 20;                         // no tensor carries this exponent: the next set_exps re-uploads
+    return Status();
 }
 
 // Re-fold the tensor exponents into the device copies of the epilogue constants (only when they change: calibration).
@@ -231,6 +254,7 @@ Status ConvLayer::build_conv(const std::string& name_, int dt_, const float* w_o
                              int stride_, const float* scale_, const float* shift_, int cinPad_, int64_t pixels_hint_, int out_hw_) {
     name = name_; dt = dt_; cin = cin_; cinPad = cinPad_; cout = cout_; k = k_; stride = stride_;
     shuffle = false; rows = cout_; pixels_hint = pixels_hint_;
+    want_round_err = dt_ == kF16 && calibration_enabled() && bias_correction_enabled();
     halo_ok = k_ == 3 && stride_ == 1 && out_hw_ > 0 && (out_hw_ % 16 == 0 || (out_hw_ == 8 && cout_ % 128 == 0)) &&
               cinPad_ % (128 / dtype_size(dt_)) == 0;
     halo_img8 = out_hw_ == 8;
@@ -447,6 +471,10 @@ bool calibration_enabled() {
     static const bool on = env_int("CV_CALIBRATE", 1) != 0;
     return on;
 }
+bool bias_correction_enabled() {
+    static const bool on = env_int("CV_BIAS_CORR", 1) != 0;
+    return on;
+}
 
 // ---- engine --------------------------------------------------------------------------------------
 Engine::Engine() {
@@ -541,6 +569,33 @@ Status Engine::measure(const TensorRef& t, hipStream_t s) {
     return Status();
 }
 
+// rounding-bias calibration: accumulate, for K index k = (channel block, tap, channel), the sum of the layer's stored input under that
+// tap over this launch's images and output positions (in units of the FIRST half's exponent: a concatenated input's second half is
+// held 2^exp_delta smaller, and its weights carry that factor -- ConvLayer::set_input_split -- so stored values are what the MFMA sees)
+Status Engine::measure_tap_sums(ConvLayer& L, const TensorRef& x, int Ho, int Wo, hipStream_t s) {
+    if (L.h_round_err.empty() || L.dt != kF16 || L.shuffle || x.f32_only) return Status();
+    const int taps = L.k * L.k, C = x.C;
+    if (L.Kerr != taps * L.cinPad || C != L.cinPad) return Status();
+    const int slices = std::min(x.N, 64);
+    const size_t need = (size_t)slices * taps * C * sizeof(double);
+    if (bias_ws.bytes < need) CV_TRY(bias_ws.alloc(std::max(need, (size_t)1 << 20), false));
+    CV_HIP(tap_sums_f16(x, Ho, Wo, L.stride, L.k, slices, reinterpret_cast<double*>(bias_ws.ptr), s));
+    std::vector<double> part((size_t)slices * taps * C);
+    CV_HIP(hipMemcpyAsync(part.data(), bias_ws.ptr, need, hipMemcpyDeviceToHost, s));
+    CV_HIP(hipStreamSynchronize(s));
+    if (L.tap_sum.empty()) { L.tap_sum.assign((size_t)L.Kerr, 0.0); L.tap_in_exp = x.exp; }
+    if (L.tap_in_exp != x.exp) return fail(1, L.name + ": input exponent changed inside the rounding-bias pass");
+    for (int kk = 0; kk < L.Kerr; ++kk) {
+        int tap, ci;
+        k_decode(L.kgroup, taps, kk, &tap, &ci);
+        double t = 0.0;
+        for (int sl = 0; sl < slices; ++sl) t += part[((size_t)sl * taps + tap) * C + ci];      // fixed order: reproducible
+        L.tap_sum[(size_t)kk] += t;
+    }
+    L.tap_count += (double)x.N * Ho * Wo;
+    return Status();
+}
+
 size_t Engine::workspace_bytes() const {
     size_t total = 0;
     if (unet) for (const Activation* a : unet->acts) total += a->buf.bytes + a->buf32.bytes;
@@ -586,6 +641,7 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
     // tensor exponents (Activation): the fused head writes f32 logits, i.e. an output at exponent 0
     const int out_exp = head ? 0 : y.exp;
     if (x.exp_delta != 0 || L.in_delta != 0) CV_TRY(L.set_input_split(x.split, x.exp_delta, s));
+    if (bias_measuring) CV_TRY(measure_tap_sums(L, x, Ho, Wo, s));
     CV_TRY(L.set_exps(x.exp, out_exp, s));
     p.scale = reinterpret_cast<const float*>(L.scale.ptr);
     p.shift = reinterpret_cast<const float*>(L.shift.ptr);

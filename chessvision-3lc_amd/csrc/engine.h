@@ -141,6 +141,21 @@ struct ConvLayer {
     int Kdim = 0, in_split = 0, in_delta = 0;
     Status set_input_split(int split, int delta, hipStream_t s);
     unsigned layer_id = 0xfffffffeu;                // numeric guard id (Engine::register_layer)
+    // Rounding-bias correction of the f16 layers (round 6).  An f16 weight is w_hat = w + e with |e| <= 2^-12 |w|, and the e of a
+    // layer are the same for every pixel of every image: through post-ReLU inputs (positive mean) they add a CONSTANT offset
+    // sum_k e[r][k] * mean(x[k]) to output channel r that no spatial pooling averages away -- 70 % of the fp16 classifier's logit
+    // error variance, against 30 % from the (independent, zero-mean) roundings of the activations.  At load time the mean of the
+    // layer's stored input under every tap is measured on the calibration batch (Engine::measure_tap_sums), and the offset goes into
+    // the f32 epilogue shift with the opposite sign... i.e. shift += scale * sum_k (w - w_hat)[r][k] * mean(x[k]).  Exact arithmetic is
+    // untouched (the term is what exact weights would have added on the calibration mean), no launch changes.  CV_BIAS_CORR=0: off.
+    bool want_round_err = false;                    // build_*: keep (w - w_hat) of the normalised rows until the correction is folded
+    std::vector<float> h_round_err;                 // [rows][Kdim_err] in the K order of the packed rows; released after calibration
+    int Kerr = 0;
+    std::vector<float> h_shift_base;                // h_shift without the correction
+    std::vector<double> tap_sum;                    // [Kerr] sum of the stored input under (tap, channel) of K index k, calibration batch
+    double tap_count = 0;                           // output positions x images those sums cover
+    int tap_in_exp = 0;                             // exponent of the input's first half while measured
+    Status fold_rounding_bias();                    // h_shift = h_shift_base + correction; forces set_exps to re-upload
     // koff tables are geometry dependent: keyed by (xWp, xCs, xCoff)
     struct KoffKey { int xWp, xCs, xCoff; bool operator<(const KoffKey& o) const {
         if (xWp != o.xWp) return xWp < o.xWp; if (xCs != o.xCs) return xCs < o.xCs; return xCoff < o.xCoff; } };
@@ -222,6 +237,12 @@ class Engine {
     bool calibrating = false;
     DeviceBuffer cal_word;
     Status measure(const TensorRef& t, hipStream_t s);   // t.f32_only: read as f32
+    // rounding-bias calibration pass (ConvLayer::want_round_err): while set, run_conv accumulates the tap sums of every f16 layer's input
+    bool bias_measuring = false;
+    DeviceBuffer bias_ws;
+    Status measure_tap_sums(ConvLayer& L, const TensorRef& x, int Ho, int Wo, hipStream_t s);
+    // one pass of `forward` over the calibration batch with the tap sums switched on, then every layer of `layers` folds its correction
+    template <class Fwd> Status calibrate_rounding_bias(const std::vector<ConvLayer*>& layers, Fwd&& forward, hipStream_t s);
     template <class Fwd> Status calibrate(const std::vector<Activation*>& acts, Fwd&& forward, hipStream_t s, const char* what);
     size_t workspace_bytes() const;
 
@@ -285,6 +306,7 @@ class Engine {
 };
 
 bool calibration_enabled();                         // CV_CALIBRATE=0 switches the activation exponents off (tests of the guard)
+bool bias_correction_enabled();                     // CV_BIAS_CORR=0 switches the rounding-bias correction of the f16 layers off
 int choose_ct(int rows, int64_t pixels_hint, bool halo_ok, bool img8);
 int choose_cfg(int ct, int rows, int64_t pixels, int n_stages);
 int choose_ns(int cfg, int dt, int rows, int64_t pixels, int n_stages);
@@ -336,6 +358,25 @@ Status Engine::calibrate(const std::vector<Activation*>& acts, Fwd&& forward, hi
         if (!changed) return Status();
     }
     return fail(1, std::string(what) + ": activation range calibration did not converge (non-finite weights or activations beyond f32?)");
+}
+
+template <class Fwd>
+Status Engine::calibrate_rounding_bias(const std::vector<ConvLayer*>& layers, Fwd&& forward, hipStream_t s) {
+    if (dt != kF16 || !calibration_enabled() || !bias_correction_enabled()) return Status();
+    for (ConvLayer* L : layers) { L->tap_sum.clear(); L->tap_count = 0; }
+    calibrating = true;                                 // the layer-by-layer schedule: every f16 layer's input exists in memory
+    bias_measuring = true;
+    Status st = forward();
+    bias_measuring = false;
+    calibrating = false;
+    if (!st.ok()) return st;
+    CV_HIP(hipStreamSynchronize(s));
+    CV_HIP(hipMemset(guard.ptr, 0xff, sizeof(unsigned)));
+    for (ConvLayer* L : layers) {
+        CV_TRY(L->fold_rounding_bias());
+        std::vector<float>().swap(L->h_round_err);      // 4 bytes per weight of host memory: not needed again
+    }
+    return Status();
 }
 
 // Replay `run` (a launch sequence on the stream it is handed; no allocation, no synchronisation once warmed) through a cached graph.

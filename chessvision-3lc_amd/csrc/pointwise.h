@@ -21,6 +21,10 @@ hipError_t upsample_bilinear2x(int dt, const TensorRef& src, const TensorRef& ds
 // max |stored value| of the slice, as float bits (>= 0x7f800000: a non-finite value is present); *out must start at 0
 hipError_t absmax(int dt, const TensorRef& src, unsigned* out, hipStream_t s);
 
+// rounding-bias calibration: out[slice][tap][c] (double, slices x k*k x src.C) = sum of the stored f16 input under tap (ky, kx) over
+// the slice's images and all Ho x Wo output positions of a k x k / stride / pad (k-1)/2 convolution (f16 tensors only)
+hipError_t tap_sums_f16(const TensorRef& src, int Ho, int Wo, int stride, int k, int slices, double* out, hipStream_t s);
+
 // 1x1 conv C -> 1 (+bias): logits (n,1,h,w) float32; mask (nullable) = sigmoid(logit) > thr ? 255 : 0
 hipError_t outc_1x1(int dt, const TensorRef& src, const float* w, const float* bias, float* logits,
                     uint8_t* mask, float threshold, unsigned* flag, unsigned layer_id, hipStream_t s);

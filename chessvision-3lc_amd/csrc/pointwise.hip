@@ -204,6 +204,28 @@ __global__ void absmax_kernel(TensorRef src, unsigned* __restrict__ out) {
     if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
 
+// ---- load-time rounding-bias calibration (engine.cpp: Engine::measure_tap_sums): per convolution tap and input channel, the sum of
+// the stored f16 input over the slice's images and every output position -- out[slice][tap][c] = sum_n sum_(oy,ox) x(n, oy*stride +
+// ky - pad, ox*stride + kx - pad, c), the zero border read as it is.  One lane = one channel (consecutive lanes read consecutive
+// halves); slices are summed on the host in index order, so the result is the same from run to run.
+__global__ __launch_bounds__(64) void tap_sums_f16_kernel(TensorRef src, int Ho, int Wo, int stride, int k, int n_per_slice, double* __restrict__ out) {
+    const int tap = blockIdx.x, c = blockIdx.y * 64 + threadIdx.x, slice = blockIdx.z;
+    if (c >= src.C) return;
+    const int pad = (k - 1) / 2, ky = tap / k, kx = tap % k;
+    const half_t* base = reinterpret_cast<const half_t*>(src.base) + src.Coff + c;
+    const int n0 = slice * n_per_slice, n1 = min(src.N, n0 + n_per_slice);
+    double total = 0.0;
+    for (int n = n0; n < n1; ++n) {
+        float part = 0.f;                                  // <= Ho * Wo terms of one image in f32, images in f64
+        for (int oy = 0; oy < Ho; ++oy) {
+            const size_t row = ((size_t)n * (src.H + 2) + (size_t)(oy * stride + ky - pad + 1)) * (src.W + 2);
+            for (int ox = 0; ox < Wo; ++ox) part += (float)base[(row + (size_t)(ox * stride + kx - pad + 1)) * src.Cs];
+        }
+        total += (double)part;
+    }
+    out[((size_t)slice * (k * k) + tap) * src.C + c] = total;
+}
+
 // ---- pooling / upsampling --------------------------------------------------------------------------
 template <typename T>
 __global__ void maxpool2x2_kernel(TensorRef src, TensorRef dst) {
@@ -1019,6 +1041,14 @@ hipError_t absmax(int dt, const TensorRef& src, unsigned* out, hipStream_t s) {
     if (dt == kF16) hipLaunchKernelGGL(absmax_kernel<half_t>, g_, b_, 0, s, src, out);
     else if (dt == kSplit) hipLaunchKernelGGL(absmax_kernel<split_t>, g_, b_, 0, s, src, out);
     else hipLaunchKernelGGL(absmax_kernel<float>, g_, b_, 0, s, src, out);
+    return hipGetLastError();
+}
+hipError_t tap_sums_f16(const TensorRef& src, int Ho, int Wo, int stride, int k, int slices, double* out, hipStream_t s) {
+    if (slices < 1 || (k != 1 && k != 3) || (Ho - 1) * stride + k - (k - 1) / 2 > src.H + 1 || (Wo - 1) * stride + k - (k - 1) / 2 > src.W + 1)
+        return hipErrorInvalidValue;
+    const int per = (src.N + slices - 1) / slices;
+    hipLaunchKernelGGL(tap_sums_f16_kernel, dim3((unsigned)(k * k), (unsigned)((src.C + 63) / 64), (unsigned)slices), dim3(64), 0, s, src, Ho, Wo,
+                       stride, k, per, out);
     return hipGetLastError();
 }
 hipError_t maxpool2x2(int dt, const TensorRef& src, const TensorRef& dst, hipStream_t s) {

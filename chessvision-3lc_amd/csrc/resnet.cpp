@@ -229,12 +229,16 @@ Status resnet_load(Engine& e, const ParamMap& pm) {
     e.resnet = std::move(m);
 
     // range calibration on 128 squares: noise, flat grey levels, gradients and checkers (what board crops look like)
+    // (the rounding-bias pass of the fp16 layers, ConvLayer::want_round_err, reads 128 more: 64 of noise and 64 smooth ones --
+    // bilinear blow-ups of a random 4 x 4 grid, what a board crop looks like away from piece edges -- so that the channel means it
+    // measures are not those of one texture)
     Status st = resnet_reserve(e, 128);
     if (st.ok() && dt != kF32 && calibration_enabled()) {
-        std::vector<float> host((size_t)128 * 4096);
+        constexpr int kCal = 128, kBias = 256;
+        std::vector<float> host((size_t)kBias * 4096);
         uint32_t rs = 0x2545F491u;
         auto rnd = [&]() { rs = rs * 1664525u + 1013904223u; return (rs >> 24) & 0xffu; };
-        for (int q = 0; q < 128; ++q)
+        for (int q = 0; q < kCal; ++q)
             for (int y = 0; y < 64; ++y)
                 for (int x = 0; x < 64; ++x) {
                     float v;
@@ -244,9 +248,25 @@ Status resnet_load(Engine& e, const ParamMap& pm) {
                     else v = (((x >> (q & 3)) + (y >> ((q >> 2) & 3))) & 1) ? 235.f : (float)(20 + (q - 104) * 6);   // checkers
                     host[((size_t)q * 64 + y) * 64 + x] = v / 255.f;
                 }
+        for (int q = kCal; q < kBias; ++q) {
+            float grid[5][5];
+            for (auto& row : grid) for (float& g : row) g = (float)rnd();
+            for (int y = 0; y < 64; ++y)
+                for (int x = 0; x < 64; ++x) {
+                    float v;
+                    if (q < kCal + 64) v = (float)rnd();
+                    else {                                                                               // bilinear, cell = 16 pixels
+                        const int gy = y >> 4, gx = x >> 4;
+                        const float fy = (float)(y & 15) / 16.f, fx = (float)(x & 15) / 16.f;
+                        const float top = grid[gy][gx] * (1.f - fx) + grid[gy][gx + 1] * fx, bot = grid[gy + 1][gx] * (1.f - fx) + grid[gy + 1][gx + 1] * fx;
+                        v = std::floor(top * (1.f - fy) + bot * fy + 0.5f);
+                    }
+                    host[((size_t)q * 64 + y) * 64 + x] = v / 255.f;
+                }
+        }
         DeviceBuffer xin, lout;
         st = xin.upload(host.data(), host.size() * sizeof(float));
-        if (st.ok()) st = lout.alloc((size_t)128 * 13 * sizeof(float), false);
+        if (st.ok()) st = lout.alloc((size_t)kBias * 13 * sizeof(float), false);
         if (st.ok())
             st = e.calibrate(e.resnet->acts, [&]() -> Status {                 // the statistics accumulate over the chunks
                 for (int off = 0; off < 128; off += e.resnet->cap) {
@@ -255,6 +275,17 @@ Status resnet_load(Engine& e, const ParamMap& pm) {
                 }
                 return Status();
             }, nullptr, "ResNet-18");
+        if (st.ok()) {                                                          // exponents are final: rounding-bias pass of the f16 layers
+            std::vector<ConvLayer*> layers;
+            for (auto& B : e.resnet->blocks) { layers.push_back(&B.conv1); layers.push_back(&B.conv2); if (B.has_down) layers.push_back(&B.down); }
+            st = e.calibrate_rounding_bias(layers, [&]() -> Status {
+                for (int off = 0; off < kBias; off += e.resnet->cap) {
+                    const int c = std::min(e.resnet->cap, kBias - off);
+                    CV_TRY(resnet_chunk(e, (const float*)xin.ptr + (size_t)off * 4096, false, c, (float*)lout.ptr + (size_t)off * 13, false, nullptr));
+                }
+                return Status();
+            }, nullptr);
+        }
         if (st.ok()) {
             hipError_t he = hipDeviceSynchronize();
             if (he != hipSuccess) st = hip_fail(he, "ResNet-18 calibration");

@@ -302,6 +302,19 @@ Status unet_load(Engine& e, const ParamMap& pm) {
                 }
                 return Status();
             }, nullptr, "UNet");
+        if (st.ok()) {                                                          // f16 engines: rounding-bias pass on the same two images
+            Engine::UNet& U = *e.unet;
+            std::vector<ConvLayer*> layers{&U.inc0, &U.inc1};
+            for (int i = 0; i < 4; ++i) for (int j = 0; j < 2; ++j) { layers.push_back(&U.d[i][j]); layers.push_back(&U.u[i][j]); }
+            st = e.calibrate_rounding_bias(layers, [&]() -> Status {
+                for (int off = 0; off < 2; off += e.unet->cap) {
+                    const int c = std::min(e.unet->cap, 2 - off);
+                    CV_TRY(unet_chunk(e, (const float*)xin.ptr + (size_t)off * 3 * 65536, false, c, (float*)lout.ptr + (size_t)off * 65536,
+                                      nullptr, 0.5f, nullptr));
+                }
+                return Status();
+            }, nullptr);
+        }
         if (st.ok()) {
             hipError_t he = hipDeviceSynchronize();
             if (he != hipSuccess) st = hip_fail(he, "UNet calibration");

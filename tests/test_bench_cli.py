@@ -174,6 +174,7 @@ def test_eight_ranks_on_one_gpu_run_configs4_global_shape():
     assert line["config"]["global_boards_per_step"] == 2048 and line["sharding"]["gathered_in_order"] is True
     assert line["calibration_sync"]["identical_across_ranks"] is True
     assert len(line["init_s_per_rank"]) == 8 and min(line["init_s_per_rank"]) > 0
+    assert max(line["init_s_per_rank"]) <= 1.5 * min(line["init_s_per_rank"]), line["init_s_per_rank"]     # side by side, not one after the other
     e2e = line["pipeline_e2e_ranks"]
     assert e2e["global_boards"] == 2048 and e2e["fens_on_rank0"] == 2048 and e2e["precision"] == "f16x3+f16r"
     assert e2e["order_checked_on_rank0"] == 14 and e2e["order_mismatches"] == 0

@@ -124,11 +124,10 @@ def test_all_reference_label_masks_give_their_annotated_corners(find_quadrangle)
 
 
 # ---- borderline cases of the reference's filter / simplification rules (core.py:357-411), C++ == numpy restatement --------------
-# Both implementations trace every border pixel (CHAIN_APPROX_NONE); the reference asks OpenCV for CHAIN_APPROX_TC89_KCOS, whose
-# dominant-point chain is what contourArea / arcLength / approxPolyDP then see.  The area of the compressed polygon is the same to
-# within the boundary pixels; its perimeter is up to ~8 % shorter on slanted edges (an 8-connected chain overestimates the length
-# of an edge at ~22 degrees by that much), so epsilon = 10 % of the perimeter differs by at most that factor.  These cases sit
-# where such a difference could matter and pin what this port does there.
+# Both implementations follow the reference's call (core.py:360: RETR_CCOMP, CHAIN_APPROX_TC89_KCOS) since round 5: the border is
+# traced pixel by pixel, then compressed to its Teh-Chin dominant points, and contourArea / arcLength / approxPolyDP see the
+# compressed chain (csrc/contour.cpp, classical.py; against the independent plain-C oracle in tests/test_contour_parity.py).  The
+# cases below sit where the filter / simplification rules are borderline and pin what the C++ and the numpy form do there.
 def _blank(size=256):
     return np.zeros((size, size), np.uint8)
 
