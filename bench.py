@@ -119,7 +119,8 @@ def pmc_traffic(dtype, unet_chunk, resnet_chunk, unet_launches, resnet_launches)
 
 
 # ---- CPU baseline leg: the ONLY place bench.py touches oracle/ (as the checker and the timed CPU port) -------------------
-def cpu_baseline(x_cpu, sq_cpu, gpu_logits, gpu_cls, e2e_images=None, budget_s: float = 12.0, e2e_results=None):
+def cpu_baseline(x_cpu, sq_cpu, gpu_logits, gpu_cls, e2e_images=None, budget_s: float = 12.0, e2e_results=None, fp16_search_s: float = 0.0,
+                 device=None):
     """Time the oracle (torch-CPU restatement = the arithmetic the reference runs) on a bounded sample:
       (i)  the reference-style loop -- UNet batch 1 + classifier batch 64 per board (core.py:215-220,236-241) -- at the thread
            count that is fastest on this box (swept: the default of one thread per logical core oversubscribes this loop);
@@ -175,6 +176,31 @@ def cpu_baseline(x_cpu, sq_cpu, gpu_logits, gpu_cls, e2e_images=None, budget_s: 
                 dev = e2e_results[k].board_extraction.board_image if e2e_results is not None else None
                 same = dev is not None and dev.shape == r.board_extraction.board_image.shape and bool((dev == r.board_extraction.board_image).all())
                 fens.append((r.position.fen, r.position.original_fen, r.position.model_probabilities, not same))
+        # the fp16 classifier's parity margin on MORE than one network (VERDICT r05 'weak' 1): 4096 squares (BASELINE configs[2]) on weight
+        # seeds x {He-normal, stressed}, worst soft-max error against this oracle; bounded by `fp16_search_s` seconds, seed 5 (the worst
+        # of tests/dev/f16r_seed_search.py) first.  tests/test_gpu_models.py asserts the whole 8 x 2 grid.
+        search = None
+        if fp16_search_s > 0:
+            from chessvision.hip_backend import HipEngine
+            rows, t_s = [], time.perf_counter()
+            for seed in (5, 4, 2, 0, 1, 3, 6, 7):
+                sq_s = synth.squares_input(seed=1000 + seed, n=4096)
+                for wname in ("he_normal", "stress"):
+                    if rows and time.perf_counter() - t_s > fp16_search_s:
+                        break
+                    net = synth.make_resnet(seed=seed)
+                    if wname == "stress":
+                        synth.load(net, synth.stress_resnet_state_dict(seed))
+                    p_ref = torch.softmax(net(sq_s), 1)
+                    e16 = HipEngine(device, precision="f16r", resnet_chunk=4096)
+                    e16.load_resnet18(net.state_dict())
+                    p = torch.softmax(e16.resnet18_forward(sq_s).cpu(), 1)
+                    e16.close()
+                    rows.append({"seed": seed, "weights": wname, "prob_err": float((p - p_ref).abs().max())})
+            worst = max(rows, key=lambda r: r["prob_err"])
+            search = {"networks": len(rows), "squares": 4096, "worst_prob_err": worst["prob_err"], "worst_case": f"seed {worst['seed']} {worst['weights']}",
+                      "rows": rows, "seconds": round(time.perf_counter() - t_s, 1),
+                      "bar": "soft-max within 1e-3 of the fp32 oracle on EVERY network (tests/test_gpu_models.py walks 8 seeds x 2 weight kinds)"}
         torch.set_num_threads(default_threads)
     base = {"value": round(done / dt, 3), "unit": "boards/sec", "cores": best, "kind": "port",
             "sample": f"{done} boards, reference-style loop (UNet b=1 + ResNet-18 b=64 per board), torch {torch.__version__} CPU fp32 "
@@ -183,7 +209,7 @@ def cpu_baseline(x_cpu, sq_cpu, gpu_logits, gpu_cls, e2e_images=None, budget_s: 
             "batched": {"value": round(batched, 3), "unit": "boards/sec", "cores": best,
                         "sample": f"one pass of UNet b={nb} + ResNet-18 b={nb * 64} after one warm-up pass"}}
     return (base, {"unet_logit_max_abs_err": max(errs_u), "resnet_logit_max_abs_err": max(errs_r), "boards_checked": done}, fens,
-            (torch.cat(ref_u), torch.cat(ref_r)))
+            (torch.cat(ref_u), torch.cat(ref_r)), search)
 
 
 def pipeline_e2e(dtype: str, n_boards: int = 256, n_checked: int = 8):
@@ -205,12 +231,13 @@ def pipeline_e2e(dtype: str, n_boards: int = 256, n_checked: int = 8):
             latency = process_image_latency(cv)
         except Exception as exc:                                                   # extra figure only
             latency = {"error": repr(exc)}
-        best, tm_best, res = None, None, None
-        for _ in range(5):                                   # best of five: the call contains host staging copies, and the host is shared
+        best, tm_best, res, calls = None, None, None, []
+        for _ in range(5):                                   # five calls: the call contains host staging copies, and the host is shared
             tm = {}
             t0 = time.perf_counter()
             res = cv.process_images(images, fallback_quad=True, timings=tm, return_crops=False)
             dt = time.perf_counter() - t0
+            calls.append(dt)
             if best is None or dt < best:
                 best, tm_best = dt, tm
         # the same job with the classifier in its fp16 mode (BASELINE configs[4] says fp16): UNet on the headline engine, ResNet-18 on "f16r"
@@ -235,9 +262,12 @@ def pipeline_e2e(dtype: str, n_boards: int = 256, n_checked: int = 8):
     classified = sum(r.position is not None for r in res)
     whole = cv._scale_quadrangle(__import__("numpy").array([[[255, 0]], [[0, 0]], [[0, 255]], [[255, 255]]], "int32"), (512, 512))
     found = sum(r.board_extraction.quadrangle is not None and not (r.board_extraction.quadrangle == whole).all() for r in res)
-    block = {"boards_per_sec": round(n_boards / best, 1), "boards": n_boards, "classified": classified, "quadrangles_found": found,
+    calls.sort()
+    block = {"boards_per_sec": round(n_boards / best, 1), "boards_per_sec_median": round(n_boards / calls[len(calls) // 2], 1),
+             "boards_per_sec_min": round(n_boards / calls[-1], 1), "calls": len(calls),
+             "boards": n_boards, "classified": classified, "quadrangles_found": found,
              "stages": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in tm_best.items()},
-             "note": "host images in, FEN out (best of 5 calls); one host thread software-pipelined against the GPU in jobs of 64 boards, "
+             "note": "host images in, FEN out (boards_per_sec = best of 5 calls, median and slowest beside it; the headline value is a 20-step MEAN of the resident CNN passes); one host thread software-pipelined against the GPU in jobs of 64 boards, "
                      "copies on side streams; stages: host seconds (*_s) and event-timed GPU milliseconds (*_ms) summed over the jobs"}
     if mixed is not None:
         block["classifier_fp16"] = mixed
@@ -446,8 +476,37 @@ def process_image_latency(cv, iters=100):
         times.append((time.perf_counter() - t0) * 1e3)
         found += int(r.position is not None)
     a = np.array(times)
+    # the same entry point from four request threads of ONE instance (the reference's Flask app: a global instance, threaded server,
+    # cv_endpoint.py:131-133): every thread gets a request slot of its own (engines, staging block, stream), results are the serial ones
+    conc = {}
+    try:
+        import threading
+
+        slots = cv.warm_request_slots(4)
+        want = [cv.process_image(im) for im in images]
+        per_thread, bad = 100, []
+
+        def worker(t):
+            for k in range(per_thread):
+                r = cv.process_image(images[(t + k) % 8])
+                w = want[(t + k) % 8]
+                if (r.position is None) != (w.position is None) or (w.position is not None and (
+                        r.position.fen != w.position.fen or not np.array_equal(r.position.model_probabilities, w.position.model_probabilities))):
+                    bad.append((t, k))
+
+        threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+        t0 = time.perf_counter()
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        dt = time.perf_counter() - t0
+        conc = {"concurrent4_per_sec": round(4 * per_thread / dt, 1), "concurrent4_slots": slots, "concurrent4_calls": 4 * per_thread,
+                "concurrent4_results_differing_from_serial": len(bad), "serial_per_sec": round(1e3 / float(np.median(a)), 1)}
+    except Exception as exc:                                                  # extra figure only
+        conc = {"concurrent4_error": repr(exc)}
     return {"process_image_ms_median": round(float(np.median(a)), 3), "process_image_ms_p10": round(float(np.percentile(a, 10)), 3),
-            "process_image_ms_p90": round(float(np.percentile(a, 90)), 3), "iters": iters, "boards_found": found,
+            "process_image_ms_p90": round(float(np.percentile(a, 90)), 3), "iters": iters, "boards_found": found, **conc,
             "image": "512x512x3 uint8 on the host", "note": "UNet B=1 + ResNet-18 B=64 (split-K launches, hipGraph replay), C++ contours, "
                                                               "device resize / warp; the host waits twice per call (an event behind the UNet, one stream synchronisation at the end)"}
 
@@ -518,7 +577,7 @@ def rooflines(eng, x, sq, dtype, B, quiet=False):
     roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4),
             "algorithmic_bytes": conv_bytes / max(conv_n, 1),
-            "kernel": "cv::conv3x3_halo_kernel + cv::conv_igemm_kernel + cv::inc0_mfma_kernel (the conv family, all instantiations)", "launches_per_step": conv_n,
+            "kernel": "conv family: conv3x3_halo_kernel + conv_igemm_kernel + inc0_mfma_kernel, all instantiations", "launches_per_step": conv_n,
             "avg_launch_ms": round(conv_ms / max(conv_n, 1), 4), "algorithmic_gflop_per_step": round(conv_flop / 1e9, 2),
             "by_model": {m: {"achieved": round(fl / (ms * 1e-3) / 1e12, 2), "frac": round(fl / (ms * 1e-3) / 1e12 / peak, 4)}
                          for m, (ms, fl) in per_model.items()},       # north_star: >= 50 % on the UNet conv stages
@@ -552,8 +611,10 @@ def rooflines(eng, x, sq, dtype, B, quiet=False):
 
 
 def flatten_evidence(result):
-    """The driver's record of this line keeps `config`, `roofline` and `cpu_baseline` (scalar entries) and only the NAMES of the
-    other top-level blocks: the figures a reader needs to judge the run are therefore mirrored into those three as flat scalars."""
+    """The driver's record of this line keeps `config`, `roofline` and `cpu_baseline` -- about 23 scalar entries each, names cut at 40
+    characters, strings at 128 -- and only the NAMES of the other top-level blocks.  The figures a reader needs to judge the run are
+    therefore mirrored into `config` and `roofline` as flat scalars under SHORT names and placed FIRST; the longer
+    names of earlier rounds follow for the tests and tools that read them."""
     cfg, roof = result["config"], result["roofline"]
 
     def pick(d, *path):
@@ -567,7 +628,32 @@ def flatten_evidence(result):
         if val is not None and not isinstance(val, (dict, list)):
             dst[key] = val
 
-    put(cfg, "rccl_ranks_seen", result.get("rccl_ranks_seen"))
+    lat = pick(result, "pipeline_e2e", "latency")
+    head = {}
+    for key in ("workload", "boards_per_gpu", "global_boards_per_step", "gflop_per_board"):
+        put(head, key, cfg.get(key))
+    put(head, "par_unet_err", pick(result, "parity_vs_oracle", "unet_logit_max_abs_err"))       # headline engine vs the fp32 CPU oracle, same run
+    put(head, "par_resnet_err", pick(result, "parity_vs_oracle", "resnet_logit_max_abs_err"))
+    put(head, "par_boards", pick(result, "parity_vs_oracle", "boards_checked"))
+    put(head, "cls16_frac", pick(result, "classifier_fp16", "roofline", "frac"))                # fp16 classifier (configs[2]): of the 2.5 PF f16 peak
+    put(head, "cls16_ms", pick(result, "classifier_fp16", "ms_per_pass"))
+    put(head, "cls16_prob_err", pick(result, "classifier_fp16", "parity_vs_oracle", "prob_max_abs_err"))
+    put(head, "cls16_worst_err", pick(result, "classifier_fp16_seed_search", "worst_prob_err"))  # worst network of the seed search
+    put(head, "cls16_worst_nets", pick(result, "classifier_fp16_seed_search", "networks"))
+    put(head, "cls16_step_bps", pick(result, "classifier_fp16", "step_with_headline_unet", "boards_per_sec"))
+    put(head, "f32_bps", pick(result, "by_dtype", "f32", "value"))
+    put(head, "f32_frac", pick(result, "by_dtype", "f32", "roofline", "frac"))
+    put(head, "bil_bps", pick(result, "by_variant", "bilinear", "value"))
+    put(head, "e2e_bps", pick(result, "pipeline_e2e", "boards_per_sec"))                         # host photos -> FEN: best of 5 calls ...
+    put(head, "e2e_bps_median", pick(result, "pipeline_e2e", "boards_per_sec_median"))          # ... their median ...
+    put(head, "e2e_bps_min", pick(result, "pipeline_e2e", "boards_per_sec_min"))                # ... and the slowest
+    put(head, "e2e_fen_bad", pick(result, "pipeline_e2e", "fen_mismatches"))
+    if isinstance(lat, dict):
+        put(head, "lat_ms_median", lat.get("process_image_ms_median"))
+        put(head, "conc4_per_sec", lat.get("concurrent4_per_sec"))
+    put(head, "rccl_ranks_seen", result.get("rccl_ranks_seen"))
+    put(head, "e2e_ranks_bps", pick(result, "pipeline_e2e_ranks", "boards_per_sec_whole_job"))
+
     put(cfg, "dist_backend", result.get("dist_backend"))
     put(cfg, "init_s_max_over_ranks", pick(result, "init_s", "max"))
     put(cfg, "device_memory_peak_used_gb", pick(result, "device_memory", "peak_used_gb_max_over_ranks"))
@@ -586,11 +672,9 @@ def flatten_evidence(result):
     put(cfg, "pipeline_e2e_board_byte_mismatches_vs_oracle", pick(result, "pipeline_e2e", "board_byte_mismatches_vs_oracle"))
     put(cfg, "pipeline_e2e_prob_max_abs_err_vs_oracle", pick(result, "pipeline_e2e", "prob_max_abs_err_vs_oracle"))
     put(cfg, "pipeline_e2e_fp16_classifier_boards_per_sec", pick(result, "pipeline_e2e", "classifier_fp16", "boards_per_sec"))
-    lat = pick(result, "pipeline_e2e", "latency")
     if isinstance(lat, dict):
-        cfg["latency"] = lat                                     # the block itself ...
         for k in ("process_image_ms_median", "process_image_ms_p10", "process_image_ms_p90"):
-            put(cfg, "latency_" + k, lat.get(k))                 # ... and its scalars, flat
+            put(cfg, "latency_" + k, lat.get(k))
     for dt in ("f32", "f16"):
         put(cfg, f"{dt}_boards_per_sec", pick(result, "by_dtype", dt, "value"))
         put(cfg, f"{dt}_roofline_frac", pick(result, "by_dtype", dt, "roofline", "frac"))
@@ -602,18 +686,42 @@ def flatten_evidence(result):
     put(cfg, "pipeline_e2e_ranks_precision", pick(result, "pipeline_e2e_ranks", "precision"))
     for k in ("min", "mean", "max"):
         put(cfg, f"pipeline_e2e_ranks_boards_per_sec_{k}", pick(result, "pipeline_e2e_ranks", "boards_per_sec_per_rank", k))
-    put(roof, "dominant_kernel", pick(roof, "dominant", "kernel"))
-    put(roof, "dominant_frac", pick(roof, "dominant", "frac"))
-    put(roof, "dominant_avg_launch_ms", pick(roof, "dominant", "avg_launch_ms"))
-    put(roof, "dominant_launches_per_step", pick(roof, "dominant", "launches_per_step"))
-    put(roof, "dominant_share_of_conv_time", pick(roof, "dominant", "share_of_conv_time"))
-    put(roof, "unet_conv_frac", pick(roof, "by_model", "unet", "frac"))
-    put(roof, "resnet18_conv_frac", pick(roof, "by_model", "resnet18", "frac"))
-    for name, blk in (result.get("roofline_hbm") or {}).items():
+    ordered = dict(head)
+    for k, v in cfg.items():
+        ordered.setdefault(k, v)
+    if isinstance(lat, dict):
+        ordered["latency"] = lat                                 # the block itself, last
+    result["config"] = ordered
+
+    rhead = {}
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes", "kernel", "launches_per_step", "avg_launch_ms"):
+        if key in roof:
+            rhead[key] = roof[key]                               # `traffic` stays even when null (the contract names it)
+    put(rhead, "dominant_kernel", pick(roof, "dominant", "kernel"))
+    put(rhead, "dominant_frac", pick(roof, "dominant", "frac"))
+    put(rhead, "dominant_avg_launch_ms", pick(roof, "dominant", "avg_launch_ms"))
+    put(rhead, "unet_conv_frac", pick(roof, "by_model", "unet", "frac"))
+    put(rhead, "resnet18_conv_frac", pick(roof, "by_model", "resnet18", "frac"))
+    hbm_all = dict(result.get("roofline_hbm") or {})
+    for name, blk in (pick(result, "by_variant", "bilinear", "roofline_hbm") or {}).items():
+        hbm_all.setdefault(name, blk)                            # the bilinear variant's up-sampling kernel
+    short = {"upsample": "hbm_upsample_frac", "stem": "hbm_stem_frac", "head": "hbm_head_frac", "resize": "hbm_resize_frac",
+             "extract_squares": "hbm_warp_frac"}
+    for name, blk in hbm_all.items():
+        if isinstance(blk, dict) and "frac" in blk:
+            for word, key in short.items():
+                if word in name:
+                    rhead.setdefault(key, blk["frac"])
+    put(rhead, "dominant_launches_per_step", pick(roof, "dominant", "launches_per_step"))
+    put(rhead, "dominant_share_of_conv_time", pick(roof, "dominant", "share_of_conv_time"))
+    for name, blk in hbm_all.items():
         if isinstance(blk, dict) and "frac" in blk:
             key = "hbm_" + "".join(c if c.isalnum() else "_" for c in name).strip("_")
-            roof[key + "_frac"] = blk["frac"]
-            roof[key + "_gbs"] = blk["achieved"]
+            rhead[key + "_frac"] = blk["frac"]
+            rhead[key + "_gbs"] = blk["achieved"]
+    for k, v in roof.items():
+        rhead.setdefault(k, v)
+    result["roofline"] = rhead
 
 
 def main():
@@ -632,6 +740,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the by_dtype / by_variant / pipeline_e2e blocks")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
+    ap.add_argument("--fp16-search-budget", type=float, default=45.0,
+                    help="seconds for the fp16 classifier's worst-case search over weight seeds (oracle leg; 0 = skip)")
     ap.add_argument("--extra-steps", type=int, default=10, help="timed steps of each by_dtype / by_variant / classifier_fp16 leg")
     ap.add_argument("--extra-warmup", type=int, default=3)
     ap.add_argument("--e2e-precision", default=None,
@@ -757,8 +867,8 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"e2e-cnn b=256/GPU: UNet(3->1, {variant_name}) 256x256 on 256 boards + ResNet-18(1ch,13cls) on "
-                               "16384 64x64 squares per step per GPU (BASELINE configs[3]; configs[4] shape at 8 GPUs); inputs resident in HBM",
+        "config": {"workload": f"e2e-cnn b={B}/GPU: UNet(3->1,{'bilinear' if bilinear else 'convT'}) 256x256 x{B} boards + ResNet-18(1ch,13cls) x{B * 64} squares "
+                               "per step; inputs in HBM (configs[3])",
                    "boards_per_gpu": B, "global_boards_per_step": world * B, "unet_chunk": eff_unet,
                    "resnet_chunk": eff_resnet, "parallelism": f"replicas x{world}, boards sharded, weights RCCL-broadcast once",
                    "gflop_per_board": round(2 * macs_board / 1e9, 3)},
@@ -785,10 +895,13 @@ def main():
             except Exception as exc:                                      # extra figure only; never hides the headline
                 e2e_block = {"error": repr(exc)}
         nchk = min(B, 64)
-        base, parity, ref_fens, oracle_out = cpu_baseline(x[:nchk].cpu(), sq[:nchk * 64].cpu(), out[0][:nchk].cpu(), out[1][:nchk * 64].cpu(),
-                                              e2e_images=e2e_imgs, budget_s=args.cpu_budget, e2e_results=e2e_res)
+        base, parity, ref_fens, oracle_out, fp16_search = cpu_baseline(x[:nchk].cpu(), sq[:nchk * 64].cpu(), out[0][:nchk].cpu(), out[1][:nchk * 64].cpu(),
+                                              e2e_images=e2e_imgs, budget_s=args.cpu_budget, e2e_results=e2e_res,
+                                              fp16_search_s=0.0 if args.no_extras else args.fp16_search_budget, device=device)
         result["cpu_baseline"] = base
         result["parity_vs_oracle"] = parity
+        if fp16_search is not None:
+            result["classifier_fp16_seed_search"] = fp16_search
         if e2e_block is not None:
             if ref_fens is not None and e2e_res is not None:
                 import numpy as np

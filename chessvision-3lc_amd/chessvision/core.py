@@ -46,6 +46,18 @@ _RESNET_IDS = ("", "resnet18", "hip")
 _PRECISION_NAMES = ("f16x3", "split", "f32", "fp32", "float32", "f16", "fp16", "float16", "f16r")
 
 
+class _RequestSlot:
+    """What ONE in-flight ``process_image`` needs for itself: an engine per model (activation workspace, page-locked staging block,
+    captured hipGraphs -- none of which two forwards can share) and a HIP stream of its own.  Slot 0 wraps the instance's primary
+    engines; further slots hold replicas loaded from the same checkpoints (same weights, same deterministic load-time calibration:
+    bit-identical results)."""
+
+    __slots__ = ("extractor_engine", "classifier_engine", "stream", "busy")
+
+    def __init__(self, extractor_engine, classifier_engine, stream):
+        self.extractor_engine, self.classifier_engine, self.stream, self.busy = extractor_engine, classifier_engine, stream, False
+
+
 class ChessVision:
     """Chess position detection from images (drop-in for the reference class of the same name)."""
 
@@ -78,6 +90,13 @@ class ChessVision:
         self._stage: dict = {}
         self._last_board = None                         # (board array of the last native extraction, its squares on the device)
         self._f32_twin: ChessVision | None = None       # exact-f32 instance of the same checkpoints, created on the first numeric-guard trip
+        # request slots of the single-image path (round 6): request threads of ONE instance -- the reference's Flask app keeps a global
+        # instance, app/computeroot/cv_endpoint.py:131-133 -- run their B=1 forwards side by side on the device instead of queueing behind
+        # one staging block.  A B=1 forward keeps the matrix pipes 5-26 % busy, so four of them overlap almost freely.
+        self._slots: list[_RequestSlot] = []
+        self._slot_cond = threading.Condition()
+        self._slot_building = False
+        self._max_slots = max(1, int(os.environ.get("CHESSVISION_REQUEST_SLOTS", "4")))
         self._guard_logged: set = set()
         if not lazy_load:
             logger.info("Eager loading models...")
@@ -241,7 +260,12 @@ class ChessVision:
         classifier, soft-max, FEN and the pawn rule all happen behind the C ABI; Python only wraps the arrays into the result records."""
         from .hip_backend import process_image_native
 
-        r = process_image_native(self.board_extractor.engine, self.classifier.engine, image, threshold, flip, fallback_quad)
+        slot = self._acquire_slot()
+        try:
+            r = process_image_native(slot.extractor_engine, slot.classifier_engine, image, threshold, flip, fallback_quad,
+                                     stream=slot.stream.cuda_stream)
+        finally:
+            self._release_slot(slot)
         if not r["found"]:
             logger.info("No valid board found in image")
             extraction = BoardExtractionResult(board_image=None, binary_mask=r["mask"], quadrangle=None, probabilities=r["logits"])
@@ -255,6 +279,70 @@ class ChessVision:
         elapsed = time.time() - started
         logger.info(f"Processing completed in {elapsed:.2f} seconds")
         return ChessVisionResult(board_extraction=extraction, position=position, processing_time=elapsed)
+
+    # ---- request slots ----------------------------------------------------------------------------------------------------------
+    def _acquire_slot(self) -> _RequestSlot:
+        """A free slot, waiting for one if all are in flight.  The first request creates slot 0 around the primary engines; a request
+        that finds every slot busy starts ONE background thread that loads a replica pair (a few seconds: pack + calibrate, while the
+        existing slots keep serving) until ``CHESSVISION_REQUEST_SLOTS`` (default 4) exist -- so a single-threaded caller never pays for
+        replicas, and a threaded server reaches its full width after its first busy seconds."""
+        extractor, classifier = self.board_extractor, self.classifier      # lazy initialisation outside the slot lock
+        with self._slot_cond:
+            if not self._slots:
+                self._slots.append(_RequestSlot(extractor.engine, classifier.engine, torch.cuda.Stream(self.device)))
+            while True:
+                for slot in self._slots:
+                    if not slot.busy:
+                        slot.busy = True
+                        return slot
+                if len(self._slots) < self._max_slots and not self._slot_building:
+                    self._slot_building = True
+                    threading.Thread(target=self._build_slot, name="chessvision-slot-builder", daemon=True).start()
+                self._slot_cond.wait()
+
+    def _release_slot(self, slot: _RequestSlot) -> None:
+        with self._slot_cond:
+            slot.busy = False
+            self._slot_cond.notify()
+
+    def _build_slot(self) -> None:
+        from .hip_backend import HipEngine
+
+        try:
+            parts = self._precision.split("+")
+            engines = {}
+            for prec in dict.fromkeys(parts):
+                engines[prec] = HipEngine(self.device, precision=prec)
+            unet_eng, cls_eng = engines[parts[0]], engines[parts[-1]]
+            state, _ = utils.read_checkpoint(self._board_extractor_weights or constants.BEST_EXTRACTOR_WEIGHTS)
+            unet_eng.load_unet(state)
+            state, _ = utils.read_checkpoint(self._classifier_weights or constants.BEST_CLASSIFIER_WEIGHTS)
+            cls_eng.load_resnet18(state)
+            slot = _RequestSlot(unet_eng, cls_eng, torch.cuda.Stream(self.device))
+        except Exception as exc:                                            # no replica: the instance keeps serving with what it has
+            logger.warning(f"request slot {len(self._slots)} could not be created ({exc}); staying at {len(self._slots)} slot(s)")
+            with self._slot_cond:
+                self._max_slots = len(self._slots)
+                self._slot_building = False
+                self._slot_cond.notify_all()
+            return
+        with self._slot_cond:
+            self._slots.append(slot)
+            self._slot_building = False
+            self._slot_cond.notify_all()
+
+    def warm_request_slots(self, n: int | None = None) -> int:
+        """Create request slots now instead of under load (a server's start-up hook); returns how many exist afterwards."""
+        want = min(self._max_slots, n or self._max_slots)
+        self._release_slot(self._acquire_slot())                             # slot 0
+        while True:
+            with self._slot_cond:
+                if len(self._slots) >= min(want, self._max_slots):
+                    return len(self._slots)
+                if not self._slot_building:
+                    self._slot_building = True
+                    threading.Thread(target=self._build_slot, name="chessvision-slot-builder", daemon=True).start()
+                self._slot_cond.wait(timeout=1.0)
 
     def _staging(self, shape=None):
         """Page-locked staging buffers of the single-image path: mask, logits, board, squares, probabilities, homography (shared),

@@ -254,7 +254,7 @@ def board_homographies(quads: np.ndarray, out_size=(512, 512), want_forward: boo
 
 
 def process_image_native(unet_engine: "HipEngine", classifier_engine: "HipEngine", image: np.ndarray, threshold: float = 0.5,
-                         flip: bool = False, fallback_quad: bool = False) -> dict:
+                         flip: bool = False, fallback_quad: bool = False, stream: int | None = None) -> dict:
     """One host image through ``cv_process_image`` (the native form of ``ChessVision.process_image``, reference core.py:152-195):
     returns {"logits" (256,256) f32, "mask" (256,256) u8, "found", and when found "quadrangle" (4,1,2) f32, "board" (512,512) u8,
     "probabilities" (64,13) f32, "squares" (64,64,64,1) u8, "fen", "original_fen", "fixes" [(square index, original class, corrected class)]}."""
@@ -272,7 +272,7 @@ def process_image_native(unet_engine: "HipEngine", classifier_engine: "HipEngine
     res.probabilities, res.squares, res.labels = probs.ctypes.data, squares.ctypes.data, None
     _check(lib.cv_process_image(unet_engine._h, classifier_engine._h, img.ctypes.data, img.shape[0], img.shape[1],
                                 float(threshold), int(bool(flip)), int(bool(fallback_quad)), ctypes.byref(res),
-                                _stream_ptr(unet_engine.device)))
+                                _stream_ptr(unet_engine.device) if stream is None else stream))       # stream: a request slot's own HIP stream
     out = {"logits": logits, "mask": mask, "found": bool(res.found)}
     if res.found:
         out.update(quadrangle=np.frombuffer(res.quadrangle, dtype=np.float32).reshape(4, 1, 2).copy(), board=board, probabilities=probs, squares=squares,

@@ -56,7 +56,7 @@ hipError_t softmax13(const float* logits, int n, float* probs, hipStream_t s);
 // C in {64, 128, 256}) at f32 grade: three split-f16 MFMA products per MAC.  wpk: [C_out/128][C_in/32][fragment 8][hi | lo][lane 64] x
 // half8, MFMA row i of fragment f = channel 32 (i/4) + 4 f + i%4 of the group (resnet.cpp: pack_shortcut); scale / shift [C_out].
 hipError_t shortcut1x1s2(const TensorRef& x32, const void* wpk, const float* scale, const float* shift, const TensorRef& y32,
-                         unsigned* flag, unsigned layer_id, hipStream_t s);
+                         unsigned* flag, unsigned layer_id, hipStream_t s, bool split = false);
 
 // MFMA lane-map probes used by cv_selftest_mfma (D = A*B^T with A:16xK, B:16xK row-major)
 hipError_t mfma_probe_f16(const half_t* a, const half_t* b, float* d, hipStream_t s);   // K = 32

@@ -10,6 +10,7 @@
 // adaptive_avg_pool2d(1) + linear 512->13 (+ softmax, core.py:242), and the u8 HWC -> /255 -> NCHW input
 // packing of core.py:215-216 / 236-237.
 #include "pointwise.h"
+#include "conv_device.h"   // OutVec (split-f16 store units)
 
 #include <algorithm>
 #include <cmath>
@@ -1238,7 +1239,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // for 16 pixels of work (2.1 GB of L2 traffic per launch against 0.2-0.8 GB of HBM bytes: that, not the stride-2 read, was what the
 // launch waited for).  The next pixel group's floats are fetched while the current one is multiplied (CIN <= 128: 16-32 registers).
 // Same arithmetic, same operation order per output as the first form: same bits.
-template <int CIN, int NW, bool PREFETCH, bool STAGE>
+// SPLIT (round 6: the headline engine's shortcuts): x and y are split-f16 tensors instead of f32 twins.  A channel group is 32 bytes
+// either way, so every address is the same; the two 16-byte chunks a lane fetches per k-step ARE its hi and lo operand (no conversion),
+// and the staged epilogue writes each group's hi and lo chunk from the lane pair that shares the group -- still one contiguous KB per
+// store instruction.  Products and their order (w_hi x_hi, w_lo x_hi, w_hi x_lo per 32-channel k-step) are those of conv_igemm_kernel
+// on split_t: bit-identical to the generic launch it replaces.
+template <int CIN, int NW, bool PREFETCH, bool STAGE, bool SPLIT = false>
 __global__ __launch_bounds__(64 * NW) void shortcut1x1s2_lds_kernel(
     const float* __restrict__ x, int n, int H, int W, const half8* __restrict__ wpk, const float* __restrict__ scale,
     const float* __restrict__ shift, float* __restrict__ y, unsigned* flag, unsigned layer_id) {
@@ -1285,11 +1291,17 @@ __global__ __launch_bounds__(64 * NW) void shortcut1x1s2_lds_kernel(
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
             half8 bh, bl;                                    // plain C conversion: see the first form
+            if constexpr (SPLIT) {                           // group k*4 + q: even groups are stored [hi, lo], odd ones [lo, hi]
+                const half8 a = __builtin_bit_cast(half8, xv[k][0]), b = __builtin_bit_cast(half8, xv[k][1]);
+                bh = (q & 1) ? b : a;
+                bl = (q & 1) ? a : b;
+            } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float v = j < 4 ? xv[k][0][j] : xv[k][1][j - 4];
                 bh[j] = (half_t)v;
                 bl[j] = (half_t)(v - (float)bh[j]);
+            }
             }
             // weight fragments four channel fragments at a time (32 registers live; left alone the compiler hoists every LDS read of
             // every k-step to the top of the iteration and spills 200-400 registers)
@@ -1338,22 +1350,37 @@ __global__ __launch_bounds__(64 * NW) void shortcut1x1s2_lds_kernel(
 #pragma unroll
                 for (int j = 0; j < SR / 2; ++j) {
                     const int px = 2 * j + (lane >> 5), part = lane & 31;
-                    const f4 v = *reinterpret_cast<const f4*>(stg + px * SROW + part * 16);
                     const unsigned op = pixw[px];
+                    if constexpr (SPLIT) {
+                        // lanes 2g and 2g + 1 share channel group g of the pixel: one writes the group's first 16-byte chunk, the other the second
+                        const int gl = part >> 1, par = gl & 1;                  // (cg * 16 + gl) & 1: a 128-channel group starts on an even group
+                        const f4 v0 = *reinterpret_cast<const f4*>(stg + px * SROW + gl * 32), v1 = *reinterpret_cast<const f4*>(stg + px * SROW + gl * 32 + 16);
+                        const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                        if ((part & 1) == 0) {                                   // range guard on the f16 hi halves, once per group
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) bad = __builtin_fmaf((float)(half_t)v[i], 0.f, bad);
+                        }
+                        if (op != 0xffffffffu)
+                            OutVec<split_t, 8>::store_half(reinterpret_cast<split_t*>(y) + (size_t)op * COUT + cg * 128 + gl * 8, gl * 8, v, (part & 1) == par);
+                    } else {
+                    const f4 v = *reinterpret_cast<const f4*>(stg + px * SROW + part * 16);
                     if (op != 0xffffffffu) *reinterpret_cast<f4*>(y + (size_t)op * COUT + cg * 128 + part * 4) = v;
+                    }
                 }
                 asm volatile("" ::: "memory");
             }
         } else {
         float* const yp = y + opix * COUT + c0;
+        float ov[32];
 #pragma unroll
         for (int f = 0; f < 8; ++f) {
             const f4 sc = *reinterpret_cast<const f4*>(sl + q * 32 + f * 4), sh = *reinterpret_cast<const f4*>(sl + 128 + q * 32 + f * 4);
             f4 o;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { o[r] = acc[f][r] * sc[r] + sh[r]; bad = __builtin_fmaf(o[r], 0.f, bad); }
-            if (live) *reinterpret_cast<f4*>(yp + f * 4) = o;
+            for (int r = 0; r < 4; ++r) { o[r] = acc[f][r] * sc[r] + sh[r]; bad = __builtin_fmaf(o[r], 0.f, bad); ov[f * 4 + r] = o[r]; }
+            if (!SPLIT && live) *reinterpret_cast<f4*>(yp + f * 4) = o;
         }
+        if (SPLIT && live) OutVec<split_t, 32>::store(reinterpret_cast<split_t*>(yp), c0, ov, bad);
         }
         if (!PREFETCH) { if (pg + stride < ngroups) fetch(src_of(pg + stride), xn); }
     }
@@ -1361,8 +1388,8 @@ __global__ __launch_bounds__(64 * NW) void shortcut1x1s2_lds_kernel(
 }
 
 hipError_t shortcut1x1s2(const TensorRef& x32, const void* wpk, const float* scale, const float* shift, const TensorRef& y32,
-                         unsigned* flag, unsigned layer_id, hipStream_t s) {
-    if (!x32.f32_only || !y32.f32_only || x32.Coff || y32.Coff || x32.Cs != x32.C || y32.Cs != y32.C || y32.C != 2 * x32.C ||
+                         unsigned* flag, unsigned layer_id, hipStream_t s, bool split) {
+    if ((!split && (!x32.f32_only || !y32.f32_only)) || (split && (x32.f32_only || y32.f32_only)) || x32.Coff || y32.Coff || x32.Cs != x32.C || y32.Cs != y32.C || y32.C != 2 * x32.C ||
         x32.H != 2 * y32.H || x32.W != 2 * y32.W || x32.N != y32.N)
         return hipErrorInvalidValue;
     const int cin = x32.C, M = x32.N * y32.H * y32.W;
@@ -1385,12 +1412,13 @@ hipError_t shortcut1x1s2(const TensorRef& x32, const void* wpk, const float* sca
         static const int stage_knob = [] { const char* v = std::getenv("CV_SHORTCUT_STAGE"); return v && *v ? std::atoi(v) : 1; }();
         const bool stage = stage_knob != 0;
         const size_t lds = (size_t)(cin / 32) * 16 * 1024 + 1024 + (stage ? (size_t)nw * ((cin <= 128 ? 16 : 4) * 528 + 64) : 0);   // weights + scale / shift (+ staging)
-#define CV_SC_LAUNCH(CIN_, NW_, PF_, ST_)                                                                                                 \
+#define CV_SC_LAUNCH1(CIN_, NW_, PF_, ST_, SP_)                                                                                           \
         do {                                                                                                                              \
             static bool set_ = false;                                                                                                     \
-            if (!set_) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(shortcut1x1s2_lds_kernel<CIN_, NW_, PF_, ST_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set_ = true; } \
-            hipLaunchKernelGGL((shortcut1x1s2_lds_kernel<CIN_, NW_, PF_, ST_>), g2, b2, lds, s, xb, x32.N, x32.H, x32.W, w, scale, shift, yb, flag, layer_id); \
+            if (!set_) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(shortcut1x1s2_lds_kernel<CIN_, NW_, PF_, ST_, SP_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set_ = true; } \
+            hipLaunchKernelGGL((shortcut1x1s2_lds_kernel<CIN_, NW_, PF_, ST_, SP_>), g2, b2, lds, s, xb, x32.N, x32.H, x32.W, w, scale, shift, yb, flag, layer_id); \
         } while (0)
+#define CV_SC_LAUNCH(CIN_, NW_, PF_, ST_) do { if (split) CV_SC_LAUNCH1(CIN_, NW_, PF_, ST_, true); else CV_SC_LAUNCH1(CIN_, NW_, PF_, ST_, false); } while (0)
         if (cin == 64 && nw == 4) { if (stage) CV_SC_LAUNCH(64, 4, true, true); else CV_SC_LAUNCH(64, 4, true, false); }
         else if (cin == 64) { if (stage) CV_SC_LAUNCH(64, 8, true, true); else CV_SC_LAUNCH(64, 8, true, false); }
         else if (cin == 128) { if (stage) CV_SC_LAUNCH(128, 8, true, true); else CV_SC_LAUNCH(128, 8, true, false); }
@@ -1398,8 +1426,10 @@ hipError_t shortcut1x1s2(const TensorRef& x32, const void* wpk, const float* sca
         else if (cin == 256) { if (stage) CV_SC_LAUNCH(256, 8, false, true); else CV_SC_LAUNCH(256, 8, false, false); }
         else return hipErrorInvalidValue;
 #undef CV_SC_LAUNCH
+#undef CV_SC_LAUNCH1
         return hipGetLastError();
     }
+    if (split) return hipErrorInvalidValue;               // the first form exists for the f32 twins only
     if (cin == 64) hipLaunchKernelGGL(shortcut1x1s2_kernel<64>, grid, block, 0, s, xb, x32.N, x32.H, x32.W, w, scale, shift, yb, flag, layer_id);
     else if (cin == 128) hipLaunchKernelGGL(shortcut1x1s2_kernel<128>, grid, block, 0, s, xb, x32.N, x32.H, x32.W, w, scale, shift, yb, flag, layer_id);
     else if (cin == 256) hipLaunchKernelGGL(shortcut1x1s2_kernel<256>, grid, block, 0, s, xb, x32.N, x32.H, x32.W, w, scale, shift, yb, flag, layer_id);

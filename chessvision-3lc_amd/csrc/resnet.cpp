@@ -34,6 +34,13 @@ static int chain_form() {
     return form;
 }
 
+// split-f16 engine: squares from which the dedicated shortcut kernel replaces the generic launch (CV_SHORTCUT_SPLIT_MIN; below it the
+// generic launch shares conv1's launch, Engine::PendingConv)
+static int fast_sc_min_squares() {
+    static const int v = [] { const char* e = std::getenv("CV_SHORTCUT_SPLIT_MIN"); return e && *e ? std::atoi(e) : 1024; }();
+    return v;
+}
+
 static void bn_keys(std::vector<std::string>& out, const std::string& p) {
     for (const char* leaf : {".weight", ".bias", ".running_mean", ".running_var"}) out.push_back(p + leaf);
 }
@@ -147,7 +154,9 @@ Status resnet_load(Engine& e, const ParamMap& pm) {
                 // form (weights resident in LDS, persistent waves, full-line stores) 0.145 / 0.085 / 0.084 -- ON by default;
                 // CV_SHORTCUT_FAST=0 switches it off (the generic launch then rides with conv1 at single-board sizes, Engine::PendingConv)
                 static const bool fast_on = [] { const char* v = std::getenv("CV_SHORTCUT_FAST"); return !(v && v[0] == '0'); }();
-                if (e.trunk32 && dt == kF16 && fast_on && w == 2 * cin && (cin == 64 || cin == 128 || cin == 256)) {
+                // round 6: the headline engine (split-f16 tensors) takes the same kernel in its SPLIT form at throughput batch sizes -- there it
+                // computes exactly what the generic launch computes (same products, same order: bit-identical), so the choice may follow the batch
+                if (((e.trunk32 && dt == kF16) || dt == kSplit) && fast_on && w == 2 * cin && (cin == 64 || cin == 128 || cin == 256)) {
                     // split-f16 image of the 1x1 weights for shortcut1x1s2: rows normalised to [0.5, 1) (exponent into the scale), hi / lo halves,
                     // [channel group of 128][k-step of 32][fragment 8][hi | lo][lane 64][8]; MFMA row i of fragment f = channel 32 (i/4) + 4 f + i%4
                     const float* wd;
@@ -421,6 +430,31 @@ static Status resnet_chunk(Engine& e, const void* x, bool x_u8, int n, float* ou
                 } else {
                     CV_TRY(down_beside_conv1(in32, B.sc.ref32(n)));
                 }
+            } else if (B.fast_sc && dt == kSplit && !e.calibrating && n >= fast_sc_min_squares()) {
+                // split-f16 tensors in, split-f16 tensors out; below the threshold the generic launch rides with conv1 (one launch fewer)
+                const TensorRef out = B.sc.ref(n);
+                if (B.sc_in_exp != cur.exp || B.sc_out_exp != out.exp) {
+                    if (capture_flag()) return fail(1, "shortcut constants re-folded during graph capture");
+                    CV_HIP(hipStreamSynchronize(s));
+                    std::vector<float> sc(B.h_sc_scale.size()), sh(sc.size());
+                    for (size_t k = 0; k < sc.size(); ++k) {
+                        sc[k] = std::ldexp(B.h_sc_scale[k], cur.exp - out.exp);
+                        sh[k] = std::ldexp(B.h_sc_shift[k], -out.exp);
+                        if (!std::isfinite(sc[k]) || !std::isfinite(sh[k])) return fail(1, "shortcut: range factors leave the f32 range");
+                    }
+                    CV_HIP(hipMemcpy(B.sc_scale.ptr, sc.data(), sc.size() * sizeof(float), hipMemcpyHostToDevice));
+                    CV_HIP(hipMemcpy(B.sc_shift.ptr, sh.data(), sh.size() * sizeof(float), hipMemcpyHostToDevice));
+                    B.sc_in_exp = cur.exp; B.sc_out_exp = out.exp;
+                }
+                const double opx = (double)n * out.H * out.W;
+                if (e.profiling) {
+                    e.prof_begin(B.down.name, true, opx * cur.C * out.C, s, opx * (cur.C + out.C) * 4.0 + (double)cur.C * out.C * 4.0);
+                    e.prof.back().kernel = "shortcut1x1s2_kernel<" + std::to_string(cur.C) + ",split>";
+                }
+                const hipError_t err = shortcut1x1s2(cur, B.sc_wpk.ptr, (const float*)B.sc_scale.ptr, (const float*)B.sc_shift.ptr, out,
+                                                     e.guard_ptr(), B.sc_id, s, /*split=*/true);
+                if (e.profiling) e.prof_end(s);
+                if (err != hipSuccess) return hip_fail(err, "shortcut1x1s2 (split)");
             } else {
                 CV_TRY(down_beside_conv1(cur, B.sc.ref(n)));
             }
