@@ -130,7 +130,7 @@ static int impl_cv_engine_destroy(cv_engine_t* eng) {
     if (!eng) return CV_OK;
     {
         DeviceGuard g(eng->impl.device);
-        (void)hipDeviceSynchronize();
+        (void)device_synchronize();
         eng->impl.unet.reset();
         eng->impl.resnet.reset();
     }
@@ -235,9 +235,9 @@ static int impl_cv_get_activation(cv_engine_t* eng, const char* model, const cha
     DeviceBuffer tmp;
     s = tmp.alloc(numel * sizeof(float), false);
     if (!s.ok()) return finish(s);
-    hipError_t e = hipDeviceSynchronize();
+    hipError_t e = device_synchronize();
     if (e == hipSuccess) e = unpack_nchw_f32(t.f32_only ? (int)kF32 : eng->impl.dt, t, (float*)tmp.ptr, nullptr);
-    if (e == hipSuccess) e = hipMemcpy(out_host, tmp.ptr, numel * sizeof(float), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = sync_memcpy(out_host, tmp.ptr, numel * sizeof(float), hipMemcpyDeviceToHost);
     if (e != hipSuccess) return finish(hip_fail(e, "cv_get_activation"));
     return CV_OK;
 }
@@ -557,7 +557,7 @@ static int impl_cv_engine_calibration(cv_engine_t* eng, const char* model, int32
         if (a->split_c) a->exp2 = exps[2 * i + 1];
     }
     if (changed) {                                                // the layers re-fold their epilogue constants at their next launch
-        hipError_t he = hipDeviceSynchronize();
+        hipError_t he = device_synchronize();
         if (he != hipSuccess) return finish(hip_fail(he, "cv_engine_import_calibration"));
         e.graph_invalidate();
         e.graph_clear();
@@ -830,12 +830,12 @@ static int impl_cv_selftest_mfma(cv_engine_t* eng, float* max_err_f16, float* ma
     float err16 = 0.f, err32 = 0.f;
     if (!(s = da.upload(a16, sizeof(a16))).ok() || !(s = db.upload(b16, sizeof(b16))).ok() || !(s = dd.alloc(sizeof(got), true)).ok()) return finish(s);
     e = mfma_probe_f16((const half_t*)da.ptr, (const half_t*)db.ptr, (float*)dd.ptr, nullptr);
-    if (e == hipSuccess) e = hipMemcpy(got, dd.ptr, sizeof(got), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = sync_memcpy(got, dd.ptr, sizeof(got), hipMemcpyDeviceToHost);
     if (e != hipSuccess) return finish(hip_fail(e, "mfma_probe_f16"));
     for (int i = 0; i < 256; ++i) err16 = std::max(err16, std::fabs(got[i] - ref16[i]));
     if (!(s = da.upload(a32, sizeof(a32))).ok() || !(s = db.upload(b32, sizeof(b32))).ok()) return finish(s);
     e = mfma_probe_f32((const float*)da.ptr, (const float*)db.ptr, (float*)dd.ptr, nullptr);
-    if (e == hipSuccess) e = hipMemcpy(got, dd.ptr, sizeof(got), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = sync_memcpy(got, dd.ptr, sizeof(got), hipMemcpyDeviceToHost);
     if (e != hipSuccess) return finish(hip_fail(e, "mfma_probe_f32"));
     for (int i = 0; i < 256; ++i) err32 = std::max(err32, std::fabs(got[i] - ref32[i]));
     if (max_err_f16) *max_err_f16 = err16;

@@ -27,6 +27,27 @@ Status hip_fail(hipError_t e, const char* what) {
     return fail(2, std::string(what) + ": " + hipGetErrorString(e));
 }
 
+// ---- legacy-stream operations vs graph capture (engine.h) ----------------------------------------
+std::shared_mutex& capture_mutex() {
+    static std::shared_mutex mu;
+    return mu;
+}
+hipError_t sync_memcpy(void* dst, const void* src, size_t n, hipMemcpyKind kind) {
+    if (capture_flag()) return hipErrorStreamCaptureUnsupported;         // this thread is recording: its caller falls back to an eager run
+    std::shared_lock<std::shared_mutex> lk(capture_mutex());
+    return hipMemcpy(dst, src, n, kind);
+}
+hipError_t sync_memset(void* dst, int value, size_t n) {
+    if (capture_flag()) return hipErrorStreamCaptureUnsupported;
+    std::shared_lock<std::shared_mutex> lk(capture_mutex());
+    return hipMemset(dst, value, n);
+}
+hipError_t device_synchronize() {
+    if (capture_flag()) return hipErrorStreamCaptureUnsupported;
+    std::shared_lock<std::shared_mutex> lk(capture_mutex());
+    return hipDeviceSynchronize();
+}
+
 // ---- device memory -------------------------------------------------------------------------------
 DeviceBuffer::~DeviceBuffer() {
     if (ptr) (void)hipFree(ptr);
@@ -37,12 +58,12 @@ Status DeviceBuffer::alloc(size_t n, bool zero) {
     if (n == 0) return Status();
     hipError_t e = hipMalloc(&ptr, n);
     if (e != hipSuccess) { ptr = nullptr; return fail(4, std::string("hipMalloc(") + std::to_string(n) + "): " + hipGetErrorString(e)); }
-    if (zero) CV_HIP(hipMemset(ptr, 0, n));
+    if (zero) CV_HIP(sync_memset(ptr, 0, n));
     return Status();
 }
 Status DeviceBuffer::upload(const void* host, size_t n) {
     CV_TRY(alloc(n, false));
-    CV_HIP(hipMemcpy(ptr, host, n, hipMemcpyHostToDevice));
+    CV_HIP(sync_memcpy(ptr, host, n, hipMemcpyHostToDevice));
     return Status();
 }
 
@@ -227,8 +248,8 @@ Status ConvLayer::set_exps(int in_exp_, int out_exp_, hipStream_t s) {
         sh[i] = std::ldexp(h_shift[i], -out_exp_);
         if (!std::isfinite(sc[i]) || !std::isfinite(sh[i])) return fail(1, name + ": range factors leave the f32 range");
     }
-    CV_HIP(hipMemcpy(scale.ptr, sc.data(), sc.size() * sizeof(float), hipMemcpyHostToDevice));
-    CV_HIP(hipMemcpy(shift.ptr, sh.data(), sh.size() * sizeof(float), hipMemcpyHostToDevice));
+    CV_HIP(sync_memcpy(scale.ptr, sc.data(), sc.size() * sizeof(float), hipMemcpyHostToDevice));
+    CV_HIP(sync_memcpy(shift.ptr, sh.data(), sh.size() * sizeof(float), hipMemcpyHostToDevice));
     in_exp = in_exp_; out_exp = out_exp_;
     return Status();
 }
@@ -510,7 +531,7 @@ unsigned Engine::register_layer(const std::string& name) {
 Status Engine::guard_init() {
     if (guard.ptr) return Status();
     CV_TRY(guard.alloc(sizeof(unsigned), false));
-    CV_HIP(hipMemset(guard.ptr, 0xff, sizeof(unsigned)));
+    CV_HIP(sync_memset(guard.ptr, 0xff, sizeof(unsigned)));
     CV_TRY(cal_word.alloc(sizeof(unsigned), true));
     return Status();
 }
@@ -527,7 +548,7 @@ Status Engine::guard_read_async(unsigned* pinned, hipStream_t s) {
 
 Status Engine::guard_eval(unsigned v) {
     if (v == 0xffffffffu) return Status();
-    CV_HIP(hipMemset(guard.ptr, 0xff, sizeof(unsigned)));
+    CV_HIP(sync_memset(guard.ptr, 0xff, sizeof(unsigned)));
     const std::string who = v < layer_names.size() ? layer_names[v] : ("layer #" + std::to_string(v));
     if (v == 0) return fail(5, "non-finite value (NaN / inf) in the input tensor");
     return fail(5, "non-finite value produced by '" + who + "': an activation left the range the " +
@@ -542,7 +563,7 @@ Status Engine::guard_check(hipStream_t s) {
     CV_HIP(hipMemcpyAsync(&v, guard.ptr, sizeof(v), hipMemcpyDeviceToHost, s));
     CV_HIP(hipStreamSynchronize(s));
     if (v == 0xffffffffu) return Status();
-    CV_HIP(hipMemset(guard.ptr, 0xff, sizeof(unsigned)));
+    CV_HIP(sync_memset(guard.ptr, 0xff, sizeof(unsigned)));
     const std::string who = v < layer_names.size() ? layer_names[v] : ("layer #" + std::to_string(v));
     if (v == 0) return fail(5, "non-finite value (NaN / inf) in the input tensor");
     return fail(5, "non-finite value produced by '" + who + "': an activation left the range the " +
@@ -820,7 +841,7 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
     if (stamp_dev) {
         std::vector<unsigned long long> h(stamp_n);
         (void)hipStreamSynchronize(s);
-        (void)hipMemcpy(h.data(), stamp_dev, stamp_n * 8, hipMemcpyDeviceToHost);
+        (void)sync_memcpy(h.data(), stamp_dev, stamp_n * 8, hipMemcpyDeviceToHost);
         (void)hipFree(stamp_dev);
         std::vector<double> cyc, clk, wfrac, hd, is, tl, ep;
         double stages = 0;

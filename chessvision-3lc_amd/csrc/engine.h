@@ -7,6 +7,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -18,6 +19,16 @@ namespace cv {
 
 bool& capture_flag();                               // this thread is recording a forward pass into a hipGraph: nothing may allocate,
                                                     // copy synchronously or synchronise (such paths fail, the caller re-runs eagerly)
+// Legacy-stream operations (synchronous copies / fills, whole-device synchronisation) against graph capture: the runtime refuses a
+// legacy-stream operation while ANY stream of the process records a graph ("operation would make the legacy stream depend on a
+// capturing blocking stream" -- seen with eight request slots, one thread capturing its second call while another uploaded the offset
+// tables of its first).  Every such call of this library goes through these helpers, which hold capture_mutex() shared; a capture
+// (Engine::run_graphed) takes it exclusively, by try_lock only -- a request thread never waits for somebody's model load, it runs
+// eagerly once more and captures next time.
+std::shared_mutex& capture_mutex();
+hipError_t sync_memcpy(void* dst, const void* src, size_t n, hipMemcpyKind kind);
+hipError_t sync_memset(void* dst, int value, size_t n);
+hipError_t device_synchronize();
 void set_error(const std::string& msg);
 const char* get_error();
 
@@ -334,7 +345,7 @@ Status Engine::calibrate(const std::vector<Activation*>& acts, Fwd&& forward, hi
         calibrating = false;
         if (!st.ok()) return st;
         CV_HIP(hipStreamSynchronize(s));
-        CV_HIP(hipMemset(guard.ptr, 0xff, sizeof(unsigned)));      // overflow during calibration is expected, not an error
+        CV_HIP(sync_memset(guard.ptr, 0xff, sizeof(unsigned)));      // overflow during calibration is expected, not an error
         bool changed = false;
         auto adjust = [&](int& ex, float seen, bool bad) {
             int want = ex;
@@ -371,7 +382,7 @@ Status Engine::calibrate_rounding_bias(const std::vector<ConvLayer*>& layers, Fw
     calibrating = false;
     if (!st.ok()) return st;
     CV_HIP(hipStreamSynchronize(s));
-    CV_HIP(hipMemset(guard.ptr, 0xff, sizeof(unsigned)));
+    CV_HIP(sync_memset(guard.ptr, 0xff, sizeof(unsigned)));
     for (ConvLayer* L : layers) {
         CV_TRY(L->fold_rounding_bias());
         std::vector<float>().swap(L->h_round_err);      // 4 bytes per weight of host memory: not needed again
@@ -412,12 +423,15 @@ Status Engine::run_graphed(const GraphKey& key, hipStream_t s, Run&& run) {
     if (hit->graph) { (void)hipGraphDestroy(hit->graph); hit->graph = nullptr; }
     if (!capture_stream && hipStreamCreateWithFlags(&capture_stream, hipStreamNonBlocking) != hipSuccess) { graphs_on = false; return run(s); }
     const uint64_t epoch0 = graph_epoch;
+    std::unique_lock<std::shared_mutex> capture_lock(capture_mutex(), std::try_to_lock);
+    if (!capture_lock.owns_lock()) return run(s);       // somebody is loading a model / growing a workspace: capture on a later call
     if (hipStreamBeginCapture(capture_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); graphs_on = false; return run(s); }
     capture_flag() = true;
     Status st = run(capture_stream);
     capture_flag() = false;
     hipGraph_t graph = nullptr;
     const hipError_t ce = hipStreamEndCapture(capture_stream, &graph);
+    capture_lock.unlock();
     if (!st.ok() || ce != hipSuccess || !graph || graph_epoch != epoch0) {
         if (graph) (void)hipGraphDestroy(graph);
         (void)hipGetLastError();

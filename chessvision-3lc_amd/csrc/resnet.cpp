@@ -231,7 +231,7 @@ Status resnet_load(Engine& e, const ParamMap& pm) {
         for (ConvLayer* l : L) fits = fits && l->dt == kF16 && l->ct == 64 && l->rows == 64 && l->nStages == 9 && l->nCt == 1 && l->w.bytes >= one && l->halo_ok;
         if (fits) {
             CV_TRY(R.chain_w.alloc(4 * one, false));
-            for (int i = 0; i < 4; ++i) CV_HIP(hipMemcpy((char*)R.chain_w.ptr + i * one, L[i]->w.ptr, one, hipMemcpyDeviceToDevice));
+            for (int i = 0; i < 4; ++i) CV_HIP(sync_memcpy((char*)R.chain_w.ptr + i * one, L[i]->w.ptr, one, hipMemcpyDeviceToDevice));
             R.chain_ok = true;
         }
     }
@@ -296,7 +296,7 @@ Status resnet_load(Engine& e, const ParamMap& pm) {
             }, nullptr);
         }
         if (st.ok()) {
-            hipError_t he = hipDeviceSynchronize();
+            hipError_t he = device_synchronize();
             if (he != hipSuccess) st = hip_fail(he, "ResNet-18 calibration");
         }
     }
@@ -308,7 +308,7 @@ static Status resnet_reserve(Engine& e, int n) {
     Engine::ResNet& R = *e.resnet;
     const int want = std::min(R.max_cap, std::max(n, 1));
     if (want <= R.cap) return Status();
-    CV_HIP(hipDeviceSynchronize());
+    CV_HIP(device_synchronize());
     e.graph_invalidate();                            // captured launches hold the old buffers
     CV_TRY(Activation::reserve_all(R.acts, want));
     R.cap = want;
@@ -414,8 +414,8 @@ static Status resnet_chunk(Engine& e, const void* x, bool x_u8, int n, float* ou
                             sh[k] = std::ldexp(B.h_sc_shift[k], -out32.exp);
                             if (!std::isfinite(sc[k]) || !std::isfinite(sh[k])) return fail(1, "shortcut: range factors leave the f32 range");
                         }
-                        CV_HIP(hipMemcpy(B.sc_scale.ptr, sc.data(), sc.size() * sizeof(float), hipMemcpyHostToDevice));
-                        CV_HIP(hipMemcpy(B.sc_shift.ptr, sh.data(), sh.size() * sizeof(float), hipMemcpyHostToDevice));
+                        CV_HIP(sync_memcpy(B.sc_scale.ptr, sc.data(), sc.size() * sizeof(float), hipMemcpyHostToDevice));
+                        CV_HIP(sync_memcpy(B.sc_shift.ptr, sh.data(), sh.size() * sizeof(float), hipMemcpyHostToDevice));
                         B.sc_in_exp = in32.exp; B.sc_out_exp = out32.exp;
                     }
                     const double opx = (double)n * out32.H * out32.W;
@@ -442,8 +442,8 @@ static Status resnet_chunk(Engine& e, const void* x, bool x_u8, int n, float* ou
                         sh[k] = std::ldexp(B.h_sc_shift[k], -out.exp);
                         if (!std::isfinite(sc[k]) || !std::isfinite(sh[k])) return fail(1, "shortcut: range factors leave the f32 range");
                     }
-                    CV_HIP(hipMemcpy(B.sc_scale.ptr, sc.data(), sc.size() * sizeof(float), hipMemcpyHostToDevice));
-                    CV_HIP(hipMemcpy(B.sc_shift.ptr, sh.data(), sh.size() * sizeof(float), hipMemcpyHostToDevice));
+                    CV_HIP(sync_memcpy(B.sc_scale.ptr, sc.data(), sc.size() * sizeof(float), hipMemcpyHostToDevice));
+                    CV_HIP(sync_memcpy(B.sc_shift.ptr, sh.data(), sh.size() * sizeof(float), hipMemcpyHostToDevice));
                     B.sc_in_exp = cur.exp; B.sc_out_exp = out.exp;
                 }
                 const double opx = (double)n * out.H * out.W;

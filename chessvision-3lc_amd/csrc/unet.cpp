@@ -316,7 +316,7 @@ Status unet_load(Engine& e, const ParamMap& pm) {
             }, nullptr);
         }
         if (st.ok()) {
-            hipError_t he = hipDeviceSynchronize();
+            hipError_t he = device_synchronize();
             if (he != hipSuccess) st = hip_fail(he, "UNet calibration");
         }
     }
@@ -329,7 +329,7 @@ static Status unet_reserve(Engine& e, int n) {
     Engine::UNet& U = *e.unet;
     const int want = std::min(U.max_cap, std::max(n, 1));
     if (want <= U.cap) return Status();
-    CV_HIP(hipDeviceSynchronize());                  // nothing may still read the buffers about to be replaced
+    CV_HIP(device_synchronize());                  // nothing may still read the buffers about to be replaced
     e.graph_invalidate();                            // captured launches hold the old buffers
     CV_TRY(Activation::reserve_all(U.acts, want));
     U.cap = want;

@@ -1,0 +1,58 @@
+"""(test infrastructure, not collected by pytest) `ChessVision.process_image` from T request threads of one instance on T request
+slots: aggregate requests/s for T = 1, 2, 4, 8 (CHESSVISION_REQUEST_SLOTS decides how many slots exist).  Under
+`rocprofv3 --kernel-trace` (argument `trace <T>`) it runs T threads only, so that tests/dev/concurrent_overlap.py can reduce the
+kernel trace to busy / overlapped time.
+
+usage: python tests/dev/concurrent_probe.py [sweep | trace <threads>] [calls per thread]"""
+from __future__ import annotations
+
+import sys
+import tempfile
+import threading
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "chessvision-3lc_amd"))
+
+from chessvision import ChessVision, synthetic  # noqa: E402
+
+
+def run(cv, images, threads, calls):
+    def worker(t):
+        for k in range(calls):
+            cv.process_image(images[(t + k) % len(images)])
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(threads)]
+    t0 = time.perf_counter()
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    return threads * calls / (time.perf_counter() - t0)
+
+
+def main():
+    mode = sys.argv[1] if len(sys.argv) > 1 else "sweep"
+    with tempfile.TemporaryDirectory() as d:
+        pe, pc = synthetic.save_checkpoints(d, segmenting=True)
+        cv = ChessVision(board_extractor_weights=str(pe), classifier_weights=str(pc))
+        images = [synthetic.board_photo(700 + k) for k in range(8)]
+        for im in images:
+            cv.process_image(im)
+        if mode == "trace":
+            threads = int(sys.argv[2])
+            calls = int(sys.argv[3]) if len(sys.argv) > 3 else 100
+            cv.warm_request_slots(threads)
+            run(cv, images, threads, 20)
+            print(f"threads {threads}: {run(cv, images, threads, calls):.0f} requests/s", flush=True)
+            return
+        calls = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+        print(f"slots {cv.warm_request_slots()}")
+        for threads in (1, 2, 3, 4, 8):
+            run(cv, images, threads, 20)
+            print(f"threads {threads}: {run(cv, images, threads, calls):.0f} requests/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
