@@ -22,7 +22,7 @@ import torch
 
 _LIB_NAME = "libchessvision_hip.so"
 PREC_F32, PREC_F16, PREC_F16X3, PREC_F16R = 0, 1, 2, 3
-ABI_VERSION = 5
+ABI_VERSION = 6
 _PRECISIONS = {"f32": PREC_F32, "fp32": PREC_F32, "float32": PREC_F32, "f16": PREC_F16, "fp16": PREC_F16,
                "float16": PREC_F16, "f16x3": PREC_F16X3, "split": PREC_F16X3, "f16r": PREC_F16R}
 _PREC_NAMES = {PREC_F32: "f32", PREC_F16: "f16", PREC_F16X3: "f16x3", PREC_F16R: "f16r"}
@@ -113,6 +113,7 @@ SYMBOLS = [
     ("cv_engine_export_calibration", _i, [_vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int32), _i, ctypes.POINTER(_i)]),
     ("cv_engine_import_calibration", _i, [_vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int32), _i, ctypes.POINTER(_i)]),
     ("cv_process_image", _i, [_vp, _vp, _vp, _i, _i, _f, _i, _i, ctypes.c_void_p, _vp]),
+    ("cv_process_image_v2", _i, [_vp, _vp, _vp, _i, _i, _f, _i, _i, ctypes.c_void_p, ctypes.c_size_t, _vp]),
     ("cv_board_homographies", _i, [_fp, _i, _i, _i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     ("cv_decode_positions", _i, [_fp, _i, _i, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int8),
                                  ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
@@ -277,9 +278,9 @@ def process_image_native(unet_engine: "HipEngine", classifier_engine: "HipEngine
     res = _ImageResult()
     res.logits, res.mask, res.board = logits.ctypes.data, mask.ctypes.data, board.ctypes.data
     res.probabilities, res.squares, res.labels = probs.ctypes.data, squares.ctypes.data, None
-    _check(lib.cv_process_image(unet_engine._h, classifier_engine._h, img.ctypes.data, img.shape[0], img.shape[1],
-                                float(threshold), int(bool(flip)), int(bool(fallback_quad)), ctypes.byref(res),
-                                _stream_ptr(unet_engine.device) if stream is None else stream))       # stream: a request slot's own HIP stream
+    _check(lib.cv_process_image_v2(unet_engine._h, classifier_engine._h, img.ctypes.data, img.shape[0], img.shape[1],
+                                   float(threshold), int(bool(flip)), int(bool(fallback_quad)), ctypes.byref(res), ctypes.sizeof(res),
+                                   _stream_ptr(unet_engine.device) if stream is None else stream))    # stream: a request slot's own HIP stream
     out = {"logits": logits, "mask": mask, "found": bool(res.found)}
     if res.found:
         out.update(quadrangle=np.frombuffer(res.quadrangle, dtype=np.float32).reshape(4, 1, 2).copy(), board=board, probabilities=probs, squares=squares,

@@ -498,7 +498,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(halo_wa
                         for (int k = 0; k < 4; ++k) t[k] = acc[f][g0 + r][k] * sc[f * 4 + k] + sh[f * 4 + k];
                         *reinterpret_cast<f4*>(stg + r * (16 * SROW) + l15 * SROW + (q * 16 + f * 4) * 4) = t;
                     }
-                asm volatile("" ::: "memory");
+                wave_lds_sync();
 #pragma unroll
                 for (int i = 0; i < UPL; ++i) {
                     const int unit = lane + 64 * i, px = unit / UPP, cu = unit % UPP;
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(halo_wa
                         hold[g0 + r][i] = h;
                     }
                 }
-                asm volatile("" ::: "memory");
+                wave_lds_sync();
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave has read its staged rows back: the buffer becomes the halo again
 #pragma unroll
@@ -961,7 +961,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(halo_wa
                 }
                 *reinterpret_cast<f4*>(stg + r * (16 * SROW) + l15 * SROW + (q * NV + f * 4) * 4) = t;
             }
-        asm volatile("" ::: "memory");
+        wave_lds_sync();
 #pragma unroll
         for (int i = 0; i < UPL; ++i) {
             const int unit = lane + 64 * i;
@@ -1046,7 +1046,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(halo_wa
                 }
             }
         }
-        asm volatile("" ::: "memory");
+        wave_lds_sync();
     }
 #if CV_STAMP
     const unsigned long long st_e1 = __builtin_amdgcn_s_memtime();

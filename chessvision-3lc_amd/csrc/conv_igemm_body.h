@@ -387,7 +387,7 @@
             for (int r = 0; r < 4; ++r) t[r] = acc[f][g][r] * sc[f * 4 + r] + sh[f * 4 + r];
             *reinterpret_cast<f4*>(stg + l15 * SROW + (q * NV + f * 4) * 4) = t;
         }
-        asm volatile("" ::: "memory");
+        wave_lds_sync();
 #pragma unroll
         for (int i = 0; i < UPL; ++i) {
             const int unit = lane + 64 * i;
@@ -430,6 +430,6 @@
                 }
             }
         }
-        asm volatile("" ::: "memory");
+        wave_lds_sync();
     }
     report_bad(p, bad);

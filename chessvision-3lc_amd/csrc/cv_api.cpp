@@ -577,7 +577,11 @@ static int impl_cv_board_homographies(const float* quads, int n, int out_w, int 
 static Status resize_on_stream(Engine& en, const uint8_t* src, int n, int h, int w_, int channels, uint8_t* dst, int out_h, int out_w, hipStream_t st);
 
 static int impl_cv_process_image(cv_engine_t* ue, cv_engine_t* ce, const uint8_t* image, int h, int w_, float threshold, int flip,
-                                 int fallback_quad, cv_image_result_t* out, void* stream) {
+                                 int fallback_quad, cv_image_result_t* out, size_t out_size, void* stream) {
+    // the caller's struct may be the shorter one of an earlier ABI: nothing at or beyond out_size is touched
+    if (out && out_size < offsetof(cv_image_result_t, n_fixes) + sizeof(int32_t))
+        return finish(fail(CV_ERR_INVALID, "cv_process_image: result struct smaller than the ABI 3 layout"));
+    uint8_t* const out_squares = (out && out_size >= offsetof(cv_image_result_t, squares) + sizeof(uint8_t*)) ? out->squares : nullptr;
     Status s = check_engine(ue);
     if (s.ok()) s = check_engine(ce);
     if (!s.ok()) return finish(s);
@@ -719,11 +723,11 @@ static int impl_cv_process_image(cv_engine_t* ue, cv_engine_t* ce, const uint8_t
     if (out->logits) std::memcpy(out->logits, h_lg, lg_b);
     if (!found) return CV_OK;
     if (out->board) std::memcpy(out->board, h_bd, bd_b);
-    if (out->squares)                                        // extract_squares (core.py:419-439) on the host copy: 4096 rows of 64 bytes
+    if (out_squares)                                         // extract_squares (core.py:419-439) on the host copy: 4096 rows of 64 bytes
         for (int r = 0; r < 8; ++r)
             for (int c = 0; c < 8; ++c)
                 for (int y = 0; y < 64; ++y)
-                    std::memcpy(out->squares + ((size_t)(r * 8 + c) * 64 + y) * 64, h_bd + (size_t)(r * 64 + y) * 512 + c * 64, 64);
+                    std::memcpy(out_squares + ((size_t)(r * 8 + c) * 64 + y) * 64, h_bd + (size_t)(r * 64 + y) * 512 + c * 64, 64);
     if (out->probabilities) std::memcpy(out->probabilities, h_pr, pr_b);
     int8_t labels[64];
     decode_positions(h_pr, 1, flip, out->fen, out->original_fen, labels, out->fixes, &out->n_fixes);
@@ -974,10 +978,18 @@ int cv_engine_import_calibration(cv_engine_t* eng, const char* model, const int3
     });
 }
 
+int cv_process_image_v2(cv_engine_t* unet_engine, cv_engine_t* classifier_engine, const uint8_t* image, int h, int w, float threshold,
+                        int flip, int fallback_quad, cv_image_result_t* out, size_t out_size, void* stream) {
+    return guarded("cv_process_image_v2", [&]() -> int {
+        return impl_cv_process_image(unet_engine, classifier_engine, image, h, w, threshold, flip, fallback_quad, out, out_size, stream);
+    });
+}
+
 int cv_process_image(cv_engine_t* unet_engine, cv_engine_t* classifier_engine, const uint8_t* image, int h, int w, float threshold,
                      int flip, int fallback_quad, cv_image_result_t* out, void* stream) {
-    return guarded("cv_process_image", [&]() -> int {
-        return impl_cv_process_image(unet_engine, classifier_engine, image, h, w, threshold, flip, fallback_quad, out, stream);
+    return guarded("cv_process_image", [&]() -> int {      // the struct of ABI 3 / 4: `squares` did not exist
+        return impl_cv_process_image(unet_engine, classifier_engine, image, h, w, threshold, flip, fallback_quad, out,
+                                     offsetof(cv_image_result_t, squares), stream);
     });
 }
 

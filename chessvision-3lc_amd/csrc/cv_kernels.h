@@ -50,6 +50,18 @@ __device__ __forceinline__ void split_pair(float v0, float v1, unsigned& hp, uns
 #endif
 }
 
+// Hand-over of wave-private LDS staging between the lanes of ONE wave (epilogue transposes, pooled-row stores): the writes of every
+// lane are ordered before the reads of every lane at the language level -- release / acquire fences at wavefront scope around a wave
+// barrier -- instead of relying on a compiler-only barrier plus the fact that a wave's DS operations issue in order.
+// Costs no instruction: at wavefront scope the fences need no s_waitcnt and the barrier is a scheduling boundary only.
+__device__ __forceinline__ void wave_lds_sync() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+
 struct TensorRef {            // a channel slice of a PHWC tensor
     void* base;               // address of padded element (n=0, y=-1, x=-1, c=0)
     void* base32;             // f16r engine only: the tensor's unrounded f32 twin (same geometry, float elements) or null --

@@ -738,27 +738,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int i = 0; i < 16; i += Grp<T>::N)
                     Grp<T>::store(stg + l15 * SRA + (q * 16 + i) * ESZ, ((q * 16 + i) / Grp<T>::N) & 1, best + i, bad);
-                asm volatile("" ::: "memory");
+                wave_lds_sync();
                 char* const grow = reinterpret_cast<char*>(dst.base) + pix_index(dst, sq, py, 0) * (size_t)PB;
 #pragma unroll
                 for (int t = 0; t < 16 * PB / 1024; ++t) {
                     const int o = t * 1024 + lane * 16;
                     *reinterpret_cast<u4*>(grow + o) = *reinterpret_cast<const u4*>(stg + (o / PB) * SRA + (o % PB));
                 }
-                asm volatile("" ::: "memory");
+                wave_lds_sync();
                 if constexpr (__is_same(T, half_t) && SPLIT) {
                     if (dst.base32) {
 #pragma unroll
                         for (int i = 0; i < 16; i += 4)
                             *reinterpret_cast<f4*>(stg + l15 * 272 + (q * 16 + i) * 4) = f4{best[i], best[i + 1], best[i + 2], best[i + 3]};
-                        asm volatile("" ::: "memory");
+                        wave_lds_sync();
                         char* const grow32 = reinterpret_cast<char*>(dst.base32) + pix_index(dst, sq, py, 0) * (size_t)256;
 #pragma unroll
                         for (int t = 0; t < 4; ++t) {
                             const int o = t * 1024 + lane * 16;
                             *reinterpret_cast<u4*>(grow32 + o) = *reinterpret_cast<const u4*>(stg + (o / 256) * 272 + (o % 256));
                         }
-                        asm volatile("" ::: "memory");
+                        wave_lds_sync();
                     }
                 }
             }
@@ -859,7 +859,7 @@ __global__ __launch_bounds__(256) void inc0_mfma_kernel(const XT* __restrict__ x
             for (int k = 0; k < 4; ++k) t[k] = __builtin_fmaxf(acc[f][k] * sc[f * 4 + k] + sh[f * 4 + k], 0.f);
             *reinterpret_cast<f4*>(stg + l15 * SROW + (q * 16 + f * 4) * 4) = t;
         }
-        asm volatile("" ::: "memory");
+        wave_lds_sync();
         const size_t row_pix = pix_index(dst, n, y0 + r, cb * 16);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {                                  // 16 px x 8 groups of 8 channels = 128 units
@@ -874,7 +874,7 @@ __global__ __launch_bounds__(256) void inc0_mfma_kernel(const XT* __restrict__ x
             char* d = grp_ptr<T>(dst, row_pix + px, g, &par);
             Grp<T>::store(d, par, w, out_bad);
         }
-        asm volatile("" ::: "memory");
+        wave_lds_sync();
     }
     report_bad(flag, layer_id, out_bad);
 }
@@ -1346,7 +1346,7 @@ __global__ __launch_bounds__(64 * NW) void shortcut1x1s2_lds_kernel(
                     for (int f = 0; f < 8; ++f) *reinterpret_cast<f4*>(stg + (l15 % SR) * SROW + (q * 32 + f * 4) * 4) = o[f];
                     if (q == 0) pixw[l15 % SR] = live ? (unsigned)opix : 0xffffffffu;
                 }
-                asm volatile("" ::: "memory");
+                wave_lds_sync();
 #pragma unroll
                 for (int j = 0; j < SR / 2; ++j) {
                     const int px = 2 * j + (lane >> 5), part = lane & 31;
@@ -1367,7 +1367,7 @@ __global__ __launch_bounds__(64 * NW) void shortcut1x1s2_lds_kernel(
                     if (op != 0xffffffffu) *reinterpret_cast<f4*>(y + (size_t)op * COUT + cg * 128 + part * 4) = v;
                     }
                 }
-                asm volatile("" ::: "memory");
+                wave_lds_sync();
             }
         } else {
         float* const yp = y + opix * COUT + c0;

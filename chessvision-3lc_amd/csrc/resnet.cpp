@@ -339,7 +339,13 @@ int64_t resnet_macs(Engine& e) { return e.resnet ? e.resnet->macs : 0; }
 Status resnet_activation(Engine& e, const std::string& name, TensorRef* out) {
     if (!e.resnet) return fail(3, "ResNet-18 not loaded");
     auto it = e.resnet->taps.find(name);
-    if (it == e.resnet->taps.end()) return fail(1, "unknown ResNet activation '" + name + "'");
+    if (it == e.resnet->taps.end()) {
+        // the fp16 classifier runs layer1 as ONE launch: conv1's outputs (and, in the one-workgroup form, block 0's output) exist in LDS only
+        if (e.resnet->chain_ok && (name == "layer1.0.act1" || name == "layer1.1.act1" || name == "layer1.0"))
+            return fail(1, "ResNet activation '" + name + "' is not materialised by precision f16r: layer1 runs as one chained launch and "
+                           "keeps it in LDS -- set CV_RESNET_CHAIN=0 before creating the engine to run layer1 as four launches");
+        return fail(1, "unknown ResNet activation '" + name + "'");
+    }
     *out = it->second;
     out->exp = static_cast<Activation*>(out->owner)->exp;
     out->N = e.resnet->last_n;

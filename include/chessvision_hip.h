@@ -41,10 +41,13 @@
 extern "C" {
 #endif
 
-#define CV_ABI_VERSION 5      /* 2: CV_PREC_F16R, CV_ERR_NUMERIC + cv_engine_numeric_status, cv_engine_set_chunk before cv_load_* only
+#define CV_ABI_VERSION 6      /* 2: CV_PREC_F16R, CV_ERR_NUMERIC + cv_engine_numeric_status, cv_engine_set_chunk before cv_load_* only
                                  3: cv_board_homographies, cv_engine_export/import_calibration, cv_process_image (additions only)
                                  4: cv_find_contours (addition); cv_find_quadrangle follows CHAIN_APPROX_TC89_KCOS
-                                 5: cv_image_result_t gains `squares` (appended; zero the struct before use, as before) */
+                                 5: cv_image_result_t gains `squares` (appended; zero the struct before use, as before)
+                                 6: cv_process_image_v2 (the caller states sizeof(cv_image_result_t) as IT was compiled); cv_process_image is
+                                    the ABI 3 / 4 entry point again and never touches `squares` -- a binary built against the shorter struct
+                                    of those versions is safe once more */
 
 enum cv_status {
     CV_OK = 0,
@@ -159,7 +162,11 @@ int cv_softmax13(cv_engine_t* eng, const float* logits, int n, float* probs, voi
 /* Copy an intermediate activation of the LAST forward chunk out of the workspace as float32 NCHW
  * (n,c,h,w written to dims[4]).  `name` is the producing module's state-dict prefix, e.g.
  * "inc.double_conv.3", "down4.maxpool_conv.1.double_conv.5" (= named_modules()[52],
- * train_unet.py:210), "up1.up", "layer1.0", "maxpool".  out_capacity in floats.  Synchronises. */
+ * train_unet.py:210), "up1.up", "layer1.0", "maxpool".  out_capacity in floats.  Synchronises.
+ * Tensors a fused launch never writes have no tap: under CV_PREC_F16R ResNet-18's layer1 runs as ONE chained launch, so
+ * "layer1.0.act1" / "layer1.1.act1" do not exist and "layer1.0" is read from the block's f32 twin (CV_ERR_INVALID naming
+ * CV_RESNET_CHAIN=0, the switch that runs layer1 as four launches and materialises them); the UNet's fused first two convolutions
+ * (CV_FUSE_INC=0 to split them) likewise leave "inc.double_conv.2" unwritten at the throughput sizes. */
 int cv_get_activation(cv_engine_t* eng, const char* model, const char* name, float* out_host,
                       size_t out_capacity, int64_t dims[4]);
 
@@ -293,6 +300,13 @@ typedef struct cv_image_result {
     uint8_t* squares;         /* 64 x 64 x 64 uint8 or NULL: PositionResult.squares, the board cut into its squares a8..h1 (the
                                  reference's extract_squares, utils.py:115-132: tile (r, c) = board[64 r .. 64 r + 63][64 c .. 64 c + 63]) */
 } cv_image_result_t;
+/* The struct grew once (ABI 5 appended `squares`) and may grow again, so the entry point takes the size of the struct AS THE CALLER
+ * COMPILED IT: fields at or beyond `out_size` are neither read nor written.  Pass sizeof(cv_image_result_t).  CV_ERR_INVALID when
+ * out_size does not even cover the ABI 3 fields (through n_fixes). */
+int cv_process_image_v2(cv_engine_t* unet_engine, cv_engine_t* classifier_engine, const uint8_t* image, int h, int w,
+                        float threshold, int flip, int fallback_quad, cv_image_result_t* out, size_t out_size, void* stream);
+/* ABI 3 / 4 entry point, kept for binaries built against the struct WITHOUT `squares`: identical to cv_process_image_v2 with out_size =
+ * offsetof(cv_image_result_t, squares), i.e. `squares` is never touched whatever the caller's struct holds there. */
 int cv_process_image(cv_engine_t* unet_engine, cv_engine_t* classifier_engine, const uint8_t* image, int h, int w,
                      float threshold, int flip, int fallback_quad, cv_image_result_t* out, void* stream);
 

@@ -9,6 +9,7 @@
  * int64 shape[4], float32 data.  squares.bin: int32 n, then n x 64 x 64 uint8.
  * Device memory comes from the HIP runtime's C API (the reference-side host owns its buffers; the library never frees them). */
 #include <stdint.h>
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -132,7 +133,7 @@ static int image_mode(const char* unet_blob, const char* resnet_blob, const char
     memset(&res, 0, sizeof(res));
     res.logits = logits; res.mask = mask; res.board = board; res.probabilities = probs; res.squares = crops;   /* squares: ABI 5 */
     for (int rep = 0; rep < 3; ++rep)                                         /* eager, graph capture, graph replay */
-        CHECK(cv_process_image(eng, eng, image, hw[0], hw[1], 0.5f, 0, 1, &res, NULL));
+        CHECK(cv_process_image_v2(eng, eng, image, hw[0], hw[1], 0.5f, 0, 1, &res, sizeof(res), NULL));   /* ABI 6: the struct size travels */
     printf("pi_found %d\npi_fen %s\npi_orig %s\npi_quad", (int)res.found, res.fen, res.original_fen);
     for (int i = 0; i < 8; ++i) printf(" %.9g", res.quadrangle[i]);
     unsigned long long msum = 0, bsum = 0;
@@ -143,7 +144,23 @@ static int image_mode(const char* unet_blob, const char* resnet_blob, const char
     printf("\npi_mask_sum %llu\npi_board_checksum %llu\npi_squares_checksum %llu\npi_probs", msum, bsum, csum);
     for (int i = 0; i < 64 * 13; ++i) printf(" %.9g", probs[i]);
     printf("\n");
-    int rc = cv_process_image(eng, eng, NULL, 512, 512, 0.5f, 0, 0, &res, NULL);
+    /* A binary built against the ABI 3 / 4 header: its struct ends after n_fixes, and whatever follows it in memory is NOT a `squares`
+     * pointer.  The old entry point must neither read nor write there (ABI 5 read it unconditionally and would have copied
+     * 256 KB to a garbage address). */
+    struct { unsigned char body[offsetof(cv_image_result_t, squares)]; unsigned char after[64]; } old;
+    memset(&old, 0, sizeof(old));
+    memset(old.after, 0xAB, sizeof(old.after));
+    cv_image_result_t* legacy = (cv_image_result_t*)(void*)&old;
+    static float probs2[64 * 13];
+    legacy->logits = logits; legacy->mask = mask; legacy->board = board; legacy->probabilities = probs2;
+    CHECK(cv_process_image(eng, eng, image, hw[0], hw[1], 0.5f, 0, 1, legacy, NULL));
+    int intact = 1;
+    for (size_t i = 0; i < sizeof(old.after); ++i) intact &= old.after[i] == 0xAB;
+    printf("pi_legacy_ok %d found %d same_fen %d same_probs %d\n", intact, (int)legacy->found, strcmp(legacy->fen, res.fen) == 0,
+           memcmp(probs, probs2, sizeof(probs)) == 0);
+    int rc_small = cv_process_image_v2(eng, eng, image, hw[0], hw[1], 0.5f, 0, 1, &res, 16, NULL);
+    printf("pi_short_struct rc=%d\n", rc_small);
+    int rc = cv_process_image_v2(eng, eng, NULL, 512, 512, 0.5f, 0, 0, &res, sizeof(res), NULL);
     printf("pi_null_image rc=%d msg=%s\n", rc, cv_last_error());
     CHECK(cv_engine_destroy(eng));
     return 0;

@@ -37,7 +37,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     for sym in declared:
         assert hasattr(lib, sym), f"{sym} declared in include/chessvision_hip.h but not exported"
         assert sym in bound, f"{sym} has no ctypes prototype in hip_backend.SYMBOLS"
-    assert lib.cv_abi_version() == hip_backend.ABI_VERSION == 5
+    assert lib.cv_abi_version() == hip_backend.ABI_VERSION == 6
 
 
 def test_code_object_targets_gfx950_only():

@@ -35,7 +35,7 @@ def test_host_entry_points_from_plain_c(tmp_path):
     out = subprocess.run([str(exe), "host"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     lines = dict(ln.split(" ", 1) for ln in out.stdout.strip().splitlines())
-    assert lines["abi"] == "5"
+    assert lines["abi"] == "6"
     assert float(lines["homography_err2"]) < 1e-16                        # cv_board_homographies from C: corners -> board corners, inv * fwd = I
     quad = [int(v) for v in lines["quad"].split()]
     assert quad[0] == 1                                                   # found; vertices = TR, TL, BL, BR of the drawn shape
@@ -130,3 +130,7 @@ def test_process_image_from_plain_c_equals_the_python_class(tmp_path):
     probs = np.array(lines["pi_probs"].split(), dtype=np.float64).astype(np.float32).reshape(64, 13)
     assert np.array_equal(probs, want.position.model_probabilities)
     assert lines["pi_null_image"].startswith("rc=1 msg=")
+    # ABI 6: a binary built against the ABI 3 / 4 struct (no `squares`) calls the old entry point -- the bytes behind its struct stay
+    # untouched and the results are the same; a struct too short for even that layout is refused
+    assert lines["pi_legacy_ok"] == "1 found 1 same_fen 1 same_probs 1", lines["pi_legacy_ok"]
+    assert lines["pi_short_struct"] == "rc=1"

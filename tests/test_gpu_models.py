@@ -189,6 +189,32 @@ def test_forward_passes_are_deterministic():
     eng.close()
 
 
+@pytest.mark.parametrize("prec", ["f16x3", "f16r", "f16", "f32"])
+def test_every_mfma_kernel_repeats_its_bits_over_many_runs(prec):
+    """the run-to-run differences round 5 chased came from inline asm next to independent MFMAs and were fixed in ONE
+    kernel.  Every MFMA kernel of every engine is repeated here: UNet at 1 (split-K launches, 8 x 16 patches), 3 and 8 boards (fused
+    first layer, halo tiles, transposed convolutions, fused pool / head), ResNet-18 at 64 (paired launches, split-K), 700 (ragged) and
+    4096 squares (position-major tiles, packed 8 x 8 images, the chained layer1 and dedicated shortcuts under f16r) -- eight forwards
+    each, alternating between shapes so that hipGraph replays and eager launches interleave; all bit-identical to the first."""
+    from chessvision.hip_backend import HipEngine
+
+    eng = HipEngine(precision=prec, unet_chunk=8, resnet_chunk=4096)
+    eng.load_unet(synth.make_unet(seed=1).state_dict())
+    eng.load_resnet18(synth.make_resnet(seed=2).state_dict())
+    xs = {b: synth.unet_input(seed=90 + b, batch=b).cuda() for b in (1, 3, 8)}
+    sqs = {n: synth.squares_input(seed=95 + n, n=n).cuda() for n in (64, 700, 4096)}
+    first = {}
+    for rep in range(8):
+        for b, x in xs.items():
+            out = eng.unet_forward(x, check=False)
+            assert torch.equal(first.setdefault(("u", b), out.clone()), out), (prec, "unet", b, rep)
+        for n, sq in sqs.items():
+            out = eng.resnet18_forward(sq, check=False)
+            assert torch.equal(first.setdefault(("r", n), out.clone()), out), (prec, "resnet18", n, rep)
+    eng.check_numerics()
+    eng.close()
+
+
 def test_empty_batches_are_no_ops():
     """B = 0 is legal at the seam (an image without a detected board yields no squares): shapes only, no launches."""
     from chessvision.hip_backend import HipEngine
