@@ -256,6 +256,8 @@ static hipError_t prepare_pos() {
 
 // the tiles that take position-major launches: the two 8-wave tiles (what the deep ResNet-18 stages run at throughput sizes)
 #define CV_FOR_EACH_POS_CFG(X, T)          \
+    X(T, 128, 128, 2, 2, 4, kCfg128x128)   \
+    X(T, 128, 128, 2, 3, 4, kCfg128x128)   \
     X(T, 128, 256, 2, 3, 8, kCfg128x256w8) \
     X(T, 256, 256, 4, 2, 8, kCfg256x256w8)
 
@@ -276,7 +278,7 @@ hipError_t conv_igemm_prepare() {
     return hipSuccess;
 }
 
-bool conv_cfg_has_pos(int cfg) { return cfg == kCfg128x256w8 || cfg == kCfg256x256w8; }
+bool conv_cfg_has_pos(int cfg) { return cfg == kCfg128x128 || cfg == kCfg128x256w8 || cfg == kCfg256x256w8; }
 
 hipError_t conv_igemm_pos_launch(int cfg, int ns, int dt, const ConvParams& p, hipStream_t stream) {
 #define X(T, CT, PT, WGC, NS, NW, ID) \

@@ -273,15 +273,17 @@ print("SHA", h.hexdigest())
 """
 
 
-@pytest.mark.parametrize("shape", ["forced_small", "production_chunk"])
+@pytest.mark.parametrize("shape", ["forced_small", "forced_small_128px_tiles", "production_chunk"])
 def test_position_major_rows_skip_the_zero_border_and_keep_every_bit(shape):
     """Round 6: the generic kernel's 3x3 launches on the 2x2 / 4x4 / 8x8 maps of ResNet-18 order their rows [output position][image] and
     walk only the K stages whose tap reads a real pixel (ConvParams::ptab): 5 of 9 taps of every position of a 2x2 map gather the zero
     border.  A skipped stage would have added exact zeros, so logits and the layer2-4 activations are BIT-IDENTICAL to CV_POS=0 -- in all
     four precisions, on full and ragged image tiles (256 / 300 / 700 squares with the 256-pixel tiles forced), and at the production
     chunk of 16384 squares where the 256 x 256 tile takes layer3 / layer4 by itself."""
-    base = {"POS_CHUNK": "1024", "POS_N": "256,300,700", "CV_CONV_PT": "256", "CV_SPLITK": "0"} if shape == "forced_small" else \
-           {"POS_CHUNK": "16384", "POS_N": "16384", "POS_PRECS": "f16x3,f16r"}
+    base = {"forced_small": {"POS_CHUNK": "1024", "POS_N": "256,300,700", "CV_CONV_PT": "256", "CV_SPLITK": "0"},
+            # the 4-wave 128 x 128 tile (what mid-size batches run: two workgroups per CU) takes position-major launches too
+            "forced_small_128px_tiles": {"POS_CHUNK": "1024", "POS_N": "128,200,700", "CV_CONV_PT": "128", "CV_SPLITK": "0", "CV_CT256": "0"},
+            "production_chunk": {"POS_CHUNK": "16384", "POS_N": "16384", "POS_PRECS": "f16x3,f16r"}}[shape]
     shas, layers = {}, {}
     for name, knobs in (("pos", {}), ("image_major", {"CV_POS": "0"})):
         env = dict(os.environ)
