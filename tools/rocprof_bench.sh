@@ -14,7 +14,7 @@ python3 - "$TRACE" "$OUT/bench_under_rocprof.json" "$OUT/kernel_trace_reduced.js
 import csv, json, sys
 trace, bench_json, out, steps, warm = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5])
 rows = sorted(csv.DictReader(open(trace)), key=lambda r: int(r["Start_Timestamp"]))
-conv = [r for r in rows if any(t in r["Kernel_Name"] for t in ("conv_igemm_kernel", "conv3x3_halo_kernel", "inc0_mfma_kernel"))]
+conv = [r for r in rows if any(t in r["Kernel_Name"] for t in ("conv_igemm_kernel", "conv3x3_halo_kernel", "inc0_mfma_kernel", "shortcut1x1s2"))]
 line = json.loads([l for l in open(bench_json) if l.startswith("{")][-1])
 per_step = line["roofline"]["launches_per_step"]
 # order of conv launches in the process: calibration ... | warm-up | timed region | then, per model (UNet, ResNet-18), one un-timed
