@@ -867,8 +867,8 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"e2e-cnn b={B}/GPU: UNet(3->1,{'bilinear' if bilinear else 'convT'}) 256x256 x{B} boards + ResNet-18(1ch,13cls) x{B * 64} squares "
-                               "per step; inputs in HBM (configs[3])",
+        "config": {"workload": f"e2e-cnn b={B}/GPU: UNet(3->1,{'bilinear' if bilinear else 'convT'}) 256x256 x{B} boards + ResNet-18(1ch,13cls) x{B * 64} squares/step; "
+                               "in HBM (configs[3])",
                    "boards_per_gpu": B, "global_boards_per_step": world * B, "unet_chunk": eff_unet,
                    "resnet_chunk": eff_resnet, "parallelism": f"replicas x{world}, boards sharded, weights RCCL-broadcast once",
                    "gflop_per_board": round(2 * macs_board / 1e9, 3)},
