@@ -36,7 +36,7 @@ import torch  # noqa: E402  (importing torch does not initialise the GPU)
 PEAK_TFLOPS = {"f32": 157.3, "f16": 2500.0, "f16x3": 2500.0 / 3.0, "f16r": 2500.0}
 MFMA_PER_MAC = {"f32": 1, "f16": 1, "f16x3": 3, "f16r": 1}
 HBM_PEAK_GBS = 8000.0
-PMC_FILE = "profiles/r05_pmc_traffic.json"
+PMC_FILE = "profiles/r06_pmc_traffic.json"
 
 
 def log(*a):

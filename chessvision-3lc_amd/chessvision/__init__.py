@@ -7,6 +7,15 @@ Sub-modules are imported lazily so that ``import chessvision.synthetic`` does no
 """
 from __future__ import annotations
 
+import os as _os
+
+# Request slots (core.py) run up to four ``process_image`` calls side by side, each on its own stream beside the engines' side
+# streams; the HIP runtime multiplexes all streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4) and two slots that
+# share a queue serialise (four request threads: 2086 -> 2313 requests/s with 16 queues).  The runtime reads the variable when it
+# initialises -- the first HIP call of the process, e.g. ``torch.cuda.is_available()`` -- so it is set here, at import, and only when the
+# host application has not chosen a value itself.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 __all__ = ["ChessVision", "BoardExtractor", "PieceClassifier", "HipEngine"]
 
 

@@ -125,13 +125,6 @@ def load_library():
     global _lib
     with _lib_lock:
         if _lib is None:
-            # Request slots (core.py) run up to four ``process_image`` calls side by side, each on its own stream next to the
-            # engines' side streams; the runtime multiplexes all streams of a process onto GPU_MAX_HW_QUEUES hardware queues
-            # (default 4) and two slots that land on one queue serialise (4 threads: 2086 -> 2313 requests/s with 16 queues).
-            # Read by the runtime when it initialises, so it only takes effect if nothing has touched the GPU yet; an explicit
-            # setting of the host application is respected.
-            if "GPU_MAX_HW_QUEUES" not in os.environ and not torch.cuda.is_initialized():
-                os.environ["GPU_MAX_HW_QUEUES"] = "16"
             path = library_path()
             if not path.exists():
                 raise HipBackendError(
