@@ -425,6 +425,7 @@ struct Knobs {
     // position-major rows + live-tap stage lists (ConvParams::ptab): 0 = off; at least pos_min_tiles pixel tiles of images per position;
     // maps up to pos_max_hw on a side
     int pos = env_int("CV_POS", 1), pos_min_tiles = env_int("CV_POS_MIN_TILES", 1), pos_max_hw = env_int("CV_POS_MAX_HW", 8);
+    int pos_small_ct = env_int("CV_POS_SMALL_CT", 1);   // 128-row tiles for position-major launches of under two rounds with unequal positions
 };
 static const Knobs& knobs() {
     static const Knobs k;
@@ -692,8 +693,8 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
         ct = 128;
         p.w = reinterpret_cast<const char*>(L.w_small.ptr);
     }
-    const int cfg = choose_cfg(ct, L.rows, p.M, L.nStages);
-    const int ns = choose_ns(cfg, dt, L.rows, p.M, L.nStages);
+    int cfg = choose_cfg(ct, L.rows, p.M, L.nStages);
+    int ns = choose_ns(cfg, dt, L.rows, p.M, L.nStages);
     p.nCt = (L.rows + conv_cfg_ct(cfg) - 1) / conv_cfg_ct(cfg);
     // 3x3 / stride-1 layers whose patch grid divides the image keep the input patch in LDS across the nine taps
     const bool halo_capable = L.k == 3 && L.stride == 1 && !L.shuffle && kbase != nullptr && L.nStages % 9 == 0 &&
@@ -778,6 +779,21 @@ Status Engine::run_conv(ConvLayer& L, const TensorRef& x, const TensorRef& y, co
         const int* porder = nullptr;
         double live = 1.0;
         CV_TRY(L.get_pos(x, Ho, Wo, &ptab, &pcount, &porder, &live));
+        // Unequal positions need more tiles than CUs for the longest-first walk to have anything to balance: a 256-row launch of
+        // under two rounds (4096 squares: layer3 = 16 positions x 16 image tiles = 256 workgroups, the 9-tap ones ARE the launch)
+        // takes the 128-row packing instead -- twice the tiles, each half as long (f16x3 layer3 at 4096 squares: 0.172 / 0.161 /
+        // 0.168 -> 0.153 / 0.140 / 0.147 ms; with equal positions or enough rounds the 256-row tile stays: fewest L2 -> LDS bytes per MFMA)
+        if (ct == 256 && L.w_small.ptr && live < 0.75 && blocks_for(L.rows, (int64_t)x.N, 256, 256) * Ho * Wo < 512 /* two rounds on 256 CUs */ &&
+            knobs().pos_small_ct) {
+            const int cfg2 = choose_cfg(128, L.rows, p.M, L.nStages);
+            if (conv_cfg_has_pos(cfg2) && x.N >= conv_cfg_pt(cfg2)) {
+                ct = 128;
+                p.w = reinterpret_cast<const char*>(L.w_small.ptr);
+                cfg = cfg2;
+                ns = choose_ns(cfg, dt, L.rows, p.M, L.nStages);
+                p.nCt = (L.rows + conv_cfg_ct(cfg) - 1) / conv_cfg_ct(cfg);
+            }
+        }
         p.ptab = ptab; p.pcount = pcount; p.porder = porder; p.posN = x.N; p.nPtPer = (x.N + conv_cfg_pt(cfg) - 1) / conv_cfg_pt(cfg);
         pos_major = true;
     }

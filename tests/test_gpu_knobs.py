@@ -273,7 +273,7 @@ print("SHA", h.hexdigest())
 """
 
 
-@pytest.mark.parametrize("shape", ["forced_small", "forced_small_128px_tiles", "production_chunk"])
+@pytest.mark.parametrize("shape", ["forced_small", "forced_small_128px_tiles", "production_chunk", "production_packing_mid_batch"])
 def test_position_major_rows_skip_the_zero_border_and_keep_every_bit(shape):
     """Round 6: the generic kernel's 3x3 launches on the 2x2 / 4x4 / 8x8 maps of ResNet-18 order their rows [output position][image] and
     walk only the K stages whose tap reads a real pixel (ConvParams::ptab): 5 of 9 taps of every position of a 2x2 map gather the zero
@@ -283,7 +283,10 @@ def test_position_major_rows_skip_the_zero_border_and_keep_every_bit(shape):
     base = {"forced_small": {"POS_CHUNK": "1024", "POS_N": "256,300,700", "CV_CONV_PT": "256", "CV_SPLITK": "0"},
             # the 4-wave 128 x 128 tile (what mid-size batches run: two workgroups per CU) takes position-major launches too
             "forced_small_128px_tiles": {"POS_CHUNK": "1024", "POS_N": "128,200,700", "CV_CONV_PT": "128", "CV_SPLITK": "0", "CV_CT256": "0"},
-            "production_chunk": {"POS_CHUNK": "16384", "POS_N": "16384", "POS_PRECS": "f16x3,f16r"}}[shape]
+            "production_chunk": {"POS_CHUNK": "16384", "POS_N": "16384", "POS_PRECS": "f16x3,f16r"},
+            # 4096 / 5000 squares on weights packed for the 16384-square chunk (configs[2]'s batch; a 64-board job of process_images):
+            # layer3's 256-row launch would be one round deep, so its unequal positions take the 128-row packing (CV_POS_SMALL_CT)
+            "production_packing_mid_batch": {"POS_CHUNK": "16384", "POS_N": "4096,5000"}}[shape]
     shas, layers = {}, {}
     for name, knobs in (("pos", {}), ("image_major", {"CV_POS": "0"})):
         env = dict(os.environ)
