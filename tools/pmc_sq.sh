@@ -12,7 +12,7 @@ import csv, json, sys, collections
 rows = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
 for r in csv.DictReader(open(sys.argv[1])):
     k = r["Kernel_Name"]
-    if "conv3x3_halo" not in k and "conv_igemm" not in k and "inc0_mfma" not in k: continue
+    if "conv3x3_halo" not in k and "conv_igemm" not in k and "inc0_mfma" not in k and "shortcut1x1s2" not in k: continue
     rows[k][r["Counter_Name"]] += float(r["Counter_Value"])
     if r["Counter_Name"] == "GRBM_GUI_ACTIVE": n[k] += 1
 out = {}

@@ -35,7 +35,7 @@ def per_dispatch(path, counter):
 def main():
     fetch, write, out, label = sys.argv[1:5]
     f, w = per_dispatch(fetch, "FETCH_SIZE"), per_dispatch(write, "WRITE_SIZE")
-    conv = lambda n: "conv_igemm" in n or "conv3x3_halo" in n or "inc0_mfma" in n      # the kernels of the conv family
+    conv = lambda n: "conv_igemm" in n or "conv3x3_halo" in n or "inc0_mfma" in n or "shortcut1x1s2" in n      # the kernels of the conv family
     fc = [v for k, (n, v) in f.items() if conv(n)]
     wc = [v for k, (n, v) in w.items() if conv(n)]
     assert len(fc) == len(wc) and fc, (len(fc), len(wc))
