@@ -231,7 +231,7 @@ def pin_rank_cpus(sysfs_root: str | None = None) -> list[int] | None:
     topo = None
     if os.environ.get("CV_PIN_TOPOLOGY", "1") != "0":
         topo = read_gpu_topology(sysfs_root or os.environ.get("CV_SYSFS_ROOT", "/sys"))
-    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0          # device_count does not initialise the GPU
+    n_dev = torch.cuda.device_count()              # counts devices without initialising the GPU runtime (no thread exists yet to inherit a mask)
     plan = plan_rank_cpus(cpus, lw, topo["gpu_cpus"], topo["siblings"], n_dev or None) if topo else None
     if plan is None:
         plan = plan_rank_cpus(cpus, lw)
