@@ -243,6 +243,11 @@ def test_four_request_threads_overlap_on_the_device_and_return_the_serial_result
     assert len(cv._slots) == 1                                    # a single-threaded caller never pays for replicas
     assert cv.warm_request_slots(4) == 4
     errors, bad = [], []
+    warm = [threading.Thread(target=lambda t=t: [cv.process_image(images[(t + k) % 8]) for k in range(20)]) for t in range(4)]
+    for th in warm:                                            # a replica's first call grows its workspace, its second records the hipGraphs
+        th.start()
+    for th in warm:
+        th.join(timeout=600)
 
     def worker(t):
         try:
