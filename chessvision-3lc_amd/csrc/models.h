@@ -17,6 +17,15 @@ struct Engine::UNet {
     int c1 = 64, c2 = 128, c3 = 256, c4 = 512, c5 = 1024;
     ConvLayer inc0, inc1, d[4][2], upT[4], u[4][2];
     unsigned up_id[4] = {0, 0, 0, 0}, outc_id = 0;  // numeric-guard ids of the non-conv producers
+    // split-f16 engine, throughput batches: up3.up / up4.up (K = 256 / 128: the whole weight block fits in LDS) on the persistent
+    // LDS-resident-weights kernel (pointwise.hip: convt2x2_lds) instead of the generic tile; upT[i] remains for calibration, small
+    // batches and CV_CONVT_FAST=0.  Same products in the same order: bit-identical.
+    struct FastUp {
+        bool on = false;
+        DeviceBuffer wpk, scale, shift;
+        std::vector<float> h_scale, h_shift;           // per GEMM row (dy, dx, co): 2^(row exponent) | bias
+        int in_exp = 1 << 20, out_exp = 1 << 20;       // exponents the device copies are folded for
+    } fast_up[4];
     DeviceBuffer outc_w, outc_b;
     DeviceBuffer inc0_wpk;                          // f16-based engines: MFMA image of inc.double_conv.0 for the fused first-layer kernel
     DeviceBuffer inc0_wpk2;                         // split-f16: the same layer for the in-kernel producer of inc.double_conv.3 (conv_halo.hip: FUSE0)

@@ -58,6 +58,12 @@ hipError_t softmax13(const float* logits, int n, float* probs, hipStream_t s);
 hipError_t shortcut1x1s2(const TensorRef& x32, const void* wpk, const float* scale, const float* shift, const TensorRef& y32,
                          unsigned* flag, unsigned layer_id, hipStream_t s, bool split = false);
 
+// UNet up3.up / up4.up (split-f16 engine): conv_transpose2d k2 s2 + bias, x (C in {128, 256}, own buffer) -> channel slice y (C/2 channels,
+// 2H x 2W) of the concatenated tensor, on the LDS-resident-weights kernel (`CONVT` form).  wpk as for shortcut1x1s2 with GEMM row
+// r = (dy * 2 + dx) * C/2 + co; scale / shift [2 C] (shift = the bias per row).
+hipError_t convt2x2_lds(const TensorRef& x, const void* wpk, const float* scale, const float* shift, const TensorRef& y, unsigned* flag,
+                        unsigned layer_id, hipStream_t s);
+
 // MFMA lane-map probes used by cv_selftest_mfma (D = A*B^T with A:16xK, B:16xK row-major)
 hipError_t mfma_probe_f16(const half_t* a, const half_t* b, float* d, hipStream_t s);   // K = 32
 hipError_t mfma_probe_f32(const float* a, const float* b, float* d, hipStream_t s);     // K = 16

@@ -1244,10 +1244,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // and the staged epilogue writes each group's hi and lo chunk from the lane pair that shares the group -- still one contiguous KB per
 // store instruction.  Products and their order (w_hi x_hi, w_lo x_hi, w_hi x_lo per 32-channel k-step) are those of conv_igemm_kernel
 // on split_t: bit-identical to the generic launch it replaces.
-template <int CIN, int NW, bool PREFETCH, bool STAGE, bool SPLIT = false>
+// CONVT (round 6, SPLIT only): the same GEMM shape -- K = Cin, 2 Cin rows -- is a k2 / s2 transposed convolution whose rows are (dy, dx, co),
+// 4 x Cin/2 of them: UNet up3.up (256 -> 128) and up4.up (128 -> 64).  Differences to the shortcut: the input pixels are dense (stride
+// 1: 16 consecutive pixels are 8-16 KB of contiguous memory), and a staged row group leaves as a PIXEL SHUFFLE -- rows of class (dy, dx)
+// go to output pixel (2 y + dy, 2 x + dx), channel slice [yCoff, yCoff + cout) of a buffer with yCs channels per pixel (the concatenated
+// skip | up tensor).  The generic 256 x 256 tile moves these two layers' bytes at 3.2 / 4.0 TB/s: a 4- or 8-stage K loop, then 256 KB of
+// stores per tile with nothing else resident on the CU; here the weights stay in LDS and eight persistent waves alternate loads, MFMAs
+// and full-line stores.  Products and their order are the generic kernel's: bit-identical.
+template <int CIN, int NW, bool PREFETCH, bool STAGE, bool SPLIT = false, bool CONVT = false>
 __global__ __launch_bounds__(64 * NW) void shortcut1x1s2_lds_kernel(
     const float* __restrict__ x, int n, int H, int W, const half8* __restrict__ wpk, const float* __restrict__ scale,
-    const float* __restrict__ shift, float* __restrict__ y, unsigned* flag, unsigned layer_id) {
+    const float* __restrict__ shift, float* __restrict__ y, unsigned* flag, unsigned layer_id, int yCs = 0, int yCoff = 0, int cout = 0) {
+    static_assert(!CONVT || (SPLIT && STAGE), "the transposed-convolution form exists for split-f16 tensors, staged stores");
     constexpr int COUT = 2 * CIN, KS = CIN / 32;
     extern __shared__ __attribute__((aligned(16))) char smem_sc[];
     half8* const wl = reinterpret_cast<half8*>(smem_sc);
@@ -1259,14 +1267,15 @@ __global__ __launch_bounds__(64 * NW) void shortcut1x1s2_lds_kernel(
     float* const sl = reinterpret_cast<float*>(smem_sc + (size_t)KS * 16 * 1024);
     if (threadIdx.x < 128) { sl[threadIdx.x] = scale[cg * 128 + threadIdx.x]; sl[128 + threadIdx.x] = shift[cg * 128 + threadIdx.x]; }
     __syncthreads();
-    const int Ho = H / 2, Wo = W / 2, M = n * Ho * Wo, ngroups = (M + 15) / 16;
+    const int Ho = CONVT ? H : H / 2, Wo = CONVT ? W : W / 2, M = n * Ho * Wo, ngroups = (M + 15) / 16;   // GEMM pixels = output pixels of the shortcut | INPUT pixels of the transposed convolution
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, l15 = lane & 15;
     const int c0 = cg * 128 + q * 32;
     auto src_of = [&](int pg) {
         int m = pg * 16 + l15;
         m = m < M ? m : M - 1;
         const int ox = m % Wo, oy = (m / Wo) % Ho, img = m / (Wo * Ho);
-        return x + ((size_t)(img * (H + 2) + 2 * oy + 1) * (W + 2) + 2 * ox + 1) * CIN + q * 8;
+        if constexpr (CONVT) return x + ((size_t)(img * (H + 2) + oy + 1) * (W + 2) + ox + 1) * CIN + q * 8;
+        else return x + ((size_t)(img * (H + 2) + 2 * oy + 1) * (W + 2) + 2 * ox + 1) * CIN + q * 8;
     };
     auto fetch = [&](const float* xp, f4 (&xv)[KS][2]) {
 #pragma unroll
@@ -1323,7 +1332,9 @@ __global__ __launch_bounds__(64 * NW) void shortcut1x1s2_lds_kernel(
         const bool live = m < M;
         const int mm = live ? m : M - 1;
         const int ox = mm % Wo, oy = (mm / Wo) % Ho, img = mm / (Wo * Ho);
-        const size_t opix = (size_t)(img * (Ho + 2) + oy + 1) * (Wo + 2) + ox + 1;
+        // shortcut: the output pixel; transposed convolution: output pixel (2 oy, 2 ox) of the 2H x 2W plane, class (dy, dx) adds dy rows + dx
+        const size_t opix = CONVT ? (size_t)(img * (2 * Ho + 2) + 2 * oy + 1) * (2 * Wo + 2) + 2 * ox + 1
+                                  : (size_t)(img * (Ho + 2) + oy + 1) * (Wo + 2) + ox + 1;
         if constexpr (STAGE) {
             // the accumulators leave each lane with 32 channels of ONE pixel: eight store instructions of 64 scattered 16-byte pieces.  Park
             // the wave's 16 x 128 tile in its own LDS corner (rows padded to 528 B) and read it back two whole pixel rows per instruction:
@@ -1360,8 +1371,15 @@ __global__ __launch_bounds__(64 * NW) void shortcut1x1s2_lds_kernel(
 #pragma unroll
                             for (int i = 0; i < 8; ++i) bad = __builtin_fmaf((float)(half_t)v[i], 0.f, bad);
                         }
+                        if constexpr (CONVT) {
+                            const int row = cg * 128 + gl * 8, cls = row / cout, co = row - cls * cout, ch0 = yCoff + co;
+                            if (op != 0xffffffffu)
+                                OutVec<split_t, 8>::store_half(reinterpret_cast<split_t*>(y) + ((size_t)op + (size_t)((cls >> 1) * (2 * Wo + 2) + (cls & 1))) * yCs + ch0,
+                                                               ch0, v, (part & 1) == ((ch0 >> 3) & 1));
+                        } else {
                         if (op != 0xffffffffu)
                             OutVec<split_t, 8>::store_half(reinterpret_cast<split_t*>(y) + (size_t)op * COUT + cg * 128 + gl * 8, gl * 8, v, (part & 1) == par);
+                        }
                     } else {
                     const f4 v = *reinterpret_cast<const f4*>(stg + px * SROW + part * 16);
                     if (op != 0xffffffffu) *reinterpret_cast<f4*>(y + (size_t)op * COUT + cg * 128 + part * 4) = v;
@@ -1434,6 +1452,37 @@ hipError_t shortcut1x1s2(const TensorRef& x32, const void* wpk, const float* sca
     else if (cin == 128) hipLaunchKernelGGL(shortcut1x1s2_kernel<128>, grid, block, 0, s, xb, x32.N, x32.H, x32.W, w, scale, shift, yb, flag, layer_id);
     else if (cin == 256) hipLaunchKernelGGL(shortcut1x1s2_kernel<256>, grid, block, 0, s, xb, x32.N, x32.H, x32.W, w, scale, shift, yb, flag, layer_id);
     else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// k2 / s2 transposed convolution (+ bias) between split-f16 tensors on the LDS-resident-weights kernel above (UNet up3.up, up4.up)
+hipError_t convt2x2_lds(const TensorRef& x, const void* wpk, const float* scale, const float* shift, const TensorRef& y, unsigned* flag,
+                        unsigned layer_id, hipStream_t s) {
+    const int cin = x.C, cout = y.C;
+    if ((cin != 128 && cin != 256) || 2 * cout != cin || x.Coff || x.Cs != cin || x.f32_only || y.f32_only || y.H != 2 * x.H || y.W != 2 * x.W ||
+        y.N != x.N || y.Coff % 8 || y.Cs % 8 || cout % 8)
+        return hipErrorInvalidValue;
+    const long long M = (long long)x.N * x.H * x.W;
+    if (M <= 0 || (long long)y.N * (y.H + 2) * (y.W + 2) >= (1ll << 32)) return hipErrorInvalidValue;
+    const int nw = 8, cgs = 2 * cin / 128;
+    const int groups = (int)((M + 15) / 16);
+    static const int per_cu = [] { const char* v = std::getenv("CV_CONVT_WGS"); return v && *v ? std::atoi(v) : 1; }();
+    int wgx = (256 * per_cu + cgs - 1) / cgs;                           // persistent: about per_cu workgroups per CU over all row groups
+    if (wgx > (groups + nw - 1) / nw) wgx = (groups + nw - 1) / nw;
+    if (wgx < 1) wgx = 1;
+    const dim3 grid((unsigned)wgx, (unsigned)cgs), block((unsigned)(64 * nw));
+    const size_t lds = (size_t)(cin / 32) * 16 * 1024 + 1024 + (size_t)nw * ((cin <= 128 ? 16 : 4) * 528 + 64);
+    const float* xb = reinterpret_cast<const float*>(x.base);
+    float* yb = reinterpret_cast<float*>(y.base);
+    const half8* w = reinterpret_cast<const half8*>(wpk);
+#define CV_CT_LAUNCH(CIN_)                                                                                                                 \
+    do {                                                                                                                                  \
+        static bool set_ = false;                                                                                                         \
+        if (!set_) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(shortcut1x1s2_lds_kernel<CIN_, 8, true, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set_ = true; } \
+        hipLaunchKernelGGL((shortcut1x1s2_lds_kernel<CIN_, 8, true, true, true, true>), grid, block, lds, s, xb, x.N, x.H, x.W, w, scale, shift, yb, flag, layer_id, y.Cs, y.Coff, cout); \
+    } while (0)
+    if (cin == 128) CV_CT_LAUNCH(128); else CV_CT_LAUNCH(256);
+#undef CV_CT_LAUNCH
     return hipGetLastError();
 }
 

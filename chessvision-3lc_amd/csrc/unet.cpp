@@ -214,6 +214,47 @@ Status unet_load(Engine& e, const ParamMap& pm) {
             known.push_back(p + ".up.weight"); known.push_back(p + ".up.bias");
             CV_TRY(U.upT[i].build_convT(p + ".up", dt, w, deep_c, deep_c / 2, b, px(lvl + 1)));
             U.upT[i].layer_id = e.register_layer(p + ".up");
+            static const bool fast_on = [] { const char* v = std::getenv("CV_CONVT_FAST"); return !(v && v[0] == '0'); }();
+            static const bool fast_256 = [] { const char* v = std::getenv("CV_CONVT_FAST_256"); return v && v[0] == '1'; }();
+            // measured (r06_tuning.md section 7): up4.up (K = 128) 0.40 -> 0.36 ms per 64 boards; up3.up (K = 256: 128 KB of weights leave
+            // room for four staged pixel rows per wave only) 0.255 -> 0.29 ms -- it stays on the generic tile unless CV_CONVT_FAST_256=1
+            if (dt == kSplit && fast_on && (deep_c == 128 || (deep_c == 256 && fast_256))) {
+                // split-f16 image of the (dy, dx, co) x ci matrix for convt2x2_lds: rows normalised to [0.5, 1) as ConvLayer rows are
+                // (finish_layer), hi / lo halves, [row group of 128][k-step of 32][fragment 8][hi | lo][lane 64][8]; MFMA row i of
+                // fragment f = row 32 (i/4) + 4 f + i%4 of the group
+                const int cin = deep_c, cout = deep_c / 2, rows = 4 * cout;
+                Engine::UNet::FastUp& F = U.fast_up[i];
+                std::vector<int> rex((size_t)rows, 0);
+                F.h_scale.assign((size_t)rows, 0.f); F.h_shift.assign((size_t)rows, 0.f);
+                auto wat = [&](int r, int ci) { const int d = r / cout, co = r - d * cout; return w[((size_t)ci * cout + co) * 4 + d]; };
+                for (int r = 0; r < rows; ++r) {
+                    float mx = 0.f;
+                    for (int ci = 0; ci < cin; ++ci) mx = std::max(mx, std::fabs(wat(r, ci)));
+                    if (mx > 0.f) (void)std::frexp(mx, &rex[r]);
+                    F.h_scale[r] = std::ldexp(1.f, rex[r]);
+                    F.h_shift[r] = b[r % cout];
+                }
+                const int KS = cin / 32, CG = rows / 128;
+                std::vector<_Float16> pk((size_t)CG * KS * 16 * 64 * 8);
+                for (int cg = 0; cg < CG; ++cg)
+                    for (int ks = 0; ks < KS; ++ks)
+                        for (int f = 0; f < 8; ++f)
+                            for (int lane = 0; lane < 64; ++lane) {
+                                const int ii = lane & 15, q = lane >> 4;
+                                const int r = cg * 128 + (ii / 4) * 32 + f * 4 + (ii % 4);
+                                for (int j = 0; j < 8; ++j) {
+                                    const float v = std::ldexp(wat(r, ks * 32 + q * 8 + j), -rex[r]);
+                                    const _Float16 hi = (_Float16)v;
+                                    const size_t at = ((((size_t)(cg * KS + ks) * 8 + f) * 2) * 64 + lane) * 8 + j;
+                                    pk[at] = hi;
+                                    pk[at + 64 * 8] = (_Float16)(v - (float)hi);
+                                }
+                            }
+                CV_TRY(F.wpk.upload(pk.data(), pk.size() * sizeof(_Float16)));
+                CV_TRY(F.scale.alloc((size_t)rows * sizeof(float), false));
+                CV_TRY(F.shift.alloc((size_t)rows * sizeof(float), false));
+                F.on = true;
+            }
             cat_c = skip_c + deep_c / 2;
             out_c = skip_c;
             mid_c = out_c;
@@ -427,7 +468,33 @@ static Status unet_chunk(Engine& e, const void* x, bool x_u8, int n, float* logi
     for (int i = 0; i < 4; ++i) {
         const int lvl = 3 - i;
         TensorRef up = U.cat[lvl].ref(n, enc_c[lvl], U.cat[lvl].C - enc_c[lvl]);
-        if (!U.bilinear) {
+        static const int fast_min = [] { const char* v = std::getenv("CV_CONVT_FAST_MIN"); return v && *v ? std::atoi(v) : 8; }();
+        if (!U.bilinear && U.fast_up[i].on && !e.calibrating && n >= fast_min) {
+            Engine::UNet::FastUp& F = U.fast_up[i];
+            if (F.in_exp != deep.exp || F.out_exp != up.exp) {          // fold the tensor exponents (ConvLayer::set_exps)
+                if (capture_flag()) return fail(1, "transposed-conv constants re-folded during graph capture");
+                CV_HIP(hipStreamSynchronize(s));
+                std::vector<float> sc(F.h_scale.size()), sh(sc.size());
+                for (size_t k = 0; k < sc.size(); ++k) {
+                    sc[k] = std::ldexp(F.h_scale[k], deep.exp - up.exp);
+                    sh[k] = std::ldexp(F.h_shift[k], -up.exp);
+                    if (!std::isfinite(sc[k]) || !std::isfinite(sh[k])) return fail(1, U.upT[i].name + ": range factors leave the f32 range");
+                }
+                CV_HIP(sync_memcpy(F.scale.ptr, sc.data(), sc.size() * sizeof(float), hipMemcpyHostToDevice));
+                CV_HIP(sync_memcpy(F.shift.ptr, sh.data(), sh.size() * sizeof(float), hipMemcpyHostToDevice));
+                F.in_exp = deep.exp; F.out_exp = up.exp;
+            }
+            if (e.profiling) {
+                const double ipx = (double)n * deep.H * deep.W;
+                e.prof_begin(U.upT[i].name, true, ipx * (double)U.upT[i].macs_per_out_pixel(), s,
+                             ipx * deep.C * esz + 4.0 * ipx * up.C * esz + (double)deep.C * up.C * 4 * esz);
+                e.prof.back().kernel = "convt2x2_lds_kernel<" + std::to_string(deep.C) + ",split>";
+            }
+            const hipError_t err = convt2x2_lds(deep, F.wpk.ptr, (const float*)F.scale.ptr, (const float*)F.shift.ptr, up, e.guard_ptr(),
+                                                U.upT[i].layer_id, s);
+            if (e.profiling) e.prof_end(s);
+            if (err != hipSuccess) return hip_fail(err, "convt2x2_lds");
+        } else if (!U.bilinear) {
             CV_TRY(e.run_conv(U.upT[i], deep, up, nullptr, false, s));
         } else {
             begin("upsample_bilinear2x", (double)n * deep.H * deep.W * deep.C * esz * 5.0);     // 1 read + 4 written elements

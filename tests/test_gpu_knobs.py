@@ -391,3 +391,47 @@ def test_split_shortcut_kernel_gives_the_bits_of_the_generic_launch():
         kernels[name] = out.stdout.split("KERNELS", 1)[1].split()[0]
     assert "shortcut1x1s2_kernel<64,split>" in kernels["dedicated"] and "shortcut1x1s2" not in kernels["generic"], kernels
     assert shas["dedicated"] == shas["generic"], shas
+
+
+CONVT_SCRIPT = r"""
+import hashlib, sys
+sys.path.insert(0, "ROOT"); sys.path.insert(0, "ROOT/chessvision-3lc_amd")
+import torch
+from chessvision.hip_backend import HipEngine
+from oracle import synth
+net = synth.make_unet(1)
+eng = HipEngine(precision="f16x3", unet_chunk=12)
+eng.load_unet(net.state_dict())
+h = hashlib.sha256()
+kernels = set()
+for b in (8, 11, 3):
+    x = synth.unet_input(500 + b, b)
+    got = eng.unet_forward(x.cuda()).cpu()
+    with torch.no_grad():
+        assert float((got - net(x)).abs().max()) <= 1e-3
+    h.update(got.numpy().tobytes())
+    for tap in ("up3.up", "up4.up"):
+        h.update(eng.activation("unet", tap).tobytes())
+    kernels |= {e["kernel"] for e in eng.profile("unet", x)[3] if e["name"] in ("up3.up", "up4.up")}
+eng.check_numerics()
+print("KERNELS", "|".join(sorted(kernels)))
+print("SHA", h.hexdigest())
+"""
+
+
+def test_lds_resident_transposed_conv_gives_the_bits_of_the_generic_launch():
+    """Round 6: UNet up3.up / up4.up (k2 s2 transposed convolutions with K = 256 / 128: the whole weight block fits in LDS) run on the
+    persistent LDS-resident-weights kernel in its CONVT form from 8 boards up -- dense input pixels, pixel-shuffle stores into the
+    channel slice of the concatenated tensor.  Same products in the same order as the generic 1-tap GEMM: logits and both up-sampled
+    tensors are bit-identical to CV_CONVT_FAST=0 at 8 and 11 boards (and at 3, where both runs take the generic launch)."""
+    shas, kernels = {}, {}
+    for name, knobs in (("lds", {"CV_CONVT_FAST_256": "1"}), ("generic", {"CV_CONVT_FAST": "0"})):     # (up3.up takes the kernel on request only: slower there)
+        env = dict(os.environ)
+        env.update(knobs)
+        out = subprocess.run([sys.executable, "-c", CONVT_SCRIPT.replace("ROOT", str(ROOT))], env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0 and "SHA" in out.stdout, (name, out.stdout[-500:], out.stderr[-3000:])
+        shas[name] = out.stdout.split("SHA", 1)[1].split()[0]
+        kernels[name] = out.stdout.split("KERNELS", 1)[1].split()[0]
+    assert "convt2x2_lds_kernel<128,split>" in kernels["lds"] and "convt2x2_lds_kernel<256,split>" in kernels["lds"], kernels
+    assert "convt2x2" not in kernels["generic"], kernels
+    assert shas["lds"] == shas["generic"], shas
