@@ -344,6 +344,41 @@ class ChessVision:
                     threading.Thread(target=self._build_slot, name="chessvision-slot-builder", daemon=True).start()
                 self._slot_cond.wait(timeout=1.0)
 
+    def close(self) -> None:
+        """Release everything the instance holds on the device and in page-locked memory NOW instead of at garbage collection: the
+        primary engines, the replica engines of the request slots, the exact-f32 instance behind the numeric-guard recovery, the
+        pipeline's streams, staging buffers and copy threads.  The instance goes back to its lazy state -- the next call loads the
+        models again -- so a long-running server can shed its GPU memory between bursts.  Not part of the reference's surface (its
+        torch modules are simply garbage-collected); idempotent.  Waits for in-flight ``process_image`` calls of other threads."""
+        with self._slot_cond:
+            while self._slot_building or any(slot.busy for slot in self._slots):
+                self._slot_cond.wait(timeout=0.1)
+            slots, self._slots = self._slots, []
+        with self._init_lock, self._native_lock:
+            twin, self._f32_twin = self._f32_twin, None
+            engines = {id(e): e for e in self._engines.values()}
+            for slot in slots:
+                for e in (slot.extractor_engine, slot.classifier_engine):
+                    engines.setdefault(id(e), e)
+            self._engines = {}
+            self._board_extractor = self._classifier = None
+            self._stage, self._last_board, self._streams = {}, None, None
+            pool, self._copy_pool = self._copy_pool, None
+        if pool is not None:
+            pool.shutdown(wait=True)
+        if twin is not None:
+            twin.close()
+        if engines and torch.cuda.is_available():
+            torch.cuda.synchronize(self.device)
+        for e in engines.values():
+            e.close()
+
+    def __enter__(self) -> "ChessVision":
+        return self
+
+    def __exit__(self, *exc) -> None:
+        self.close()
+
     def _staging(self, shape=None):
         """Page-locked staging buffers of the single-image path: mask, logits, board, squares, probabilities, homography (shared),
         and one image buffer per image shape seen (a server sees few distinct camera formats)."""

@@ -4,6 +4,7 @@ from __future__ import annotations
 
 import numpy as np
 import pytest
+import torch
 
 from chessvision import ChessVision, constants, synthetic
 
@@ -315,3 +316,28 @@ def test_repeated_process_image_calls_never_return_stale_staging(tmp_path):
         if f.position is not None:
             assert np.array_equal(r.board_extraction.board_image, f.board_extraction.board_image), it
             assert np.array_equal(r.position.model_probabilities, f.position.model_probabilities) and r.position.fen == f.position.fen, it
+
+
+def test_close_returns_the_device_memory_and_the_instance_reloads_lazily(tmp_path_factory):
+    """`ChessVision.close()` (round 6: an instance may now hold replica engines for its request slots and an exact-f32 twin) releases
+    engines, slots, staging buffers and streams at once; the instance is lazy again and the next call gives the same bits."""
+    d = tmp_path_factory.mktemp("weights_close")
+    pe, pc = synthetic.save_checkpoints(d, segmenting=True)
+    image = synthetic.board_photo(321)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    with ChessVision(board_extractor_weights=str(pe), classifier_weights=str(pc)) as cv:
+        first = cv.process_image(image)
+        assert cv.warm_request_slots(2) == 2
+        cv.process_images([image] * 4, fallback_quad=True)
+        held = free0 - torch.cuda.mem_get_info()[0]
+        assert held > 500 << 20, held                               # two engine pairs + their workspaces
+    assert cv._slots == [] and cv._engines == {} and cv._board_extractor is None
+    torch.cuda.synchronize()
+    leaked = free0 - torch.cuda.mem_get_info()[0]
+    assert leaked < 64 << 20, (leaked, held)                        # everything came back (torch's own caching aside)
+    again = cv.process_image(image)                                 # lazy reload
+    assert again.position is not None and again.position.fen == first.position.fen
+    assert np.array_equal(again.position.model_probabilities, first.position.model_probabilities)
+    assert np.array_equal(again.board_extraction.probabilities, first.board_extraction.probabilities)
+    cv.close(); cv.close()                                          # idempotent
