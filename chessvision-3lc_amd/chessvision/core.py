@@ -494,6 +494,15 @@ class ChessVision:
         if not images:
             return []
         _ = self.board_extractor, self.classifier
+        if (torch.cuda.current_stream(self.device) == torch.cuda.default_stream(self.device)
+                and os.environ.get("CHESSVISION_PIPE_OWN_STREAM", "1") != "0"):
+            # A caller that chose no stream gets the instance's own compute stream, not the NULL stream: kernels queued on the legacy
+            # stream from one thread while other threads load models / run request slots was one of the two ingredients of the device
+            # faults of the round-6 soak (profiles/r06_tuning.md section 8).  Everything the call returns has been waited for through
+            # events when it ends, so nothing is left to order against the caller's stream.
+            with torch.cuda.stream(self._pipeline_streams()[2]):
+                return self._process_images_native(images, threshold, flip, fallback_quad, pipeline_chunk, return_crops, timings,
+                                                   first_job, last_job)
         from concurrent.futures import ThreadPoolExecutor
 
         from .distributed import host_threads
@@ -543,7 +552,7 @@ class ChessVision:
             return torch.empty(shape, dtype=dtype, pin_memory=True)
 
         main = torch.cuda.current_stream(dev)
-        up, down = self._pipeline_streams()
+        up, down = self._pipeline_streams()[:2]
         pool = self._copy_pool
         if pool is None:
             pool = self._copy_pool = ThreadPoolExecutor(max_workers=min(16, n_host), thread_name_prefix="cv-stage")
@@ -723,9 +732,9 @@ class ChessVision:
         return results
 
     def _pipeline_streams(self):
-        """(host->device, device->host) side streams of ``process_images``, created once per instance."""
+        """(host->device, device->host, compute) streams of ``process_images``, created once per instance."""
         if self._streams is None:
-            self._streams = (torch.cuda.Stream(self.device), torch.cuda.Stream(self.device))
+            self._streams = (torch.cuda.Stream(self.device), torch.cuda.Stream(self.device), torch.cuda.Stream(self.device))
         return self._streams
 
     # ---- host-side post-processing (static, usable without models) ----------------------------------

@@ -76,6 +76,7 @@ SYMBOLS = [
     ("cv_device_count", _i, [ctypes.POINTER(_i)]),
     ("cv_engine_create", _i, [_i, _i, ctypes.POINTER(_vp)]),
     ("cv_engine_destroy", _i, [_vp]),
+    ("cv_trim_memory", _i, [ctypes.POINTER(ctypes.c_size_t)]),
     ("cv_load_unet", _i, [_vp, ctypes.POINTER(_Param), _i]),
     ("cv_load_resnet18", _i, [_vp, ctypes.POINTER(_Param), _i]),
     ("cv_engine_set_chunk", _i, [_vp, _i, _i]),
@@ -118,6 +119,14 @@ SYMBOLS = [
     ("cv_decode_positions", _i, [_fp, _i, _i, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int8),
                                  ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
 ]
+
+
+def trim_memory() -> int:
+    """Hand the blocks of closed engines, which the library keeps for the next load, back to the driver (``cv_trim_memory``);
+    returns the bytes freed.  The counterpart of ``torch.cuda.empty_cache()`` for this library's own allocations."""
+    n = ctypes.c_size_t(0)
+    _check(load_library().cv_trim_memory(ctypes.byref(n)))
+    return int(n.value)
 
 
 def load_library():

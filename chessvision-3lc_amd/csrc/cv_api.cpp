@@ -113,8 +113,19 @@ static int impl_cv_engine_create(int device, int precision, cv_engine_t** out) {
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return finish(hip_fail(e, "hipGetDeviceProperties"));
     if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
         return finish(fail(CV_ERR_STATE, std::string("libchessvision_hip is built for gfx950 (MI355X); device is ") + prop.gcnArchName));
-    if ((e = conv_igemm_prepare()) != hipSuccess) return finish(hip_fail(e, "conv_igemm_prepare"));
-    if ((e = conv_halo_prepare()) != hipSuccess) return finish(hip_fail(e, "conv_halo_prepare"));
+    {
+        // the dynamic-LDS limits of the conv kernels are raised ONCE per device and process, under a lock: repeating hipFuncSetAttribute
+        // at every engine creation while other threads launch those very kernels (request slots: replicas are loaded in the background
+        // of a serving instance) is not something the runtime promises to survive
+        static std::mutex prep_mu;
+        static bool prepared[64] = {};
+        std::lock_guard<std::mutex> lk(prep_mu);
+        if (device >= 64 || !prepared[device]) {
+            if ((e = conv_igemm_prepare()) != hipSuccess) return finish(hip_fail(e, "conv_igemm_prepare"));
+            if ((e = conv_halo_prepare()) != hipSuccess) return finish(hip_fail(e, "conv_halo_prepare"));
+            if (device < 64) prepared[device] = true;
+        }
+    }
     cv_engine* eng = new (std::nothrow) cv_engine();
     if (!eng) return finish(fail(CV_ERR_NOMEM, "out of host memory"));
     eng->impl.device = device;
@@ -149,9 +160,20 @@ static int impl_cv_engine_set_chunk(cv_engine_t* eng, int unet_images, int resne
     return CV_OK;
 }
 
+// Model loads are serialised process-wide.  A load packs, uploads and calibrates through the legacy stream (hundreds of synchronous
+// allocations, fills and copies, calibration forwards on stream 0); two of them side by side in one process -- a second instance created
+// while another loads, or beside the background replica of a request slot -- ended in a GPU memory access fault in 50-80 % of the
+// soak runs (tests/dev/slots_soak.py; forwards beside ONE load never did, in any number of runs).  Loads take seconds and happen once
+// per engine: one at a time costs nothing.
+static std::mutex& load_mutex() {
+    static std::mutex mu;
+    return mu;
+}
+
 static int impl_cv_load_unet(cv_engine_t* eng, const cv_param_t* params, int n_params) {
     Status s = check_engine(eng);
     if (!s.ok()) return finish(s);
+    std::lock_guard<std::mutex> load_lk(load_mutex());
     std::lock_guard<std::mutex> lk(eng->impl.mu);
     DeviceGuard g(eng->impl.device);
     ParamMap pm;
@@ -163,6 +185,7 @@ static int impl_cv_load_unet(cv_engine_t* eng, const cv_param_t* params, int n_p
 static int impl_cv_load_resnet18(cv_engine_t* eng, const cv_param_t* params, int n_params) {
     Status s = check_engine(eng);
     if (!s.ok()) return finish(s);
+    std::lock_guard<std::mutex> load_lk(load_mutex());
     std::lock_guard<std::mutex> lk(eng->impl.mu);
     DeviceGuard g(eng->impl.device);
     ParamMap pm;
@@ -612,10 +635,10 @@ static int impl_cv_process_image(cv_engine_t* ue, cv_engine_t* ce, const uint8_t
         if (U.pipe_host_bytes < h_need) {
             hipError_t e = hipStreamSynchronize(st);
             if (e != hipSuccess) return finish(hip_fail(e, "cv_process_image"));
-            if (U.pipe_host) (void)hipHostFree(U.pipe_host);
-            U.pipe_host = nullptr; U.pipe_host_bytes = 0;
-            e = hipHostMalloc(&U.pipe_host, h_need, hipHostMallocDefault);
-            if (e != hipSuccess) return finish(fail(CV_ERR_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e)));
+            if (U.pipe_host) block_release(U.pipe_host, U.pipe_host_cap, true);
+            U.pipe_host = nullptr; U.pipe_host_bytes = 0; U.pipe_host_cap = 0;
+            e = block_alloc(&U.pipe_host, h_need, &U.pipe_host_cap, true);
+            if (e != hipSuccess) { U.pipe_host = nullptr; return finish(fail(CV_ERR_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e))); }
             U.pipe_host_bytes = h_need;
         }
         if (U.pipe_dev.bytes < at) {
@@ -856,6 +879,13 @@ const char* cv_last_error(void) { return get_error(); }
 
 int cv_device_count(int* count) {
     return guarded("cv_device_count", [&]() -> int { return impl_cv_device_count(count); });
+}
+int cv_trim_memory(size_t* bytes_freed) {
+    return guarded("cv_trim_memory", [&]() -> int {
+        const size_t n = block_cache_trim();
+        if (bytes_freed) *bytes_freed = n;
+        return CV_OK;
+    });
 }
 
 int cv_engine_create(int device, int precision, cv_engine_t** out) {

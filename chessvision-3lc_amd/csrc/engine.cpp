@@ -32,32 +32,196 @@ std::shared_mutex& capture_mutex() {
     static std::shared_mutex mu;
     return mu;
 }
+std::mutex& legacy_mutex() {
+    static std::mutex mu;
+    return mu;
+}
+std::shared_mutex& graph_mutex() {
+    static std::shared_mutex mu;
+    return mu;
+}
+static std::mutex g_grave_mu;
+static std::vector<std::pair<hipGraphExec_t, hipGraph_t>> g_grave;
+void graph_bury(hipGraphExec_t exec, hipGraph_t graph) {
+    if (!exec && !graph) return;
+    { std::lock_guard<std::mutex> lk(g_grave_mu); g_grave.emplace_back(exec, graph); }
+    graph_drain();
+}
+void graph_drain() {
+    std::unique_lock<std::shared_mutex> quiet(graph_mutex(), std::try_to_lock);     // nobody is inside hipGraphLaunch
+    if (!quiet.owns_lock()) return;
+    std::vector<std::pair<hipGraphExec_t, hipGraph_t>> dead;
+    { std::lock_guard<std::mutex> lk(g_grave_mu); dead.swap(g_grave); }
+    for (auto& d : dead) {
+        if (d.first) (void)hipGraphExecDestroy(d.first);
+        if (d.second) (void)hipGraphDestroy(d.second);
+    }
+}
 hipError_t sync_memcpy(void* dst, const void* src, size_t n, hipMemcpyKind kind) {
     if (capture_flag()) return hipErrorStreamCaptureUnsupported;         // this thread is recording: its caller falls back to an eager run
     std::shared_lock<std::shared_mutex> lk(capture_mutex());
+    std::lock_guard<std::mutex> one(legacy_mutex());
     return hipMemcpy(dst, src, n, kind);
 }
 hipError_t sync_memset(void* dst, int value, size_t n) {
     if (capture_flag()) return hipErrorStreamCaptureUnsupported;
     std::shared_lock<std::shared_mutex> lk(capture_mutex());
-    return hipMemset(dst, value, n);
+    std::lock_guard<std::mutex> one(legacy_mutex());
+    const hipError_t e = hipMemset(dst, value, n);
+    return e != hipSuccess ? e : hipStreamSynchronize(nullptr);          // a fill of device memory may return before it has run
 }
 hipError_t device_synchronize() {
     if (capture_flag()) return hipErrorStreamCaptureUnsupported;
     std::shared_lock<std::shared_mutex> lk(capture_mutex());
+    std::lock_guard<std::mutex> one(legacy_mutex());
     return hipDeviceSynchronize();
+}
+hipError_t copy_to_host_sync(void* dst_pageable, const void* src_dev, size_t n, hipStream_t s) {
+    if (capture_flag()) return hipErrorStreamCaptureUnsupported;
+    std::shared_lock<std::shared_mutex> lk(capture_mutex());
+    std::lock_guard<std::mutex> one(legacy_mutex());
+    const hipError_t e = hipMemcpyAsync(dst_pageable, src_dev, n, hipMemcpyDeviceToHost, s);
+    return e != hipSuccess ? e : hipStreamSynchronize(s);
 }
 
 // ---- device memory -------------------------------------------------------------------------------
-DeviceBuffer::~DeviceBuffer() {
-    if (ptr) (void)hipFree(ptr);
+namespace {
+struct BlockCache {
+    std::mutex mu;
+    std::multimap<std::pair<int, size_t>, void*> idle[2];       // [host]: (device, block bytes) -> block
+    size_t held[2] = {0, 0};
+};
+BlockCache& block_cache() {
+    static BlockCache* c = new BlockCache();                    // never destroyed: engines may be released during process exit
+    return *c;
 }
+bool block_cache_on() {
+    static const bool on = env_int("CV_MEM_CACHE", 1) != 0;
+    return on;
+}
+size_t block_cache_limit() {
+    static const size_t lim = (size_t)env_int("CV_MEM_CACHE_MB", 16384) << 20;
+    return lim;
+}
+}  // namespace
+
+hipError_t block_alloc(void** ptr, size_t n, size_t* cap, bool host) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (block_cache_on()) {
+        BlockCache& c = block_cache();
+        std::lock_guard<std::mutex> lk(c.mu);
+        auto it = c.idle[host].lower_bound({dev, n});           // smallest idle block of this device that fits ...
+        if (it != c.idle[host].end() && it->first.first == dev && it->first.second <= n + n / 4 + 4096) {   // ... without wasting > 25 %
+            *ptr = it->second; *cap = it->first.second;
+            c.held[host] -= *cap;
+            c.idle[host].erase(it);
+            return hipSuccess;
+        }
+    }
+    *cap = n;
+    for (int attempt = 0;; ++attempt) {
+        hipError_t e;
+        {
+            std::lock_guard<std::mutex> one(legacy_mutex());
+            e = host ? hipHostMalloc(ptr, n, hipHostMallocDefault) : hipMalloc(ptr, n);
+        }
+        if (e == hipSuccess || attempt == 1) return e;
+        (void)hipGetLastError();
+        if (block_cache_trim() == 0) return e;                  // out of memory with idle blocks in the cache: hand them back, once
+    }
+}
+void block_release(void* ptr, size_t cap, bool host) {
+    if (!ptr) return;
+    if (block_cache_on()) {
+        // what hipFree did implicitly: nothing queued anywhere still uses the block when its next owner fills it on another stream
+        (void)device_synchronize();
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        BlockCache& c = block_cache();
+        std::lock_guard<std::mutex> lk(c.mu);
+        if (c.held[host] + cap <= block_cache_limit()) {
+            c.idle[host].insert({{dev, cap}, ptr});
+            c.held[host] += cap;
+            return;
+        }
+    }
+    std::lock_guard<std::mutex> one(legacy_mutex());
+    if (host) (void)hipHostFree(ptr); else (void)hipFree(ptr);
+}
+size_t block_cache_trim() {
+    BlockCache& c = block_cache();
+    std::multimap<std::pair<int, size_t>, void*> dead[2];
+    size_t bytes = 0;
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        for (int h = 0; h < 2; ++h) { dead[h].swap(c.idle[h]); bytes += c.held[h]; c.held[h] = 0; }
+    }
+    std::lock_guard<std::mutex> one(legacy_mutex());
+    (void)hipDeviceSynchronize();
+    for (int h = 0; h < 2; ++h)
+        for (auto& b : dead[h]) { if (h) (void)hipHostFree(b.second); else (void)hipFree(b.second); }
+    return bytes;
+}
+
+static int guard_alloc_mode() {
+    static const int mode = env_int("CV_GUARD_ALLOC", 0);
+    return mode;
+}
+void DeviceBuffer::release() {
+    if (!ptr) return;
+    if (!guard_base) { block_release(ptr, cap_bytes, false); ptr = nullptr; cap_bytes = 0; return; }
+    std::lock_guard<std::mutex> one(legacy_mutex());
+    if (guard_base) {
+        (void)hipDeviceSynchronize();
+        const size_t guard = (guard_span - guard_mapped) / 2;
+        (void)hipMemUnmap((char*)guard_base + guard, guard_mapped);
+        (void)hipMemRelease((hipMemGenericAllocationHandle_t)guard_handle);
+        (void)hipMemAddressFree(guard_base, guard_span);
+        guard_base = nullptr; guard_handle = nullptr; guard_span = guard_mapped = 0;
+        ptr = nullptr;
+        return;
+    }
+    ptr = nullptr;
+}
+DeviceBuffer::~DeviceBuffer() { release(); }
 Status DeviceBuffer::alloc(size_t n, bool zero) {
-    if (ptr) { (void)hipFree(ptr); ptr = nullptr; }
+    release();
     bytes = n;
     if (n == 0) return Status();
-    hipError_t e = hipMalloc(&ptr, n);
-    if (e != hipSuccess) { ptr = nullptr; return fail(4, std::string("hipMalloc(") + std::to_string(n) + "): " + hipGetErrorString(e)); }
+    hipError_t e;
+    if (const int mode = guard_alloc_mode()) {
+        std::lock_guard<std::mutex> one(legacy_mutex());
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        hipMemAllocationProp prop{};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = dev;
+        size_t gran = 0;
+        e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum);
+        if (e != hipSuccess || gran == 0) return fail(4, std::string("CV_GUARD_ALLOC: hipMemGetAllocationGranularity: ") + hipGetErrorString(e));
+        const size_t guard = ((size_t)env_int("CV_GUARD_MB", 64) << 20) / gran * gran;             // unmapped bytes on either side
+        const size_t mapped = (n + gran - 1) / gran * gran, span = mapped + 2 * guard;
+        void* base = nullptr;
+        hipMemGenericAllocationHandle_t h{};
+        e = hipMemAddressReserve(&base, span, gran, nullptr, 0);
+        if (e == hipSuccess) e = hipMemCreate(&h, mapped, &prop, 0);
+        if (e == hipSuccess) e = hipMemMap((char*)base + guard, mapped, 0, h, 0);
+        hipMemAccessDesc acc{};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        if (e == hipSuccess) e = hipMemSetAccess((char*)base + guard, mapped, &acc, 1);
+        if (e != hipSuccess) return fail(4, std::string("CV_GUARD_ALLOC: virtual-memory mapping of ") + std::to_string(n) + " bytes: " + hipGetErrorString(e));
+        const size_t align = (size_t)env_int("CV_GUARD_ALIGN", 256);
+        guard_base = base; guard_span = span; guard_mapped = mapped; guard_handle = (void*)h;
+        ptr = (char*)base + guard + (mode == 1 ? (mapped - n) / align * align : 0);
+        if (env_int("CV_GUARD_LOG", 0))
+            std::fprintf(stderr, "[guard] buffer %p .. %p (%zu bytes) in reserve %p .. %p\n", ptr, (void*)((char*)ptr + n), n, base, (void*)((char*)base + span));
+    } else {
+        e = block_alloc(&ptr, n, &cap_bytes, false);
+        if (e != hipSuccess) { ptr = nullptr; cap_bytes = 0; return fail(4, std::string("hipMalloc(") + std::to_string(n) + "): " + hipGetErrorString(e)); }
+    }
     if (zero) CV_HIP(sync_memset(ptr, 0, n));
     return Status();
 }
@@ -507,7 +671,7 @@ Engine::~Engine() {
     prof_clear();
     graph_clear();
     if (capture_stream) (void)hipStreamDestroy(capture_stream);
-    if (pipe_host) (void)hipHostFree(pipe_host);
+    if (pipe_host) block_release(pipe_host, pipe_host_cap, true);
     if (pipe_event) (void)hipEventDestroy(pipe_event);
     if (pipe_event2) (void)hipEventDestroy(pipe_event2);
     if (pipe_event3) (void)hipEventDestroy(pipe_event3);
@@ -516,10 +680,21 @@ Engine::~Engine() {
 
 void Engine::graph_clear() {
     for (auto& g : graphs) {
-        if (g.exec) (void)hipGraphExecDestroy(g.exec);
-        if (g.graph) (void)hipGraphDestroy(g.graph);
+        graph_bury(g.exec, g.graph);
     }
     graphs.clear();
+}
+
+Status Engine::order_forward(int model, hipStream_t s) {
+    const int m = model & 1;
+    if (last_stream_set[m] && last_stream[m] != s) {
+        if (capture_flag()) return fail(1, "stream change during graph capture");
+        const hipError_t e = hipStreamSynchronize(last_stream[m]);           // the previous forward of this model has left the workspace
+        if (e != hipSuccess) (void)hipGetLastError();                        // (a stream destroyed meanwhile has nothing in flight)
+    }
+    last_stream[m] = s;
+    last_stream_set[m] = true;
+    return Status();
 }
 
 unsigned Engine::register_layer(const std::string& name) {
@@ -561,8 +736,7 @@ Status Engine::guard_eval(unsigned v) {
 Status Engine::guard_check(hipStream_t s) {
     if (!guard.ptr) return Status();
     unsigned v = 0xffffffffu;
-    CV_HIP(hipMemcpyAsync(&v, guard.ptr, sizeof(v), hipMemcpyDeviceToHost, s));
-    CV_HIP(hipStreamSynchronize(s));
+    CV_HIP(copy_to_host_sync(&v, guard.ptr, sizeof(v), s));
     if (v == 0xffffffffu) return Status();
     CV_HIP(sync_memset(guard.ptr, 0xff, sizeof(unsigned)));
     const std::string who = v < layer_names.size() ? layer_names[v] : ("layer #" + std::to_string(v));
@@ -580,8 +754,7 @@ Status Engine::measure(const TensorRef& t, hipStream_t s) {
     CV_HIP(hipMemsetAsync(cal_word.ptr, 0, sizeof(unsigned), s));
     CV_HIP(absmax(t.f32_only ? (int)kF32 : dt, t, reinterpret_cast<unsigned*>(cal_word.ptr), s));
     unsigned bits = 0;
-    CV_HIP(hipMemcpyAsync(&bits, cal_word.ptr, sizeof(bits), hipMemcpyDeviceToHost, s));
-    CV_HIP(hipStreamSynchronize(s));
+    CV_HIP(copy_to_host_sync(&bits, cal_word.ptr, sizeof(bits), s));
     const bool second = a->split_c && t.Coff >= a->split_c;         // producers write one half of a concatenation each
     if (bits >= 0x7f800000u) { (second ? a->seen_bad2 : a->seen_bad) = true; return Status(); }
     float stored;
@@ -603,8 +776,7 @@ Status Engine::measure_tap_sums(ConvLayer& L, const TensorRef& x, int Ho, int Wo
     if (bias_ws.bytes < need) CV_TRY(bias_ws.alloc(std::max(need, (size_t)1 << 20), false));
     CV_HIP(tap_sums_f16(x, Ho, Wo, L.stride, L.k, slices, reinterpret_cast<double*>(bias_ws.ptr), s));
     std::vector<double> part((size_t)slices * taps * C);
-    CV_HIP(hipMemcpyAsync(part.data(), bias_ws.ptr, need, hipMemcpyDeviceToHost, s));
-    CV_HIP(hipStreamSynchronize(s));
+    CV_HIP(copy_to_host_sync(part.data(), bias_ws.ptr, need, s));
     if (L.tap_sum.empty()) { L.tap_sum.assign((size_t)L.Kerr, 0.0); L.tap_in_exp = x.exp; }
     if (L.tap_in_exp != x.exp) return fail(1, L.name + ": input exponent changed inside the rounding-bias pass");
     for (int kk = 0; kk < L.Kerr; ++kk) {

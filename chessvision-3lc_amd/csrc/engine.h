@@ -26,6 +26,18 @@ bool& capture_flag();                               // this thread is recording 
 // (Engine::run_graphed) takes it exclusively, by try_lock only -- a request thread never waits for somebody's model load, it runs
 // eagerly once more and captures next time.
 std::shared_mutex& capture_mutex();
+// ... and against EACH OTHER: synchronous copies to or from pageable memory, fills and allocations of two threads were seen to end in
+// GPU memory access faults when they overlapped (round 6 soak: a model load beside another engine's lazily created offset tables;
+// the runtime stages such copies through shared buffers).  They are short and rare on the request path: one at a time, process-wide.
+std::mutex& legacy_mutex();
+// ... and graph DESTRUCTION against graph LAUNCHES of other threads: closing an instance (hipGraphExecDestroy of its captured forwards)
+// while the request threads of another instance replayed theirs faulted in ~10 % of the soak runs -- and in none with CV_GRAPH=0 or with
+// the instances kept alive.  Launches hold graph_mutex() shared; a graph that is no longer needed is BURIED (graph_bury) and destroyed
+// by graph_drain() at a moment when no launch is in flight (exclusive try_lock: after a bury and after every capture), never waited for.
+std::shared_mutex& graph_mutex();
+void graph_bury(hipGraphExec_t exec, hipGraph_t graph);
+void graph_drain();
+hipError_t copy_to_host_sync(void* dst_pageable, const void* src_dev, size_t n, hipStream_t s);   // D2H into pageable memory + wait for `s`
 hipError_t sync_memcpy(void* dst, const void* src, size_t n, hipMemcpyKind kind);
 hipError_t sync_memset(void* dst, int value, size_t n);
 hipError_t device_synchronize();
@@ -59,16 +71,38 @@ struct ParamView {
 typedef std::map<std::string, ParamView> ParamMap;
 
 // one device allocation, zero-filled once (PHWC borders rely on it)
+// Device (and page-locked host) blocks released by a closing instance go to a process-wide, size-keyed cache instead of back to the
+// driver, and the next load takes them from there (block_alloc / block_release).  Why: with request threads replaying forwards, an
+// instance closed by ANOTHER thread (hipFree of its weights and workspaces while kernels of the live instances run) ended ~1 soak in
+// 5 with "Memory access fault by GPU" -- never with the instances kept alive (tests/dev/slots_soak.py, profiles/r06_tuning.md
+// section 8).  A serving process that reloads models therefore never unmaps device memory under running kernels; what the cache holds
+// is bounded (CV_MEM_CACHE_MB, default 16384; beyond it blocks are freed, behind a device synchronise) and cv_trim_memory() hands
+// everything back.  CV_MEM_CACHE=0: every release is a hipFree again.
+hipError_t block_alloc(void** ptr, size_t n, size_t* cap, bool host);
+void block_release(void* ptr, size_t cap, bool host);
+size_t block_cache_trim();                              // frees every cached block; returns the bytes handed back
+
 struct DeviceBuffer {
     void* ptr = nullptr;
     size_t bytes = 0;
+    size_t cap_bytes = 0;                               // size of the underlying block (>= bytes when it came out of the cache)
+    // CV_GUARD_ALLOC=1|2 (debugging): the buffer is placed at the END (1) or START (2) of its own virtual-memory mapping with an
+    // unmapped granule on either side, so that a kernel reading or writing past that side of a buffer faults at once instead of
+    // landing in whatever allocation happens to be its neighbour (tests/dev/guard_alloc.sh)
+    void* guard_base = nullptr;
+    size_t guard_span = 0, guard_mapped = 0;
+    void* guard_handle = nullptr;
+    void release();
     DeviceBuffer() = default;
     DeviceBuffer(const DeviceBuffer&) = delete;
     DeviceBuffer& operator=(const DeviceBuffer&) = delete;
     ~DeviceBuffer();
     Status alloc(size_t n, bool zero);
     Status upload(const void* host, size_t n);
-    void swap(DeviceBuffer& o) { std::swap(ptr, o.ptr); std::swap(bytes, o.bytes); }
+    void swap(DeviceBuffer& o) {
+        std::swap(ptr, o.ptr); std::swap(bytes, o.bytes); std::swap(cap_bytes, o.cap_bytes);
+        std::swap(guard_base, o.guard_base); std::swap(guard_span, o.guard_span); std::swap(guard_mapped, o.guard_mapped); std::swap(guard_handle, o.guard_handle);
+    }
 };
 
 // a PHWC activation buffer sized for `cap` images
@@ -221,9 +255,16 @@ class Engine {
     // forward (0 = UNet and the single-layer entry points, 1 = ResNet-18) under the engine mutex.
     DeviceBuffer splitk_ws[2];
     int ws_slot = 0;
+    // One workspace per model: two forwards of the SAME model must not overlap on the device.  The engine mutex orders their enqueue on
+    // the host only, so a forward that arrives on another stream than the model's previous one first waits (on the host) for that stream
+    // -- rare by construction (a request slot's private stream beside process_images on the caller's stream, round 6: without this
+    // the B = 8 forward of a batch overwrote the activations of a B = 1 forward still in flight on the slot's stream), free otherwise.
+    hipStream_t last_stream[2] = {nullptr, nullptr};
+    bool last_stream_set[2] = {false, false};
+    Status order_forward(int model, hipStream_t s);
     // staging of cv_process_image: one page-locked host block and one device block, carved up per call (grown on demand)
     void* pipe_host = nullptr;
-    size_t pipe_host_bytes = 0;
+    size_t pipe_host_bytes = 0, pipe_host_cap = 0;
     DeviceBuffer pipe_dev;
     std::mutex pipe_mu;                                 // one cv_process_image at a time per extractor engine (the staging is shared)
     hipEvent_t pipe_event = nullptr;
@@ -400,6 +441,7 @@ Status Engine::run_graphed(const GraphKey& key, hipStream_t s, Run&& run) {
         if (g.key == key) { hit = &g; break; }
     if (hit && hit->exec && hit->epoch == graph_epoch) {
         hit->last_use = graph_clock; ++hit->hits;
+        std::shared_lock<std::shared_mutex> launching(graph_mutex());
         CV_HIP(hipGraphLaunch(hit->exec, s));
         return Status();
     }
@@ -409,8 +451,7 @@ Status Engine::run_graphed(const GraphKey& key, hipStream_t s, Run&& run) {
             for (size_t i = 1; i < graphs.size(); ++i)
                 if (graphs[i].last_use < graphs[victim].last_use) victim = i;
             if (graphs[victim].exec && graphs[victim].hits == 0 && ++graph_wasted >= 4) graphs_on = false;   // pointers never repeat: stop capturing
-            if (graphs[victim].exec) (void)hipGraphExecDestroy(graphs[victim].exec);
-            if (graphs[victim].graph) (void)hipGraphDestroy(graphs[victim].graph);
+            graph_bury(graphs[victim].exec, graphs[victim].graph);
             graphs.erase(graphs.begin() + (long)victim);
         }
         GraphEntry ge;
@@ -419,8 +460,8 @@ Status Engine::run_graphed(const GraphKey& key, hipStream_t s, Run&& run) {
         return run(s);
     }
     // second sight (or a stale capture): record the sequence on the engine's own stream, instantiate, replay on the caller's
-    if (hit->exec) { (void)hipGraphExecDestroy(hit->exec); hit->exec = nullptr; }
-    if (hit->graph) { (void)hipGraphDestroy(hit->graph); hit->graph = nullptr; }
+    graph_bury(hit->exec, hit->graph);
+    hit->exec = nullptr; hit->graph = nullptr;
     if (!capture_stream && hipStreamCreateWithFlags(&capture_stream, hipStreamNonBlocking) != hipSuccess) { graphs_on = false; return run(s); }
     const uint64_t epoch0 = graph_epoch;
     std::unique_lock<std::shared_mutex> capture_lock(capture_mutex(), std::try_to_lock);
@@ -433,7 +474,7 @@ Status Engine::run_graphed(const GraphKey& key, hipStream_t s, Run&& run) {
     const hipError_t ce = hipStreamEndCapture(capture_stream, &graph);
     capture_lock.unlock();
     if (!st.ok() || ce != hipSuccess || !graph || graph_epoch != epoch0) {
-        if (graph) (void)hipGraphDestroy(graph);
+        graph_bury(nullptr, graph);
         (void)hipGetLastError();
         hit->last_use = graph_clock;
         if (st.ok() && graph_epoch == epoch0 && ce != hipSuccess) graphs_on = false;          // the runtime cannot capture this sequence at all
@@ -441,12 +482,14 @@ Status Engine::run_graphed(const GraphKey& key, hipStream_t s, Run&& run) {
     }
     hipGraphExec_t exec = nullptr;
     if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess || !exec) {
-        (void)hipGraphDestroy(graph);
+        graph_bury(nullptr, graph);
         (void)hipGetLastError();
         graphs_on = false;
         return run(s);
     }
     hit->graph = graph; hit->exec = exec; hit->epoch = graph_epoch; hit->last_use = graph_clock; hit->hits = 0;
+    graph_drain();
+    std::shared_lock<std::shared_mutex> launching(graph_mutex());
     CV_HIP(hipGraphLaunch(exec, s));
     return Status();
 }

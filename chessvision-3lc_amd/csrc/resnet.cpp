@@ -537,6 +537,7 @@ Status resnet_forward(Engine& e, const void* x, bool x_u8, int n, float* out, bo
     if (!e.resnet) return fail(3, "ResNet-18 weights not loaded (call cv_load_resnet18 first)");
     if (n < 0 || (n > 0 && (!x || !out))) return fail(1, "cv_resnet18_forward: null tensor or negative batch");
     if (n == 0) return Status();
+    CV_TRY(e.order_forward(1, s));
     CV_TRY(resnet_reserve(e, n));
     if (n <= e.resnet->cap && n <= 512) {                // one small chunk (a board's 64 squares): the launch sequence replays as a hipGraph
         Engine::GraphKey key;

@@ -523,6 +523,7 @@ Status unet_forward(Engine& e, const void* x, bool x_u8, int batch, float* logit
     if (!e.unet) return fail(3, "UNet weights not loaded (call cv_load_unet first)");
     if (batch < 0 || (batch > 0 && (!x || !logits))) return fail(1, "cv_unet_forward: null tensor or negative batch");
     if (batch == 0) return Status();
+    CV_TRY(e.order_forward(0, s));
     CV_TRY(unet_reserve(e, batch));
     if (batch <= e.unet->cap && batch <= 8) {            // one small chunk: the launch sequence replays as a hipGraph
         Engine::GraphKey key;

@@ -98,6 +98,14 @@ int         cv_device_count(int* count);
 int cv_engine_create(int device, int precision, cv_engine_t** out);
 int cv_engine_destroy(cv_engine_t* eng);
 
+/* Device and page-locked blocks of a destroyed engine (weights, workspaces, staging) stay in a process-wide cache and are handed to
+ * the next engine that asks for a block of that size, so a server that reloads models does not unmap device memory beside the
+ * running forwards of its other engines (round 6: that combination ended in device faults).  The cache holds at
+ * most CV_MEM_CACHE_MB (environment, default 16384) and CV_MEM_CACHE=0 switches it off.  cv_trim_memory waits for the device and
+ * returns every cached block to the driver; *bytes_freed (may be NULL) receives their total size.  The reference has no counterpart:
+ * torch's caching allocator plays this role there (torch.cuda.empty_cache()). */
+int cv_trim_memory(size_t* bytes_freed);
+
 /* Load + pack weights (host fp32 state dict -> device, BN folded to per-channel scale/shift applied in
  * the conv epilogue).  cv_load_unet auto-detects the transposed-conv vs bilinear variant from the
  * presence of "up1.up.weight" and validates every key/shape, failing with the offending key name.

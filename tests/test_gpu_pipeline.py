@@ -320,11 +320,15 @@ def test_repeated_process_image_calls_never_return_stale_staging(tmp_path):
 
 def test_close_returns_the_device_memory_and_the_instance_reloads_lazily(tmp_path_factory):
     """`ChessVision.close()` (round 6: an instance may now hold replica engines for its request slots and an exact-f32 twin) releases
-    engines, slots, staging buffers and streams at once; the instance is lazy again and the next call gives the same bits."""
+    engines, slots, staging buffers and streams at once; the instance is lazy again and the next call gives the same bits.  The
+    device blocks go to the library's process-wide cache (`cv_trim_memory`, include/chessvision_hip.h): a reload takes them from
+    there instead of from the driver, and `trim_memory()` hands them back."""
+    from chessvision import hip_backend
     d = tmp_path_factory.mktemp("weights_close")
     pe, pc = synthetic.save_checkpoints(d, segmenting=True)
     image = synthetic.board_photo(321)
     torch.cuda.synchronize()
+    hip_backend.trim_memory()                                       # blocks of instances closed by earlier tests
     free0 = torch.cuda.mem_get_info()[0]
     with ChessVision(board_extractor_weights=str(pe), classifier_weights=str(pc)) as cv:
         first = cv.process_image(image)
@@ -334,10 +338,21 @@ def test_close_returns_the_device_memory_and_the_instance_reloads_lazily(tmp_pat
         assert held > 500 << 20, held                               # two engine pairs + their workspaces
     assert cv._slots == [] and cv._engines == {} and cv._board_extractor is None
     torch.cuda.synchronize()
-    leaked = free0 - torch.cuda.mem_get_info()[0]
-    assert leaked < 64 << 20, (leaked, held)                        # everything came back (torch's own caching aside)
-    again = cv.process_image(image)                                 # lazy reload
+    again = cv.process_image(image)                                 # lazy reload ...
+    assert cv.warm_request_slots(2) == 2
+    cv.process_images([image] * 4, fallback_quad=True)
+    regrown = free0 - torch.cuda.mem_get_info()[0]
+    assert regrown < held + (64 << 20), (regrown, held)             # ... out of the cached blocks: nothing new from the driver
     assert again.position is not None and again.position.fen == first.position.fen
     assert np.array_equal(again.position.model_probabilities, first.position.model_probabilities)
     assert np.array_equal(again.board_extraction.probabilities, first.board_extraction.probabilities)
+    cv.close()
+    freed = hip_backend.trim_memory()
+    assert freed > 500 << 20, freed
+    assert hip_backend.trim_memory() == 0
+    torch.cuda.synchronize()
+    leaked = free0 - torch.cuda.mem_get_info()[0]
+    assert leaked < 64 << 20, (leaked, held)                        # everything came back (torch's own caching aside)
+    again = cv.process_image(image)                                 # and the instance still reloads after a trim
+    assert again.position is not None and again.position.fen == first.position.fen
     cv.close(); cv.close()                                          # idempotent
