@@ -25,10 +25,15 @@
  *     `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are asynchronous
  *     with respect to the host and ordered on `stream`.
  *   - the caller owns inputs and outputs; the engine owns its packed weights and its workspace and
- *     frees them in cv_engine_destroy.  The library never frees caller memory.
- *   - an engine serialises concurrent forward calls with an internal mutex (one workspace per engine and model).  The mutex orders
- *     the HOST side only: forwards of the SAME model must be enqueued on one stream (or on streams ordered by events); a UNet
- *     forward and a ResNet-18 forward of one engine may run on two streams at once (separate workspaces and scratch).
+ *     releases them in cv_engine_destroy.  The library never frees caller memory.
+ *   - an engine serialises concurrent forward calls with an internal mutex (one workspace per engine and model).  Forwards of the
+ *     SAME model may be enqueued on different streams: when the stream of a model's forward differs from that of its previous
+ *     forward, the call first waits (on the host) for the previous stream, so the two never overlap on the shared workspace
+ *     (rounds 1-5 left this to the caller; a soak in round 6 showed the library's own host layer getting it wrong).  Keep one
+ *     stream per engine and the wait never happens.  A UNet forward and a ResNet-18 forward of one engine may run on two streams
+ *     at once (separate workspaces and scratch).
+ *   - engines of one process may be created, loaded, used and destroyed from different threads at the same time: loads are
+ *     serialized process-wide, and memory released by cv_engine_destroy is cached for the next engine (cv_trim_memory).
  *   - plain C types only: no torch / C++ types cross this boundary.
  */
 #ifndef CHESSVISION_HIP_H

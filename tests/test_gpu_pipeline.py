@@ -356,3 +356,20 @@ def test_close_returns_the_device_memory_and_the_instance_reloads_lazily(tmp_pat
     again = cv.process_image(image)                                 # and the instance still reloads after a trim
     assert again.position is not None and again.position.fen == first.position.fen
     cv.close(); cv.close()                                          # idempotent
+
+
+def test_request_threads_beside_batches_and_instances_that_come_and_go():
+    """The round-6 soak in small (tests/dev/slots_soak.py, in a process of its own: what it guards against is a device fault, which
+    ends the process): four request threads on the slots of one instance, one thread running `process_images` batches on the same
+    instance and one creating, using and closing OTHER instances.  Every single-image result equals the serial one bit for bit.  What
+    it found (profiles/r06_tuning.md section 8): forwards of one engine on two streams overlapped (6567 of 12000 results wrong),
+    and instances closed beside running forwards ended in "Memory access fault by GPU" in roughly a third of the runs."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    out = subprocess.run([sys.executable, str(root / "tests" / "dev" / "slots_soak.py"), "4", "250"], capture_output=True, text=True, timeout=600)
+    tail = "\n".join((out.stdout + out.stderr).strip().splitlines()[-6:])
+    assert out.returncode == 0, tail
+    assert "1000 results" in out.stdout and " 0 differing from the serial result, 0 errors" in out.stdout, tail
+    assert "instances created, used twice and closed meanwhile: 0" not in out.stdout, tail
