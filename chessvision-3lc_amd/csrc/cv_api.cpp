@@ -140,12 +140,13 @@ static int impl_cv_engine_create(int device, int precision, cv_engine_t** out) {
 static int impl_cv_engine_destroy(cv_engine_t* eng) {
     if (!eng) return CV_OK;
     {
-        DeviceGuard g(eng->impl.device);
+        DeviceGuard g(eng->impl.device);                // every block of the engine goes back to the cache under ITS device
         (void)device_synchronize();
+        ReleaseAlreadySynced quiescent;                 // nothing can be queued on a dying engine's buffers from here on
         eng->impl.unet.reset();
         eng->impl.resnet.reset();
+        delete eng;
     }
-    delete eng;
     return CV_OK;
 }
 

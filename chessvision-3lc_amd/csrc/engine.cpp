@@ -105,6 +105,13 @@ size_t block_cache_limit() {
 }
 }  // namespace
 
+static int& release_synced_depth() {
+    static thread_local int depth = 0;
+    return depth;
+}
+ReleaseAlreadySynced::ReleaseAlreadySynced() { ++release_synced_depth(); }
+ReleaseAlreadySynced::~ReleaseAlreadySynced() { --release_synced_depth(); }
+
 hipError_t block_alloc(void** ptr, size_t n, size_t* cap, bool host) {
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -135,7 +142,7 @@ void block_release(void* ptr, size_t cap, bool host) {
     if (!ptr) return;
     if (block_cache_on()) {
         // what hipFree did implicitly: nothing queued anywhere still uses the block when its next owner fills it on another stream
-        (void)device_synchronize();
+        if (release_synced_depth() == 0) (void)device_synchronize();
         int dev = 0;
         (void)hipGetDevice(&dev);
         BlockCache& c = block_cache();
@@ -164,6 +171,10 @@ size_t block_cache_trim() {
     return bytes;
 }
 
+static bool poison_alloc() {
+    static const bool on = env_int("CV_POISON_ALLOC", 0) != 0;
+    return on;
+}
 static int guard_alloc_mode() {
     static const int mode = env_int("CV_GUARD_ALLOC", 0);
     return mode;
@@ -223,6 +234,7 @@ Status DeviceBuffer::alloc(size_t n, bool zero) {
         if (e != hipSuccess) { ptr = nullptr; cap_bytes = 0; return fail(4, std::string("hipMalloc(") + std::to_string(n) + "): " + hipGetErrorString(e)); }
     }
     if (zero) CV_HIP(sync_memset(ptr, 0, n));
+    else if (poison_alloc()) CV_HIP(sync_memset(ptr, 0xff, n));     // CV_POISON_ALLOC=1 (debugging): whoever relies on fresh memory being zero reads NaNs
     return Status();
 }
 Status DeviceBuffer::upload(const void* host, size_t n) {

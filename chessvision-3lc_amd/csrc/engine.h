@@ -81,6 +81,14 @@ typedef std::map<std::string, ParamView> ParamMap;
 hipError_t block_alloc(void** ptr, size_t n, size_t* cap, bool host);
 void block_release(void* ptr, size_t cap, bool host);
 size_t block_cache_trim();                              // frees every cached block; returns the bytes handed back
+// block_release waits for the device before a block becomes somebody else's (what hipFree did implicitly).  A caller that has just
+// synchronised and releases many blocks of a quiescent owner (cv_engine_destroy: ~100 buffers) holds one of these meanwhile.
+struct ReleaseAlreadySynced {
+    ReleaseAlreadySynced();
+    ~ReleaseAlreadySynced();
+    ReleaseAlreadySynced(const ReleaseAlreadySynced&) = delete;
+    ReleaseAlreadySynced& operator=(const ReleaseAlreadySynced&) = delete;
+};
 
 struct DeviceBuffer {
     void* ptr = nullptr;
@@ -88,7 +96,8 @@ struct DeviceBuffer {
     size_t cap_bytes = 0;                               // size of the underlying block (>= bytes when it came out of the cache)
     // CV_GUARD_ALLOC=1|2 (debugging): the buffer is placed at the END (1) or START (2) of its own virtual-memory mapping with an
     // unmapped granule on either side, so that a kernel reading or writing past that side of a buffer faults at once instead of
-    // landing in whatever allocation happens to be its neighbour (tests/dev/guard_alloc.sh)
+    // landing in whatever allocation happens to be its neighbour (tests/dev/guard_alloc.sh).  For FAULTS only: copies and fills into
+    // hipMemMap'ed ranges do not behave on this stack, so results computed under this mode mean nothing (r06_tuning.md section 8).
     void* guard_base = nullptr;
     size_t guard_span = 0, guard_mapped = 0;
     void* guard_handle = nullptr;
