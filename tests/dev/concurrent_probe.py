@@ -34,6 +34,23 @@ def run(cv, images, threads, calls):
 
 def main():
     mode = sys.argv[1] if len(sys.argv) > 1 else "sweep"
+    if "rccl" in sys.argv[2:]:                          # what else bench.py's process holds: a one-rank RCCL communicator ...
+        import os
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1"); os.environ.setdefault("LOCAL_RANK", "0")
+        from chessvision import distributed as cvd
+        _, _, device = cvd.init_process_group()
+        print("rccl ranks", cvd.count_ranks(device), flush=True)
+    extra = []
+    if "engines" in sys.argv[2:]:                       # ... and more engines (each with its capture / side streams)
+        import torch
+        from chessvision.hip_backend import HipEngine
+        for prec in ("f32", "f16", "f16r", "f16x3", "f16x3"):
+            e = HipEngine(torch.device("cuda", 0), precision=prec)
+            e.load_unet(synthetic.unet_state_dict(1, False)); e.load_resnet18(synthetic.resnet18_state_dict(2))
+            extra.append(e)
+        extra.append([torch.cuda.Stream() for _ in range(24)])
+        print("extra engines", len(extra) - 1, flush=True)
     with tempfile.TemporaryDirectory() as d:
         pe, pc = synthetic.save_checkpoints(d, segmenting=True)
         cv = ChessVision(board_extractor_weights=str(pe), classifier_weights=str(pc))
@@ -47,7 +64,7 @@ def main():
             run(cv, images, threads, 20)
             print(f"threads {threads}: {run(cv, images, threads, calls):.0f} requests/s", flush=True)
             return
-        calls = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+        calls = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 200
         print(f"slots {cv.warm_request_slots()}")
         for threads in (1, 2, 3, 4, 8):
             run(cv, images, threads, 20)
