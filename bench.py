@@ -519,10 +519,8 @@ def process_image_latency(cv, iters=100):
     a = np.array(times)
     # the same entry point from four request threads of ONE instance (the reference's Flask app: a global instance, threaded server,
     # cv_endpoint.py:131-133): every thread gets a request slot of its own (engines, staging block, stream), results are the serial ones.
-    # This process holds half a dozen engines, an RCCL communicator and several dozen HIP streams by now, and the figure is lower here
-    # than in a process that holds one instance (r06: 1483-2116 requests/s over six boxes against 2312-2334 for
-    # tests/dev/concurrent_probe.py on the same boxes, at the SAME serial rate: what is lost is overlap on the device; a child process
-    # started from here, beside this one, measured 1773 -- it is the device's queues that are crowded, not this interpreter).
+    # (Until late in round 6 this read 1480-2120 requests/s against 2310-2375 in tests/dev/concurrent_probe.py: the four slots were
+    # first used all at once here, and the HIP runtime binds streams to hardware queues at first use -- ChessVision._warm_slot.)
     conc = {}
     try:
         inside = concurrent_requests(cv, images)

@@ -46,6 +46,9 @@ _RESNET_IDS = ("", "resnet18", "hip")
 _PRECISION_NAMES = ("f16x3", "split", "f32", "fp32", "float32", "f16", "fp16", "float16", "f16r")
 
 
+_FIRST_USE_LOCK = threading.Lock()          # first use of a slot's streams, one slot of the process at a time (ChessVision._warm_slot)
+
+
 class _RequestSlot:
     """What ONE in-flight ``process_image`` needs for itself: an engine per model (activation workspace, page-locked staging block,
     captured hipGraphs -- none of which two forwards can share) and a HIP stream of its own.  Slot 0 wraps the instance's primary
@@ -287,9 +290,16 @@ class ChessVision:
         existing slots keep serving) until ``CHESSVISION_REQUEST_SLOTS`` (default 4) exist -- so a single-threaded caller never pays for
         replicas, and a threaded server reaches its full width after its first busy seconds."""
         extractor, classifier = self.board_extractor, self.classifier      # lazy initialisation outside the slot lock
+        first = None
         with self._slot_cond:
             if not self._slots:
-                self._slots.append(_RequestSlot(extractor.engine, classifier.engine, torch.cuda.Stream(self.device)))
+                first = _RequestSlot(extractor.engine, classifier.engine, torch.cuda.Stream(self.device))
+                first.busy = True
+                self._slots.append(first)
+        if first is not None:
+            self._warm_slot(first)
+            return first
+        with self._slot_cond:
             while True:
                 for slot in self._slots:
                     if not slot.busy:
@@ -319,6 +329,7 @@ class ChessVision:
             state, _ = utils.read_checkpoint(self._classifier_weights or constants.BEST_CLASSIFIER_WEIGHTS)
             cls_eng.load_resnet18(state)
             slot = _RequestSlot(unet_eng, cls_eng, torch.cuda.Stream(self.device))
+            self._warm_slot(slot)
         except Exception as exc:                                            # no replica: the instance keeps serving with what it has
             logger.warning(f"request slot {len(self._slots)} could not be created ({exc}); staying at {len(self._slots)} slot(s)")
             with self._slot_cond:
@@ -330,6 +341,21 @@ class ChessVision:
             self._slots.append(slot)
             self._slot_building = False
             self._slot_cond.notify_all()
+
+    def _warm_slot(self, slot: _RequestSlot) -> None:
+        """Two requests on a blank photo through a slot nobody else can see yet, one slot of the PROCESS at a time.  The HIP runtime binds
+        a stream to a hardware queue when the stream is first used, and streams first used at the same moment end up sharing queues:
+        four slots whose first requests arrived together served 1850-1880 requests/s for the rest of the process's life, the same slots
+        first used one after the other 2340-2370 (profiles/r06_tuning.md section 5).  The two calls also grow the slot's workspace and
+        record its hipGraphs, so the first real request on a new slot is as fast as any other."""
+        from .hip_backend import process_image_native
+        blank = np.zeros((512, 512, 3), dtype=np.uint8)
+        with _FIRST_USE_LOCK:
+            try:
+                for _ in range(2):
+                    process_image_native(slot.extractor_engine, slot.classifier_engine, blank, 0.5, False, True, stream=slot.stream.cuda_stream)
+            except Exception as exc:                                        # a warm-up only: the slot serves without it
+                logger.warning(f"request slot warm-up failed ({exc})")
 
     def warm_request_slots(self, n: int | None = None) -> int:
         """Create request slots now instead of under load (a server's start-up hook); returns how many exist afterwards."""

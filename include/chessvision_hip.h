@@ -32,6 +32,11 @@
  *     (rounds 1-5 left this to the caller; a soak in round 6 showed the library's own host layer getting it wrong).  Keep one
  *     stream per engine and the wait never happens.  A UNet forward and a ResNet-18 forward of one engine may run on two streams
  *     at once (separate workspaces and scratch).
+ *   - a server that runs several engines side by side (one per request thread, each on its own stream) should send ONE warm-up
+ *     request through each of them, one after the other, before the threads start: the HIP runtime binds a stream to a hardware
+ *     queue at the stream's first use, and streams first used at the same moment end up sharing queues (measured on MI355X, round 6:
+ *     four engine pairs 1850-1880 requests/s when first used together, 2340-2370 when first used in turn).  The Python host layer
+ *     does this for its request slots (ChessVision._warm_slot).
  *   - engines of one process may be created, loaded, used and destroyed from different threads at the same time: loads are
  *     serialized process-wide, and memory released by cv_engine_destroy is cached for the next engine (cv_trim_memory).
  *   - plain C types only: no torch / C++ types cross this boundary.
