@@ -201,6 +201,10 @@ static int gpu_mode(const char* blob_path, const char* squares_path) {
     printf("unet_not_loaded rc=%d msg=%s\n", rc, cv_last_error());
     (void)hipFree(d_sq); (void)hipFree(d_probs);
     CHECK(cv_engine_destroy(eng));
+    size_t trimmed = 0, again = 1;                                            /* the destroyed engine's blocks were cached for the next one */
+    CHECK(cv_trim_memory(&trimmed));
+    CHECK(cv_trim_memory(&again));
+    printf("trimmed %zu then %zu\n", trimmed, again);
     return 0;
 }
 #endif

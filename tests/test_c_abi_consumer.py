@@ -77,6 +77,8 @@ def test_classifier_from_plain_c_matches_python_binding_and_oracle(tmp_path):
     got = np.array(rows, dtype=np.float64).astype(np.float32)
     assert got.shape == (96, 13)
     assert any(ln.startswith("unet_not_loaded rc=3") for ln in out.stdout.splitlines())
+    trimmed = [ln.split() for ln in out.stdout.splitlines() if ln.startswith("trimmed ")][0]
+    assert int(trimmed[1]) > 20 << 20 and int(trimmed[3]) == 0            # cv_trim_memory from C: the classifier's blocks, then nothing left
 
     eng = HipEngine(precision="f16x3")
     eng.load_resnet18(sd)
