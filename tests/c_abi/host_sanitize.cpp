@@ -3,9 +3,11 @@
 // built with AddressSanitizer + UndefinedBehaviorSanitizer (tests/test_host_sanitizers.py compiles the three units from csrc/ together with
 // this file; GPU sanitizers are not available on the pool, the host code is what CAN be checked this way).  The inputs aim at the edges:
 // 1 x 1 and single-row masks, odd sizes, shapes touching the frame, holes inside holes, one-pixel lines, noise at every density, capacities
-// one short of what a call needs, collinear and repeated quadrangle corners, ties and NaNs in the probability tables.  Results are only
-// sanity-checked here (value parity has its own tests: test_contour_cpp.py, test_contour_parity.py, test_classical.py); what this binary
-// proves is that none of it reads or writes out of bounds, overflows a signed integer or shifts out of range.
+// one short of what a call needs, collinear and repeated quadrangle corners, ties and NaNs in the probability tables.  What this binary
+// proves is that none of it reads or writes out of bounds, overflows a signed integer or shifts out of range -- and, built with
+// -DWITH_ORACLE, that on every generated mask the contours (both approximation methods) and the quadrangle equal those of the
+// independent plain-C oracle (compiled in with the same sanitizers).  Homographies and positions are sanity-checked only (their value
+// parity: test_classical.py, test_classical_ref.py, test_core_api.py).
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -19,6 +21,15 @@ bool find_quadrangle(const uint8_t* mask, int h, int w, int32_t quad[8]);
 long find_contours_flat(const uint8_t* mask, int h, int w, bool tc89, int32_t* xy, long cap_pts, int32_t* counts, int32_t* holes, long cap_contours);
 void board_homographies(const float* quads, int n, int out_w, int out_h, double* forward, double* inverse);
 }  // namespace cv
+
+#ifdef WITH_ORACLE
+// the independent plain-C restatement of the same OpenCV chain (oracle/c_ref/contours_ref.c, raster-scan relabelling instead of border
+// following from start pixels), compiled into this binary with the same sanitizers: every generated mask is also a differential test
+extern "C" {
+int ref_find_contours(const uint8_t* mask, int h, int w, int method, int* xy, int cap_pts, int* counts, int* holes, int cap_contours);
+int ref_find_quadrangle(const uint8_t* mask, int h, int w, int* quad);
+}
+#endif
 
 namespace {
 
@@ -84,12 +95,24 @@ std::vector<uint8_t> make_mask(int kind, int h, int w, Rng& r) {
     return m;
 }
 
-long g_masks = 0, g_quads = 0, g_contours = 0, g_short = 0;
+long g_masks = 0, g_quads = 0, g_contours = 0, g_short = 0, g_diff = 0;
 
 int check_mask(const std::vector<uint8_t>& m, int h, int w) {
     ++g_masks;
     int32_t quad[8] = {0};
-    if (cv::find_quadrangle(m.data(), h, w, quad)) {
+    const bool found = cv::find_quadrangle(m.data(), h, w, quad);
+#ifdef WITH_ORACLE
+    {
+        int rq[8] = {0};
+        const int rf = ref_find_quadrangle(m.data(), h, w, rq);
+        if (rf < 0 || (rf == 1) != found || (found && std::memcmp(rq, quad, sizeof(rq)) != 0)) {
+            std::fprintf(stderr, "quadrangle differs from the oracle's on a %d x %d mask (found %d vs %d)\n", h, w, (int)found, rf);
+            return 1;
+        }
+        ++g_diff;
+    }
+#endif
+    if (found) {
         ++g_quads;
         for (int i = 0; i < 4; ++i)
             if (quad[2 * i] < 0 || quad[2 * i] >= w || quad[2 * i + 1] < 0 || quad[2 * i + 1] >= h) { std::fprintf(stderr, "quadrangle vertex outside a %d x %d mask\n", h, w); return 1; }
@@ -106,6 +129,17 @@ int check_mask(const std::vector<uint8_t>& m, int h, int w) {
             if (counts[q] <= 0 || (holes[q] != 0 && holes[q] != 1)) { std::fprintf(stderr, "bad contour record\n"); return 1; }
             pts += counts[q];
         }
+#ifdef WITH_ORACLE
+        {
+            std::vector<int> rxy((size_t)2 * cap_pts), rc((size_t)cap_cnt), rh((size_t)cap_cnt);
+            const int rn = ref_find_contours(m.data(), h, w, tc89, rxy.data(), (int)cap_pts, rc.data(), rh.data(), (int)cap_cnt);
+            bool same = rn == n;
+            for (long q = 0; same && q < n; ++q) same = rc[q] == counts[q] && rh[q] == holes[q];
+            same = same && std::memcmp(rxy.data(), xy.data(), (size_t)2 * pts * sizeof(int)) == 0;
+            if (!same) { std::fprintf(stderr, "contours (method %d) differ from the oracle's on a %d x %d mask: %ld vs %d\n", tc89, h, w, n, rn); return 1; }
+            ++g_diff;
+        }
+#endif
         for (long i = 0; i < pts; ++i)
             if (xy[2 * i] < 0 || xy[2 * i] >= w || xy[2 * i + 1] < 0 || xy[2 * i + 1] >= h) { std::fprintf(stderr, "contour point outside the mask\n"); return 1; }
         if (n > 0) {
@@ -211,6 +245,7 @@ int run_positions() {
 int main() {
     if (run_masks()) return 1;
     std::printf("masks: %ld masks, %ld quadrangles, %ld contours, %ld under-capacity calls refused\n", g_masks, g_quads, g_contours, g_short);
+    std::printf("oracle: %ld results compared with oracle/c_ref/contours_ref.c, all equal\n", g_diff);
     if (run_homographies()) return 1;
     if (run_positions()) return 1;
     std::printf("host sanitizers: ok\n");
