@@ -96,8 +96,9 @@ struct DeviceBuffer {
     size_t cap_bytes = 0;                               // size of the underlying block (>= bytes when it came out of the cache)
     // CV_GUARD_ALLOC=1|2 (debugging): the buffer is placed at the END (1) or START (2) of its own virtual-memory mapping with an
     // unmapped granule on either side, so that a kernel reading or writing past that side of a buffer faults at once instead of
-    // landing in whatever allocation happens to be its neighbour (tests/dev/guard_alloc.sh).  For FAULTS only: copies and fills into
-    // hipMemMap'ed ranges do not behave on this stack, so results computed under this mode mean nothing (r06_tuning.md section 8).
+    // landing in whatever allocation happens to be its neighbour (tests/dev/guard_alloc.sh).  For FAULTS only by default: when a freed
+    // range's addresses are reserved again, kernels still see the previous mapping on this stack, so numbers computed under this mode
+    // are only right with CV_GUARD_KEEP_VA=1, which small cases can afford (engine.cpp: DeviceBuffer::release; r06_tuning.md section 8).
     void* guard_base = nullptr;
     size_t guard_span = 0, guard_mapped = 0;
     void* guard_handle = nullptr;
