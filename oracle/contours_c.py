@@ -8,12 +8,14 @@ Algorithm 1 publishes it and shares no code with the product's ``csrc/contour.cp
 from __future__ import annotations
 
 import ctypes
+import os
 import subprocess
 from pathlib import Path
 
 import numpy as np
 
-_DIR = Path(__file__).resolve().parent / "c_ref"
+# CV_ORACLE_CREF_DIR: load the libraries from another directory (tests/test_oracle_sanitizers.py: builds with AddressSanitizer + UBSan)
+_DIR = Path(os.environ.get("CV_ORACLE_CREF_DIR") or Path(__file__).resolve().parent / "c_ref")
 _lib = None
 
 NONE, TC89_KCOS = 0, 1
@@ -23,7 +25,8 @@ def library():
     global _lib
     if _lib is None:
         so = _DIR / "libcontours_ref.so"
-        if not so.exists() or so.stat().st_mtime < (_DIR / "contours_ref.c").stat().st_mtime:
+        src = _DIR / "contours_ref.c"                              # (absent in a directory of prebuilt sanitizer libraries)
+        if src.exists() and (not so.exists() or so.stat().st_mtime < src.stat().st_mtime):
             subprocess.run(["make", "libcontours_ref.so"], cwd=_DIR, check=True, stdout=subprocess.DEVNULL)
         lib = ctypes.CDLL(str(so))
         lib.ref_arc_length_closed.restype = ctypes.c_double

@@ -6,12 +6,14 @@ order) that per-op cross-checks cannot see.  Driven from a flat state dict (refe
 from __future__ import annotations
 
 import ctypes
+import os
 import subprocess
 from pathlib import Path
 
 import numpy as np
 
-_DIR = Path(__file__).resolve().parent / "c_ref"
+# CV_ORACLE_CREF_DIR: load the libraries from another directory (tests/test_oracle_sanitizers.py: builds with AddressSanitizer + UBSan)
+_DIR = Path(os.environ.get("CV_ORACLE_CREF_DIR") or Path(__file__).resolve().parent / "c_ref")
 _lib = None
 
 
@@ -24,7 +26,8 @@ def library():
     global _lib
     if _lib is None:
         so = _DIR / "libnets_ref.so"
-        if not so.exists() or so.stat().st_mtime < (_DIR / "nets_ref.c").stat().st_mtime:
+        src = _DIR / "nets_ref.c"                              # (absent in a directory of prebuilt sanitizer libraries)
+        if src.exists() and (not so.exists() or so.stat().st_mtime < src.stat().st_mtime):
             subprocess.run(["make", "libnets_ref.so"], cwd=_DIR, check=True, stdout=subprocess.DEVNULL)
         _lib = ctypes.CDLL(str(so))
     return _lib
