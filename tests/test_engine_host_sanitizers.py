@@ -1,0 +1,66 @@
+"""AddressSanitizer + UndefinedBehaviorSanitizer over the HOST side of the whole library: csrc/ compiled with `--cuda-host-only` (every
+.hip and .cpp unit: launch wrappers, planners, packers, the C ABI) and linked against a stand-in HIP runtime whose "device" memory is
+host memory and whose launches are checked no-ops (tests/c_abi/hip_host_stub.cpp), then driven through the C ABI by
+tests/c_abi/engine_host_driver.py: whole-model loads in four precisions and both UNet variants, forwards around the chunk sizes, the
+single-layer entry points, `cv_process_image_v2`, profiling and calibration tables, error paths.  Kernels do not run here -- their parity
+is the GPU suite's business; this is the part of the product a GPU test cannot see into: whether the code AROUND the kernels stays inside
+its buffers.  GPU sanitizers are not available on the pool."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+CSRC = ROOT / "chessvision-3lc_amd" / "csrc"
+CLANG = Path("/opt/rocm/lib/llvm/bin/clang++")
+UNITS = ["conv_igemm.hip", "conv_halo.hip", "pointwise.hip", "pipeline.hip", "engine.cpp", "unet.cpp", "resnet.cpp", "contour.cpp",
+         "position.cpp", "homography.cpp", "cv_api.cpp"]            # the Makefile's SRCS
+SAN = ["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer"]
+
+
+def _run(cmd, **kw):
+    out = subprocess.run([str(c) for c in cmd], capture_output=True, text=True, timeout=1500, **kw)
+    assert out.returncode == 0, (" ".join(str(c) for c in cmd[:6]), out.stderr[-3000:])
+    return out
+
+
+def test_host_side_of_the_engine_is_clean_under_asan_and_ubsan(tmp_path):
+    runtimes = sorted(Path("/opt/rocm/lib/llvm/lib/clang").glob("*/lib/linux/libclang_rt.asan-x86_64.so"))
+    if not CLANG.exists() or not runtimes:
+        pytest.skip("ROCm clang or its shared AddressSanitizer runtime is not installed")
+    makefile = (CSRC / "Makefile").read_text()
+    assert all(u in makefile for u in UNITS) and makefile.count(".hip ") + makefile.count(".cpp ") + 1 >= len(UNITS)
+    host = ["-std=c++17", "-O1", "-g", "-x", "hip", "--cuda-host-only", "--offload-arch=gfx950", "--rocm-path=/opt/rocm", *SAN, "-fPIC",
+            "-I/opt/rocm/include", f"-I{ROOT / 'include'}", f"-I{CSRC}"]
+    with ThreadPoolExecutor(max_workers=6) as pool:                    # the shipped sources, host code only
+        list(pool.map(lambda u: _run([CLANG, *host, "-c", CSRC / u, "-o", tmp_path / f"{u}.o"]), UNITS))
+    _run([CLANG, "-std=c++17", "-O1", "-g", *SAN, "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-c",
+          ROOT / "tests" / "c_abi" / "hip_host_stub.cpp", "-o", tmp_path / "stub.o"])
+    # a host-only object still refers to the device code object of its unit by a per-unit symbol: give each an empty one
+    objs = [tmp_path / f"{u}.o" for u in UNITS]
+    syms = sorted({ln.split()[-1] for o in objs for ln in _run(["nm", "-u", o]).stdout.splitlines() if "__hip_fatbin" in ln})
+    (tmp_path / "fatbins.c").write_text("".join(f"const char {s}[16] = {{0}};\n" for s in syms))
+    _run([CLANG.with_name("clang"), "-fPIC", "-c", tmp_path / "fatbins.c", "-o", tmp_path / "fatbins.o"])
+    lib = tmp_path / "libchessvision_hip_hostsan.so"
+    _run([CLANG, "-shared", *SAN, "-shared-libsan", "--rtlib=compiler-rt", "-o", lib, *objs, tmp_path / "stub.o", tmp_path / "fatbins.o"])
+    env = dict(os.environ, CHESSVISION_HIP_LIB=str(lib), LD_PRELOAD=str(runtimes[-1]),
+               ASAN_OPTIONS="detect_leaks=0:verify_asan_link_order=0", UBSAN_OPTIONS="print_stacktrace=1")
+    # negative control: the instrumentation is live in THIS library, in THIS process set-up
+    bad = subprocess.run([sys.executable, "-c", f"import ctypes; ctypes.CDLL({str(lib)!r}).cv_stub_selftest_overflow(); print('survived')"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "AddressSanitizer" in bad.stderr and "survived" not in bad.stdout, (bad.stdout, bad.stderr[-1500:])
+    run = subprocess.run([sys.executable, str(ROOT / "tests" / "c_abi" / "engine_host_driver.py")], cwd=ROOT, env=env, capture_output=True,
+                         text=True, timeout=1500)
+    tail = (run.stdout[-2500:], run.stderr[-4000:])
+    assert run.returncode == 0, tail
+    assert "AddressSanitizer" not in run.stderr and "runtime error" not in run.stderr, tail
+    last = run.stdout.strip().splitlines()[-1]
+    assert last.startswith("engine host sanitizers: ok") and "(0 refused)" in last, tail
+    assert run.stdout.count("bilinear=") == 8 and run.stdout.count("single-layer entry points: ok") == 4, tail   # 4 precisions x 2 variants
+    launches = int(last.split("calls, ")[1].split()[0])
+    assert launches > 3000, last
