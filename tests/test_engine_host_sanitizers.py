@@ -1,7 +1,7 @@
 """AddressSanitizer + UndefinedBehaviorSanitizer over the HOST side of the whole library: csrc/ compiled with `--cuda-host-only` (every
 .hip and .cpp unit: launch wrappers, planners, packers, the C ABI) and linked against a stand-in HIP runtime whose "device" memory is
 host memory and whose launches are checked no-ops (tests/c_abi/hip_host_stub.cpp), then driven through the C ABI by
-tests/c_abi/engine_host_driver.py: whole-model loads in four precisions and both UNet variants, forwards around the chunk sizes, the
+tests/c_abi/engine_host_driver.py: whole-model loads in four precisions (both UNet variants in two of them), forwards around the chunk sizes, the
 single-layer entry points, `cv_process_image_v2`, profiling and calibration tables, error paths.  Kernels do not run here -- their parity
 is the GPU suite's business; this is the part of the product a GPU test cannot see into: whether the code AROUND the kernels stays inside
 its buffers.  GPU sanitizers are not available on the pool."""
@@ -67,7 +67,7 @@ def test_host_side_of_the_engine_is_clean_under_asan_and_ubsan(tmp_path):
     assert "AddressSanitizer" not in run.stderr and "runtime error" not in run.stderr, tail
     last = run.stdout.strip().splitlines()[-1]
     assert last.startswith("engine host sanitizers: ok") and "(0 refused)" in last, tail
-    assert run.stdout.count("bilinear=") == 8 and run.stdout.count("single-layer entry points: ok") == 4, tail   # 4 precisions x 2 variants
+    assert run.stdout.count("bilinear=") == 6 and run.stdout.count("single-layer entry points: ok") == 4, tail   # 4 precisions, 2 of them with both UNet variants
     launches = int(last.split("calls, ")[1].split()[0])
     assert launches > 3000, last
 
@@ -90,7 +90,8 @@ def test_host_side_of_the_engine_is_race_free_under_tsan(tmp_path):
     """The round-6 soak (request threads on private and shared engine pairs, batch forwards beside them, engines that are created,
     used and destroyed meanwhile, cache trims) as a C++ program on the stand-in runtime under ThreadSanitizer: every lock, cache and
     table the threads share (engine.h: capture / legacy / load / graph mutexes, the graph graveyard, the block cache, per-engine
-    mutexes, thread-local error strings) without a report.  The full-size run: profiles/r06_tsan_engine_threads.txt."""
+    mutexes, thread-local error strings) without a report.  The suite runs it small (two request threads and the batch thread on ONE engine pair, one engine
+    coming and going: every lock is contended, two model loads instead of nine); the full-size run: profiles/r06_tsan_engine_threads.txt."""
     if not CLANG.exists() or not list(Path("/opt/rocm/lib/llvm/lib/clang").glob("*/lib/linux/libclang_rt.tsan-x86_64.a")):
         pytest.skip("ROCm clang or its ThreadSanitizer runtime is not installed")
     sys.path.insert(0, str(ROOT / "chessvision-3lc_amd"))
@@ -104,11 +105,11 @@ def test_host_side_of_the_engine_is_race_free_under_tsan(tmp_path):
     assert control.returncode == 66 and "ThreadSanitizer: data race" in control.stderr       # the instrumentation is live
     _write_blob(tmp_path / "unet.blob", synthetic.unet_state_dict(1, segmenting=True))
     _write_blob(tmp_path / "resnet.blob", synthetic.resnet18_state_dict(2))
-    run = subprocess.run([str(exe), str(tmp_path / "unet.blob"), str(tmp_path / "resnet.blob"), "40", "1", "1", "2"], env=env, capture_output=True,
+    run = subprocess.run([str(exe), str(tmp_path / "unet.blob"), str(tmp_path / "resnet.blob"), "40", "0", "1", "2"], env=env, capture_output=True,
                          text=True, timeout=1500)
     tail = (run.stdout[-1500:], run.stderr[-5000:])
     assert run.returncode == 0, tail
     assert "ThreadSanitizer" not in run.stderr, tail
     last = run.stdout.strip().splitlines()[-1]
-    assert last.startswith("engine threads:") and last.endswith(" 0 failures") and "3 engines loaded" in last and "2 batch rounds" in last, tail
-    assert int(last.split()[2]) >= 3 * 40, last                        # every request thread served its quota beside the side threads
+    assert last.startswith("engine threads:") and last.endswith(" 0 failures") and "2 engines loaded" in last and "2 batch rounds" in last, tail
+    assert int(last.split()[2]) >= 2 * 40, last                        # both request threads of the shared pair served their quota beside the side threads
