@@ -194,10 +194,34 @@ def main() -> int:
         check(lib, lib.cv_engine_destroy(h), "destroy ops engine")
         print(f"{prec_name:6s} single-layer entry points: ok", flush=True)
 
+    # the block cache: an engine like one that was just destroyed is served entirely from the blocks that one left behind
+    lib.cv_stub_launches.restype = lib.cv_stub_bad_launches.restype = lib.cv_stub_allocations.restype = ctypes.c_long
+
+    def load_and_drop():
+        h = _vp()
+        check(lib, lib.cv_engine_create(0, hb._PRECISIONS["f16x3"], ctypes.byref(h)), "create for the cache")
+        table, cnt, keep = hb._as_param_table(rsd)
+        check(lib, lib.cv_load_resnet18(h, table, cnt), "load for the cache")
+        sq = np.zeros((70, 1, 64, 64), np.float32)
+        out = np.zeros((70, 13), np.float32)
+        check(lib, lib.cv_resnet18_forward(h, ptr(sq), 70, ptr(out), None), "forward for the cache")
+        check(lib, lib.cv_engine_destroy(h), "destroy for the cache")
+
+    load_and_drop()
+    before = lib.cv_stub_allocations()
+    load_and_drop()
+    reused = lib.cv_stub_allocations() - before
+    assert reused == 0, f"{reused} blocks came from the runtime although an identical engine had just been destroyed"
     freed = ctypes.c_size_t(0)
     check(lib, lib.cv_trim_memory(ctypes.byref(freed)), "trim")
     assert freed.value > 0
-    lib.cv_stub_launches.restype = lib.cv_stub_bad_launches.restype = lib.cv_stub_allocations.restype = ctypes.c_long
+    again = ctypes.c_size_t(1)
+    check(lib, lib.cv_trim_memory(ctypes.byref(again)), "second trim")
+    assert again.value == 0
+    before = lib.cv_stub_allocations()
+    load_and_drop()
+    assert lib.cv_stub_allocations() - before > 20                      # ... and after a trim everything comes from the runtime again
+    check(lib, lib.cv_trim_memory(ctypes.byref(freed)), "last trim")
     print(f"engine host sanitizers: ok -- {calls} forward / op calls, {lib.cv_stub_launches()} launches checked "
           f"({lib.cv_stub_bad_launches()} refused), {lib.cv_stub_allocations()} allocations, {freed.value >> 20} MB trimmed", flush=True)
     return 1 if lib.cv_stub_bad_launches() else 0
