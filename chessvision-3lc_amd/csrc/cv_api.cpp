@@ -388,7 +388,7 @@ static int pool_like(cv_engine_t* eng, const float* x, int n, int c, int h, int 
                      void* stream, pool_fn fn, const char* what) {
     Status s = check_engine(eng);
     if (!s.ok()) return finish(s);
-    if (!x || !y || n <= 0 || c <= 0) return finish(fail(CV_ERR_INVALID, std::string(what) + ": bad argument"));
+    if (!x || !y || n <= 0 || c <= 0 || h <= 0 || w_ <= 0 || ho <= 0 || wo <= 0) return finish(fail(CV_ERR_INVALID, std::string(what) + ": bad argument"));
     std::lock_guard<std::mutex> lk(eng->impl.mu);
     DeviceGuard g(eng->impl.device);
     Engine& e = eng->impl;

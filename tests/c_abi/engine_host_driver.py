@@ -183,6 +183,22 @@ def main() -> int:
         lg, mk = np.zeros((2, 1, 32, 32), np.float32), np.zeros((2, 32, 32), np.uint8)
         check(lib, lib.cv_op_outc_1x1(h, ptr(x), 2, 64, 32, 32, w.ctypes.data_as(hb._fp), b.ctypes.data_as(hb._fp), 0.5, ptr(lg), ptr(mk), None), "op_outc")
         assert lib.cv_op_conv2d(h, None, 1, 8, 4, 4, w.ctypes.data_as(hb._fp), 8, 3, 1, None, None, None, 0, ptr(lg), None) == ERR_INVALID
+        # arguments no caller should send come back as a status -- never as a launch with an empty grid or a size computed from them
+        xin, yout, w8 = np.zeros((1, 8, 8, 8), np.float32), np.zeros((1, 8, 16, 16), np.float32), np.zeros((16, 8, 3, 3), np.float32)
+        for (kk, st) in ((2, 1), (5, 1), (3, 0), (0, 1), (-3, 1)):
+            assert lib.cv_op_conv2d(h, ptr(xin), 1, 8, 8, 8, w8.ctypes.data_as(hb._fp), 16, kk, st, None, None, None, 0, ptr(yout), None) == ERR_INVALID, (kk, st)
+        for (hh, ww) in ((0, 8), (8, 0), (-1, 8), (8, -2), (1, 1)):
+            want = ERR_INVALID
+            assert lib.cv_op_conv2d(h, ptr(xin), 1, 8, hh, ww, w8.ctypes.data_as(hb._fp), 16, 3, 1, None, None, None, 0, ptr(yout), None) == (OK if hh > 0 and ww > 0 else want)
+            assert lib.cv_op_maxpool2x2(h, ptr(xin), 1, 8, hh, ww, ptr(yout), None) == want, (hh, ww)                 # 1 x 1: no output pixel
+            assert lib.cv_op_maxpool3x3s2(h, ptr(xin), 1, 8, hh, ww, ptr(yout), None) == (OK if hh > 0 and ww > 0 else want), (hh, ww)
+            assert lib.cv_op_upsample_bilinear2x(h, ptr(xin), 1, 8, hh, ww, ptr(yout), None) == (OK if hh > 0 and ww > 0 else want), (hh, ww)
+        for b in (-1, -2 ** 31):
+            assert lib.cv_softmax13(h, ptr(lg), b, ptr(lg), None) == ERR_INVALID
+        for args in ((0, 16, 16, 3, 8, 8), (1, 0, 16, 3, 8, 8), (1, 16, 16, 3, 0, 8), (-1, 16, 16, 3, 8, 8)):
+            assert lib.cv_resize_area_u8(h, ptr(xin), *args[:4], ptr(yout), args[4], args[5], None) == ERR_INVALID, args
+        assert lib.cv_engine_create(7, prec, ctypes.byref(_vp())) == ERR_INVALID and lib.cv_engine_create(0, 99, ctypes.byref(_vp())) == ERR_INVALID
+        assert lib.cv_engine_destroy(None) == OK
         # byte-path entry points: resize to odd targets, the warp from homographies
         img = rng.integers(0, 256, (3, 480, 640, 3), dtype=np.uint8)
         for (oh, ow) in ((256, 256), (100, 77), (480, 640), (1, 1)):
